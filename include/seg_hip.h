@@ -1,0 +1,193 @@
+/* seg_hip.h -- C-ABI of libseg_hip.so: the MI355X (gfx950) kernels behind the
+ * UNetModel / FCNModel / BaseModel.train_step() / .infer() hot path.
+ *
+ * The reference (nathanin/segmentation) has no FFI boundary of its own: all of
+ * its arithmetic is TensorFlow-1.x / tf.contrib.slim graph ops.  Each entry point
+ * below replaces the TF op(s) invoked at the cited reference site (paths relative
+ * to /root/reference); the Python host (segmentation_amd/) binds them with ctypes.
+ *
+ * Conventions
+ *   - activations NHWC; every activation buffer carries a channel stride `cs`
+ *     (elements per pixel) that is a multiple of 32 with zero-filled pad channels;
+ *   - raw device pointers, int32 dims, `stream` is a hipStream_t passed as void*;
+ *   - returns 0 on success, <0 on error (message: seg_last_error(), thread-local);
+ *   - never allocates, frees or synchronises; safe to capture into a hipGraph;
+ *   - dtype: SEG_F32 (parity mode: f32 storage, exact-f32 MFMA) or SEG_BF16
+ *     (bf16 storage, fp32 accumulate on v_mfma_f32_16x16x32_bf16).
+ */
+#ifndef SEG_HIP_H
+#define SEG_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEG_F32 0
+#define SEG_BF16 1
+
+#define SEG_OK 0
+#define SEG_ERR_ARG (-1)
+#define SEG_ERR_LAUNCH (-2)
+#define SEG_ERR_UNSUPPORTED (-3)
+
+/* A window into an NHWC activation buffer: logical pixel (y,x), channel c lives at
+ * element ((b*H + y+oy)*W + x+ox)*cs + coff + c. */
+typedef struct seg_view {
+  void* ptr;
+  int32_t H, W;      /* buffer spatial extent            */
+  int32_t cs, coff;  /* channel stride / offset (elems)  */
+  int32_t oy, ox;    /* window (crop) origin             */
+  int32_t c;         /* channels used, multiple of 32 (padded) */
+} seg_view;
+
+/* Implicit-GEMM convolution descriptor (forward, dgrad and transposed-conv all run on it).
+ * GEMM view: M = B*Ho*Wo pixels, N = n_count output channels, K = KH*KW*(src0.c+src1.c). */
+typedef struct seg_conv_desc {
+  seg_view src0, src1;     /* src1.ptr==NULL: single input; else channel-concat [src0|src1] by view */
+  int32_t B, Hi, Wi;       /* logical input extent (of the windows above)  */
+  int32_t KH, KW, stride;  /* 3x3/s1, 1x1/s1, 2x2/s2                        */
+  int32_t pad_t, pad_l;    /* zero padding before (VALID: 0; SAME 3x3: 1; dgrad of VALID 3x3: 2) */
+  int32_t Ho, Wo;          /* logical output extent                          */
+  const void* w_packed;    /* [KH*KW][K/32][n_total][32] in `dtype` (seg_pack_weights) */
+  int32_t n_total;         /* rows in the packed weights (multiple of 32)    */
+  int32_t n_off, n_count;  /* this launch computes packed rows [n_off, n_off+n_count) (n_count%32==0) */
+  const float* bias;       /* nullable; bias[j] for j<bias_n, logical index = out channel (mod up_cout if up2) */
+  int32_t bias_n;
+  seg_view dst;            /* out channel j (0-based within this launch) -> dst.coff + j */
+  int32_t up2;             /* 1: 2x2/s2 transposed-conv scatter: packed row n=(a*2+c)*up_cout+co -> dst pixel (2y+a,2x+c) */
+  int32_t up_cout;
+  seg_view mask;           /* nullable ptr: ReLU-grad mask source, same logical extent/channels as dst; out=0 where mask<=0 */
+  int32_t relu;            /* fused ReLU                                     */
+  int32_t out_f32;         /* store float even when dtype==SEG_BF16 (logits)  */
+  int32_t dtype;
+  int32_t cfg;             /* 0 = auto tile choice; else forced config id (tuning/tests) */
+} seg_conv_desc;
+
+/* slim.convolution2d / conv2d_transpose fwd, Conv2DBackpropInput: models/unet.py:111-166,
+ * models/fcn.py:110-128,192,195 (forward); TF autodiff of the same sites (dgrad). */
+int seg_conv2d(const seg_conv_desc* d, void* stream);
+
+/* Filter gradient (Conv2DBackpropFilter) for the same sites.
+ * dw[tap][k][n] (+)= sum_pixels src[b, y*s+u-pad_t, x*s+v-pad_l, k] * dz[b,y,x,n], f32, atomically
+ * accumulated into `dw` which the caller zeroes once per step.  dw layout [KH*KW][k_logical][n_logical]
+ * (= TF HWIO for conv; = TF [kh,kw,Cout,Cin] for the transposed conv when src:=dz_big, dz:=x_small).
+ * k_logical maps padded concat channels back to logical ones via (src0_clog, src1_clog). */
+typedef struct seg_wgrad_desc {
+  seg_view src0, src1;
+  int32_t src0_clog, src1_clog;   /* logical (unpadded) channels of each source */
+  int32_t B, Hi, Wi;
+  int32_t KH, KW, stride, pad_t, pad_l;
+  int32_t Ho, Wo;
+  seg_view dz;                    /* [B,Ho,Wo,n] window; dz.c = padded n */
+  int32_t n_log;                  /* logical n (columns of dw)            */
+  float* dw;
+  int32_t dtype;
+  int32_t cfg;
+} seg_wgrad_desc;
+int seg_conv2d_wgrad(const seg_wgrad_desc* d, void* stream);
+
+/* First layer (Cin = input_channel <= 4, never padded to 32): models/unet.py:111-116 conv1_1,
+ * models/fcn.py:110-115 conv1.  x is float32 NHWC [B,H,W,cin] dense. */
+int seg_conv_first_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin,
+                       const float* w_hwio, const float* bias, int32_t cout, int32_t pad,
+                       const seg_view* dst, int32_t Ho, int32_t Wo, int32_t relu, int32_t dtype, void* stream);
+int seg_conv_first_wgrad(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin,
+                         const seg_view* dz, int32_t Ho, int32_t Wo, int32_t cout, int32_t pad,
+                         float* dw_hwio, int32_t dtype, void* stream);
+
+/* slim.max_pool2d(x, 2) (kernel 2, stride 2, VALID): models/unet.py:120,124,128,132; models/fcn.py:116-126.
+ * idx (nullable): uint8 plane [B,Ho,Wo,C] with the first-max position 0..3 in window order. */
+int seg_maxpool2x2_fwd(const seg_view* src, const seg_view* dst, uint8_t* idx,
+                       int32_t B, int32_t Ho, int32_t Wo, int32_t C, int32_t dtype, void* stream);
+/* MaxPoolGrad fused with (a) the zero-padded add of a skip-connection gradient (crop grad,
+ * models/unet.py:139-141 backward) and (b) the ReLU-grad mask of the producing conv:
+ *   dz[y,x,c] = ( route(dpool)[y,x,c] + (in window ? add[y-ay, x-ax, c] : 0) ) * (y_act[y,x,c] > 0)
+ * over the full H x W extent of y_act (odd trailing row/col get only the add term).
+ * Routing recomputes the first maximum of each window from y_act (bit-identical to an index plane).
+ * dpool nullable (then only the add term), add nullable. */
+int seg_maxpool2x2_bwd(const seg_view* y_act, const seg_view* dpool, const seg_view* add,
+                       int32_t add_h, int32_t add_w, int32_t add_y0, int32_t add_x0,
+                       const seg_view* dz, int32_t B, int32_t H, int32_t W, int32_t C,
+                       int32_t dtype, void* stream);
+
+/* Per-pixel softmax cross-entropy + its gradient: models/basemodel.py:59-70 (spec), :194, :360.
+ * logits: float32 view; labels: uint8 [B,LH,LW] read at (y+ly0, x+lx0) (centre crop of input_y,
+ * models/unet.py:171-174).  loss_sum += sum_pixels xent * inv_n (atomic, caller zeroes);
+ * dlogits (dtype view, padded channels written as 0) = (softmax - onehot) * inv_n * grad_scale. */
+int seg_softmax_xent(const seg_view* logits, const uint8_t* labels, int32_t LH, int32_t LW,
+                     int32_t ly0, int32_t lx0, int32_t B, int32_t H, int32_t W, int32_t n_classes,
+                     float inv_n, float grad_scale, float* loss_sum, const seg_view* dlogits,
+                     int32_t dtype, void* stream);
+
+/* tf.nn.sigmoid + tf.argmax(axis=3) + expand_dims + cast: models/unet.py:75-79, models/fcn.py:74-78.
+ * sig: dense float32 [B,H,W,n_classes]; out: dense float32 [B,H,W,1]; argmax taken over the float32
+ * sigmoid values, first maximum wins. */
+int seg_sigmoid_argmax(const seg_view* logits, int32_t B, int32_t H, int32_t W, int32_t n_classes,
+                       float* sig, float* out, void* stream);
+
+/* BiasAddGrad: db[c] += sum over B*H*W of dz[...,c] for c < n_log (atomic f32). */
+int seg_bias_grad(const seg_view* dz, int32_t B, int32_t H, int32_t W, int32_t n_log, float* db,
+                  int32_t dtype, void* stream);
+
+/* tf.train.AdamOptimizer(lr, name='segAdam') on one flat fp32 parameter arena: models/basemodel.py:321,366.
+ * TF variant: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * p -= lr_t * m / (sqrt(v) + eps)   (eps OUTSIDE the bias correction).
+ * t = *step_dev + 1 is read on the device (so a captured hipGraph replays with the live step);
+ * g is multiplied by grad_scale first (1/world for data-parallel averaging). */
+int seg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+             float eps, float grad_scale, const int64_t* step_dev, void* stream);
+/* global_step assign_add 1: models/basemodel.py:88-89,368. */
+int seg_step_increment(int64_t* step_dev, void* stream);
+
+/* Weight re-layout (+cast) from the fp32 TF-layout master copy into the packed MFMA operand layout
+ * [taps][K/32][n_total][32].  One launch handles a whole table of layers. */
+#define SEG_PACK_CONV_FWD 0   /* src HWIO [kh,kw,Cin,Cout]: K=cin(padded concat), N=cout               */
+#define SEG_PACK_CONV_DGRAD 1 /* src HWIO: taps flipped, K=cout, N=cin(padded concat)                  */
+#define SEG_PACK_UP_FWD 2     /* src [2,2,Cout,Cin]: taps=1, K=cin, N=(a*2+c)*cout_pad+co               */
+#define SEG_PACK_UP_DGRAD 3   /* src [2,2,Cout,Cin]: taps=4 (a,c), K=cout, N=cin                        */
+typedef struct seg_pack_entry {
+  int64_t src_off;      /* element offset into the fp32 arena              */
+  int64_t dst_off;      /* element offset into the packed arena            */
+  int32_t mode;
+  int32_t KH, KW;
+  int32_t cin, cout;    /* logical sizes of the source tensor              */
+  int32_t seg0_c, seg0_cp, seg1_c, seg1_cp; /* cin concat segments: logical / padded widths (seg1 may be 0) */
+  int32_t cout_pad;
+  int32_t k_pad, n_total; /* packed K (multiple of 32) and N                */
+  int64_t n_elems;      /* taps*k_pad*n_total                              */
+  int64_t blk_start;    /* first 256-element block of this entry in the launch */
+} seg_pack_entry;
+int seg_pack_weights(const float* arena, void* packed, const seg_pack_entry* table_dev, int32_t n_entries,
+                     int64_t total_blocks, int32_t dtype, void* stream);
+
+/* Depthwise bilinear transposed conv = tf.nn.conv2d_transpose(x, bilinear_upsample_weights(f,C), SAME)
+ * (models/fcn.py:199-216; filter bank utils/upsampling.py:27-46, channel-diagonal => depthwise),
+ * fused with the following resize_image_with_crop_or_pad and skip addition:
+ *   dst[y,x,c] = (add? add[y,x,c] : 0) + up(src)[y+cy, x+cx, c]   (0 outside the upsampled extent)
+ * filt: float32 [k][k] tent (k = 2f - f%2), pad_before = (k-f)/2.  bwd is the adjoint wrt src. */
+int seg_bilinear_up_fwd(const seg_view* src, int32_t Hs, int32_t Ws, int32_t factor, const float* filt,
+                        const seg_view* add, const seg_view* dst, int32_t Hd, int32_t Wd,
+                        int32_t cy, int32_t cx, int32_t B, int32_t C, int32_t dst_f32, int32_t dtype, void* stream);
+int seg_bilinear_up_bwd(const seg_view* ddst, int32_t Hd, int32_t Wd, int32_t cy, int32_t cx,
+                        int32_t factor, const float* filt, const seg_view* dsrc, int32_t Hs, int32_t Ws,
+                        int32_t B, int32_t C, int32_t ddst_f32, int32_t dtype, void* stream);
+
+/* out = a * (relu_mask>0) elementwise over a [B,H,W,C] window (ReLU-grad where no conv epilogue can do it). */
+int seg_relu_grad(const seg_view* dy, const seg_view* y_act, const seg_view* dz,
+                  int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+
+/* slim.dropout-style mask: y = x * Bernoulli(keep)/keep, counter-based RNG (seed, offset); build-defined
+ * placement.  Same call regenerates the same mask (used by bwd). */
+int seg_dropout(const seg_view* x, const seg_view* y, int32_t B, int32_t H, int32_t W, int32_t C,
+                float keep, uint64_t seed, uint64_t offset, int32_t dtype, void* stream);
+
+/* float32 NHWC -> dtype NHWC with channel padding (feeding placeholder inputs). */
+int seg_cast_pad(const float* x, int64_t npix, int32_t c, const seg_view* dst_dense, int32_t dtype, void* stream);
+
+const char* seg_last_error(void);
+int seg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,101 @@
+"""ctypes binding of libseg_hip.so (C-ABI in include/seg_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails this module
+raises.  Nothing here imports the oracle."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libseg_hip.so')
+
+SEG_F32, SEG_BF16 = 0, 1
+PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_UP_FWD, PACK_UP_DGRAD = 0, 1, 2, 3
+
+
+class SegError(RuntimeError):
+    pass
+
+
+class View(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('H', C.c_int32), ('W', C.c_int32), ('cs', C.c_int32), ('coff', C.c_int32),
+                ('oy', C.c_int32), ('ox', C.c_int32), ('c', C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('src0', View), ('src1', View), ('B', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32),
+                ('KH', C.c_int32), ('KW', C.c_int32), ('stride', C.c_int32), ('pad_t', C.c_int32), ('pad_l', C.c_int32),
+                ('Ho', C.c_int32), ('Wo', C.c_int32), ('w_packed', C.c_void_p), ('n_total', C.c_int32),
+                ('n_off', C.c_int32), ('n_count', C.c_int32), ('bias', C.c_void_p), ('bias_n', C.c_int32),
+                ('dst', View), ('up2', C.c_int32), ('up_cout', C.c_int32), ('mask', View), ('relu', C.c_int32),
+                ('out_f32', C.c_int32), ('dtype', C.c_int32), ('cfg', C.c_int32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [('src0', View), ('src1', View), ('src0_clog', C.c_int32), ('src1_clog', C.c_int32),
+                ('B', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32),
+                ('stride', C.c_int32), ('pad_t', C.c_int32), ('pad_l', C.c_int32), ('Ho', C.c_int32), ('Wo', C.c_int32),
+                ('dz', View), ('n_log', C.c_int32), ('dw', C.c_void_p), ('dtype', C.c_int32), ('cfg', C.c_int32)]
+
+
+class PackEntry(C.Structure):
+    _fields_ = [('src_off', C.c_int64), ('dst_off', C.c_int64), ('mode', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32),
+                ('cin', C.c_int32), ('cout', C.c_int32), ('seg0_c', C.c_int32), ('seg0_cp', C.c_int32),
+                ('seg1_c', C.c_int32), ('seg1_cp', C.c_int32), ('cout_pad', C.c_int32), ('k_pad', C.c_int32),
+                ('n_total', C.c_int32), ('n_elems', C.c_int64), ('blk_start', C.c_int64)]
+
+
+i32, i64, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
+PV = C.POINTER(View)
+
+# name -> argtypes (restype is always int except the two getters); mirrors include/seg_hip.h
+SIGNATURES = {
+    'seg_conv2d': [C.POINTER(ConvDesc), vp],
+    'seg_conv2d_wgrad': [C.POINTER(WgradDesc), vp],
+    'seg_conv_first_fwd': [vp, i32, i32, i32, i32, vp, vp, i32, i32, PV, i32, i32, i32, i32, vp],
+    'seg_conv_first_wgrad': [vp, i32, i32, i32, i32, PV, i32, i32, i32, i32, vp, i32, vp],
+    'seg_maxpool2x2_fwd': [PV, PV, vp, i32, i32, i32, i32, i32, vp],
+    'seg_maxpool2x2_bwd': [PV, PV, PV, i32, i32, i32, i32, PV, i32, i32, i32, i32, i32, vp],
+    'seg_softmax_xent': [PV, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, PV, i32, vp],
+    'seg_sigmoid_argmax': [PV, i32, i32, i32, i32, vp, vp, vp],
+    'seg_bias_grad': [PV, i32, i32, i32, i32, vp, i32, vp],
+    'seg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp],
+    'seg_step_increment': [vp, vp],
+    'seg_pack_weights': [vp, vp, vp, i32, i64, i32, vp],
+    'seg_bilinear_up_fwd': [PV, i32, i32, i32, vp, PV, PV, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    'seg_bilinear_up_bwd': [PV, i32, i32, i32, i32, i32, vp, PV, i32, i32, i32, i32, i32, i32, vp],
+    'seg_relu_grad': [PV, PV, PV, i32, i32, i32, i32, i32, vp],
+    'seg_dropout': [PV, PV, i32, i32, i32, i32, f32, u64, u64, i32, vp],
+    'seg_cast_pad': [vp, i64, i32, PV, i32, vp],
+}
+
+_lib = None
+
+
+def load():
+    """Loads the library (once).  Raises SegError if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SegError('libseg_hip.so not found at %s: run `python -c "import __graft_entry__ as g; g.build()"` '
+                       '(the HIP extension is mandatory; there is no CPU fallback)' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.seg_last_error.restype = C.c_char_p
+    lib.seg_last_error.argtypes = []
+    lib.seg_version.restype = C.c_int
+    lib.seg_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise SegError('%s failed (%d): %s' % (what, rc, load().seg_last_error().decode()))
+
+
+def null_view():
+    return View(None, 0, 0, 0, 0, 0, 0, 0)

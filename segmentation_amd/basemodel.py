@@ -1,0 +1,313 @@
+"""BaseModel: the train_step / test / snapshot / infer surface of the reference
+(/root/reference/models/basemodel.py:8-79, 477-531), driving HIP launch plans instead of a
+tf.Session.  The constructor keyword set and method names are the reference's; the extra
+keyword-only knobs (dtype, use_graph, crop_aware, device, process_group, seed) default to values
+that need no change in a driver script.
+
+Where the reference is broken at HEAD the *intended* behaviour is implemented:
+train_step() = one fwd + mean softmax x-entropy + bwd + TF-Adam step + global_step += 1
+(models/basemodel.py:480-489, commented body); the loss is logged from the training pass.
+"""
+import glob
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import engine as E
+from . import dist as D
+
+
+class BaseModel(object):
+    def __init__(self,
+                 sess,
+                 mode='TRAINING',
+                 log_dir='./logs',
+                 dataset=None,
+                 test_dataset=None,
+                 bayesian=False,
+                 save_dir='./snapshot',
+                 n_classes=None,
+                 input_dims=None,
+                 input_channel=3,
+                 autoencoder=False,
+                 load_snapshot=True,
+                 learning_rate=1e-3,
+                 load_snapshot_from=None,
+                 adversarial_training=False,
+                 dtype='bf16', use_graph=True, crop_aware=True, device=None, process_group=None, seed=5555,
+                 overlap_allreduce=True):
+        self.mode = mode
+        self.log_dir = log_dir
+        self.dataset = dataset
+        self.test_dataset = test_dataset
+        self.save_dir = save_dir
+        self.bayesian = bayesian
+        self.n_classes = n_classes
+        self.autoencoder = autoencoder
+        self.learning_rate = learning_rate
+        self.input_channel = input_channel
+        self.adversarial_training = adversarial_training
+        if adversarial_training:
+            # broken at HEAD in the reference and out of scope for the hot path
+            raise Exception('adversarial_training is not supported by the MI355X hot path')
+        if autoencoder:
+            raise Exception('autoencoder mode is not supported by the MI355X hot path')
+        if isinstance(input_dims, int):            # F6: the reference default is an int
+            input_dims = [input_dims, input_dims]
+        self.input_dims = list(input_dims) if input_dims is not None else None
+        if self.mode == 'INFERENCE':
+            # F8: the reference dereferences dataset.batch_size with dataset=None; take it from the input instead
+            self.batch_size = dataset.batch_size if dataset is not None else None
+        else:
+            if dataset is None:
+                raise Exception('TRAINING mode needs a dataset (batch_size, get_batch)')
+            self.batch_size = self.dataset.batch_size
+
+        self.IN_OUT_EQUAL = False
+        self.IN_OUT_CROP = False
+        self.IN_OUT_RATIO = False
+        self.load_snapshot = load_snapshot if load_snapshot else False
+        if self.mode == 'INFERENCE':
+            self.load_snapshot = True
+        self.load_snapshot_from = load_snapshot_from if load_snapshot_from else False
+        self.summary_iter = 25
+
+        # ---- MI355X runtime ----
+        if not torch.cuda.is_available():
+            raise L.SegError('no GPU visible: the segmentation hot path runs only on HIP devices (no CPU fallback)')
+        self.lib = L.load()
+        self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self.dtype_name = dtype
+        self.dtype = {'bf16': L.SEG_BF16, 'f32': L.SEG_F32, 'fp32': L.SEG_F32}[dtype]
+        self.use_graph = use_graph
+        self.crop_aware = crop_aware
+        self.seed = seed
+        self.pg = D.DataParallel(process_group, overlap=overlap_allreduce)
+        self._graphs = {}
+        self._infer_cache = {}
+        self.sess = sess
+        self._gs_host = 0
+        self.last_loss_dev = None
+        self.last_test_loss = None
+        self._summary_fh = None
+        self._init_session(sess)
+
+    # ------------------------------------------------------------------ setup
+    def _init_session(self, sess):
+        self.sess = sess
+        if self.mode == 'INFERENCE':
+            return
+        if hasattr(self.dataset, 'set_tf_sess'):
+            self.dataset.set_tf_sess(self.sess)
+        if self.log_dir is not None:
+            os.makedirs(self.log_dir, exist_ok=True)
+            self._summary_fh = open(os.path.join(self.log_dir, 'summary.jsonl'), 'a')
+
+    @property
+    def global_step(self):
+        return self._gs_host
+
+    def _init_input(self):
+        """Static device-resident input buffers (the reference binds dataset.image_op / mask_op or a
+        feed placeholder: models/basemodel.py:145-177)."""
+        if self.mode == 'INFERENCE':
+            return
+        if not getattr(self.dataset, 'has_masks', False):      # F5: intended self.dataset.has_masks
+            raise Exception('No dataset.mask_op found. Is it ImageMaskDataSet?')
+        B, (H, W), Cin = self.batch_size, self.input_dims, self.input_channel
+        self.input_x = torch.zeros((B, H, W, Cin), dtype=torch.float32, device=self.device)
+        self.input_y = torch.zeros((B, H, W), dtype=torch.uint8, device=self.device)
+        self._pin_x = torch.zeros((B, H, W, Cin), dtype=torch.float32).pin_memory()
+        self._pin_y = torch.zeros((B, H, W), dtype=torch.uint8).pin_memory()
+
+    def _init_saver(self, name='model'):
+        if self.save_dir is None:
+            self.save_path = None
+            return
+        os.makedirs(self.save_dir, exist_ok=True)
+        self.save_path = os.path.join(self.save_dir, '{}.ckpt'.format(name))
+        if self.load_snapshot:
+            try:
+                path = self.load_snapshot_from if self.load_snapshot_from else self._latest_checkpoint()
+                self.restore(path)
+                print('Success! Resuming from global step {}'.format(self.global_step))
+            except Exception as e:           # the reference swallows restore failures (basemodel.py:120-134)
+                print('Failed to load snapshot; proceed with training ({})'.format(e))
+        else:
+            print('Training from scratch. Set load_snapshot = True to resume training.')
+
+    def _latest_checkpoint(self):
+        cands = glob.glob(self.save_path + '-*.npz')
+        if not cands:
+            raise IOError('no checkpoint under %s' % self.save_dir)
+        return max(cands, key=lambda p: int(p.rsplit('-', 1)[1].split('.')[0]))
+
+    # ------------------------------------------------------------------ data
+    def _load_batch(self, dataset, x_dev, y_dev):
+        """Device-resident datasets hand over tensors; host datasets go through pinned staging buffers
+        and an async copy on the compute stream (the loader's ring of pinned buffers is in datasets.py)."""
+        if hasattr(dataset, 'get_device_batch'):
+            x, y = dataset.get_device_batch()
+            x_dev.copy_(x.reshape(x_dev.shape), non_blocking=True)
+            y_dev.copy_(y.reshape(y_dev.shape), non_blocking=True)
+            return
+        img, mask = dataset.get_batch()
+        self._pin_x.copy_(torch.from_numpy(np.ascontiguousarray(img, np.float32)).reshape(self._pin_x.shape))
+        self._pin_y.copy_(torch.from_numpy(np.ascontiguousarray(mask, np.uint8)).reshape(self._pin_y.shape))
+        x_dev.copy_(self._pin_x, non_blocking=True)
+        y_dev.copy_(self._pin_y, non_blocking=True)
+
+    # ------------------------------------------------------------------ hot loop
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _run_fwd_bwd(self):
+        s = self._stream()
+        self.store.g.zero_()
+        self.loss_buf.zero_()
+        self.fwd_plan.run(s)
+        self.bwd_plan.run(s)
+
+    def _run_update(self):
+        self.upd_plan.run(self._stream())
+
+    def _replay(self, key, fn):
+        """Runs fn eagerly once (warm-up), then captures it into a hipGraph and replays the graph."""
+        if not self.use_graph:
+            fn()
+            return
+        g = self._graphs.get(key)
+        if g is None:
+            fn()                                   # eager warm-up (lazy kernel attribute setup, allocator)
+            torch.cuda.synchronize(self.device)
+            self._graphs[key] = 'warm'
+            return
+        if g == 'warm':
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    fn()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            self._graphs[key] = graph
+            graph.replay()
+            return
+        g.replay()
+
+    def train_step(self):
+        """One optimisation step (intended body of models/basemodel.py:477-489)."""
+        if self.mode == 'INFERENCE':
+            raise Exception('train_step() with INFERENCE mode invalid')
+        self._load_batch(self.dataset, self.input_x, self.input_y)
+        if self.pg.world == 1:
+            self._replay('step', lambda: (self._run_fwd_bwd(), self._run_update()))
+        else:
+            self._train_step_dp()
+        self._gs_host += 1
+        self.last_loss_dev = self.loss_buf
+
+    def _train_step_dp(self):
+        """Data-parallel step: backward is cut into segments at gradient-bucket boundaries; each finished
+        bucket (a contiguous slice of the flat gradient arena) is all-reduced on RCCL's stream while
+        the next segment's dgrad/wgrad kernels run; Adam runs after the last bucket lands."""
+        s = self._stream()
+
+        def head():
+            self.store.g.zero_(); self.loss_buf.zero_()
+            self.fwd_plan.run(self._stream())
+            self.bwd_segments[0][0].run(self._stream())
+        self._replay('dp0', head)
+        self.pg.all_reduce_bucket(self.store.g, *self.bwd_segments[0][1])
+        for i, (plan, (lo, hi)) in enumerate(self.bwd_segments[1:], 1):
+            self._replay('dp%d' % i, lambda plan=plan: plan.run(self._stream()))
+            self.pg.all_reduce_bucket(self.store.g, lo, hi)
+        self.pg.wait_all()
+        self._replay('upd', self._run_update)
+
+    def last_loss(self):
+        """Mean x-entropy of the most recent train_step (synchronises)."""
+        return float(self.loss_buf.item())
+
+    def write_summary(self, op=None, feed_dict=None):
+        if self._summary_fh is not None:
+            rec = {'global_step': self.global_step, 'time': time.time()}
+            if isinstance(op, dict):
+                rec.update(op)
+            self._summary_fh.write(json.dumps(rec) + '\n')
+            self._summary_fh.flush()
+
+    def test(self):
+        """Forward on a held-out batch, report mean x-entropy (models/basemodel.py:420-421, 506-518)."""
+        if self.mode == 'INFERENCE':
+            print('test() with INFERENCE mode invalid')
+            return
+        ds = self.test_dataset if self.test_dataset is not None else self.dataset
+        self._load_batch(ds, self.input_x, self.input_y)
+        self.loss_buf.zero_()
+        self.fwd_plan.run(self._stream())
+        self.last_test_loss = float(self.loss_buf.item())
+        print('TEST LOSS', self.last_test_loss, self.global_step)
+        self.write_summary({'test_loss': self.last_test_loss})
+
+    # ------------------------------------------------------------------ checkpoints
+    def snapshot(self):
+        if self.mode == 'INFERENCE':
+            print('snapshot() with INFERENCE mode invalid')
+            return
+        gs = self.global_step
+        path = '{}-{}.npz'.format(self.save_path, gs)
+        print('Global step {}, snapshotting to {}'.format(gs, path))
+        if self.pg.rank != 0:
+            return
+        blob = {'global_step': np.int64(gs), 'p': self.store.p.cpu().numpy(), 'm': self.store.m.cpu().numpy(),
+                'v': self.store.v.cpu().numpy()}
+        for name, l in self.store.layers.items():     # named views for interchange: <scope>/weights, <scope>/biases
+            blob[name + '/weights'] = blob['p'][l.w_off:l.w_off + l.wsize].reshape(l.wshape)
+            blob[name + '/biases'] = blob['p'][l.b_off:l.b_off + l.cout]
+        np.savez(path, **blob)
+        for old in glob.glob(self.save_path + '-*.npz'):      # tf.train.Saver(max_to_keep=1)
+            if old != path:
+                os.remove(old)
+
+    def restore(self, path):
+        z = np.load(path)
+        params = {n: {'weights': z[n + '/weights'], 'biases': z[n + '/biases']} for n in self.store.layers}
+        self.store.set_params(params)
+        if self.store.training and 'm' in z and z['m'].shape[0] == self.store.n:
+            self.store.m.copy_(torch.from_numpy(z['m']))
+            self.store.v.copy_(torch.from_numpy(z['v']))
+        self._gs_host = int(z['global_step'])
+        self.store.step.fill_(self._gs_host)
+        self._repack()
+
+    def _repack(self):
+        p = E.Plan('pack')
+        self.net.pack(p)
+        p.run(self._stream())
+        torch.cuda.synchronize(self.device)
+
+    def set_weights(self, params):
+        """Load {scope: {'weights','biases'}} in TF layouts (tests / interchange)."""
+        self.store.set_params(params)
+        self._repack()
+
+    # ------------------------------------------------------------------ inference
+    def infer(self, imgs):
+        """imgs: float32 ndarray [B,H,W,C] -> [sigmoid(logits) [B,h,w,n_classes], float32 argmax [B,h,w,1]]
+        (models/basemodel.py:527-531; inference_ops of models/unet.py:75-79)."""
+        imgs = np.ascontiguousarray(imgs, np.float32)
+        key = tuple(imgs.shape)
+        ent = self._infer_cache.get(key)
+        if ent is None:
+            ent = self._build_infer(*imgs.shape)
+            self._infer_cache[key] = ent
+        plan, x_in, sig, out = ent
+        x_in.copy_(torch.from_numpy(imgs), non_blocking=False)
+        plan.run(self._stream())
+        torch.cuda.synchronize(self.device)
+        return [sig.cpu().numpy(), out.cpu().numpy()]

@@ -1,0 +1,148 @@
+// conv_first.hip -- the first 3x3 conv of each model (Cin = input_channel <= 4, K = 9*Cin <= 36).
+// /root/reference/models/unet.py:111-116 (conv1_1, VALID) and models/fcn.py:110-115 (conv1, SAME).
+// With K = 27 an MFMA tile would be >50 % padding and the layer is HBM-bound on its 32-channel
+// output anyway (25 FLOP/B), so it runs on the vector ALU: one thread per output pixel, 32 output
+// channels in registers, filters broadcast from LDS, 64-byte-per-lane coalesced stores.
+#include "common.h"
+
+namespace {
+
+constexpr int FT = 16;                     // 16x16 output pixels per workgroup
+constexpr int FP = FT + 2;                 // patch edge
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* x, int B, int H, int W, int cin, const float* w,
+                                                             const float* bias, int cout, int pad, seg_view dst, int Ho, int Wo,
+                                                             int relu, int tiles_x, int tiles_y) {
+  __shared__ float sx[FP * FP * 4];
+  __shared__ __attribute__((aligned(16))) float sw[36 * 32];
+  __shared__ float sb[32];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y; const int b = t / tiles_y;
+  const int co0 = blockIdx.y * 32;
+  const int oy0 = ty * FT, ox0 = tx * FT;
+  for (int i = tid; i < FP * FP * cin; i += 256) {
+    const int c = i % cin, q = i / cin;
+    const int iy = oy0 - pad + q / FP, ix = ox0 - pad + q % FP;
+    sx[q * 4 + c] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((int64_t)b * H + iy) * W + ix) * cin + c] : 0.f;
+  }
+  for (int i = tid; i < 9 * cin * 32; i += 256) {
+    const int co = i % 32, k = i / 32;            // k = tap*cin + c
+    sw[k * 32 + co] = (co0 + co < cout) ? w[(int64_t)k * cout + co0 + co] : 0.f;
+  }
+  if (tid < 32) sb[tid] = (bias && co0 + tid < cout) ? bias[co0 + tid] : 0.f;
+  __syncthreads();
+  const int py = tid / FT, px = tid % FT;
+  float acc[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) acc[c] = sb[c];
+  for (int u = 0; u < 3; ++u)
+    for (int v = 0; v < 3; ++v)
+      for (int c = 0; c < cin; ++c) {
+        const float xv = sx[((py + u) * FP + px + v) * 4 + c];
+        const f32x4* wr = reinterpret_cast<const f32x4*>(sw + ((u * 3 + v) * cin + c) * 32);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const f32x4 ww = wr[q];
+          acc[q * 4 + 0] += xv * ww[0]; acc[q * 4 + 1] += xv * ww[1]; acc[q * 4 + 2] += xv * ww[2]; acc[q * 4 + 3] += xv * ww[3];
+        }
+      }
+  const int oy = oy0 + py, ox = ox0 + px;
+  if (oy < Ho && ox < Wo) {
+    T* o = reinterpret_cast<T*>(dst.ptr) + view_off(dst, b, oy, ox) + co0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      Vec8<T> ov;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { float r = acc[q * 8 + e]; if (relu) r = fmaxf(r, 0.f); ov.set(e, r); }
+      ov.store(o + q * 8);
+    }
+  }
+}
+
+// dW[u,v,c,co] += sum_pixels x[b, y+u-pad, x+v-pad, c] * dz[b,y,x,co].
+// Thread (k = tid/8 -> (tap, c), co4 = (tid%8)*4) owns 4 outputs and walks the tile's 256 pixels from LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* x, int B, int H, int W, int cin, seg_view dz, int Ho, int Wo,
+                                                               int cout, int pad, float* dw, int tiles_x, int tiles_y, int ntiles) {
+  __shared__ float sx[FP * FP * 4];
+  __shared__ __attribute__((aligned(16))) float sz[256 * 36];     // [pixel][32 co] padded to 36
+  const int tid = threadIdx.x;
+  const int co0 = blockIdx.y * 32;
+  const int k = tid / 8, co4 = (tid % 8) * 4;
+  const int nk = 9 * cin;
+  const int tap = k / cin, c = k % cin;
+  const int u = tap / 3, v = tap % 3;
+  f32x4 acc = {0, 0, 0, 0};
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; const int b = t / tiles_y;
+    const int oy0 = ty * FT, ox0 = tx * FT;
+    __syncthreads();
+    for (int i = tid; i < FP * FP * cin; i += 256) {
+      const int cc = i % cin, q = i / cin;
+      const int iy = oy0 - pad + q / FP, ix = ox0 - pad + q % FP;
+      sx[q * 4 + cc] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((int64_t)b * H + iy) * W + ix) * cin + cc] : 0.f;
+    }
+    {
+      const int py = tid / FT, px = tid % FT;
+      const int oy = oy0 + py, ox = ox0 + px;
+      const bool ok = oy < Ho && ox < Wo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Vec8<T> zv; zv.zero();
+        if (ok) zv.load(reinterpret_cast<const T*>(dz.ptr) + view_off(dz, b, oy, ox) + co0 + q * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sz[tid * 36 + q * 8 + e] = zv.get(e);
+      }
+    }
+    __syncthreads();
+    if (k < nk) {
+      for (int p = 0; p < 256; ++p) {
+        const float xv = sx[((p / FT + u) * FP + (p % FT) + v) * 4 + c];
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(sz + p * 36 + co4);
+        acc[0] += xv * zz[0]; acc[1] += xv * zz[1]; acc[2] += xv * zz[2]; acc[3] += xv * zz[3];
+      }
+    }
+  }
+  if (k < nk) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (co0 + co4 + e < cout) atomicAdd(dw + (int64_t)k * cout + co0 + co4 + e, acc[e]);
+  }
+}
+
+}  // namespace
+
+extern "C" int seg_conv_first_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const float* w_hwio, const float* bias,
+                                  int32_t cout, int32_t pad, const seg_view* dst, int32_t Ho, int32_t Wo, int32_t relu, int32_t dtype,
+                                  void* stream) {
+  if (!x || !w_hwio || !dst || !dst->ptr || cin < 1 || cin > 4 || cout < 1 || B <= 0) { seg_set_error("conv_first_fwd: bad args (cin must be 1..4)"); return SEG_ERR_ARG; }
+  const int cp = cdiv(cout, 32) * 32;
+  if (dst->oy + Ho > dst->H || dst->ox + Wo > dst->W || dst->coff + cp > dst->cs || dst->cs % 8 || dst->coff % 8) { seg_set_error("conv_first_fwd: destination window exceeds buffer"); return SEG_ERR_ARG; }
+  if (Ho != H + 2 * pad - 2 || Wo != W + 2 * pad - 2) { seg_set_error("conv_first_fwd: inconsistent output extent"); return SEG_ERR_ARG; }
+  const int tiles_x = cdiv(Wo, FT), tiles_y = cdiv(Ho, FT);
+  dim3 grid(B * tiles_x * tiles_y, cp / 32);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SEG_F32) hipLaunchKernelGGL(conv_first_fwd_kernel<float>, grid, dim3(256), 0, st, x, B, H, W, cin, w_hwio, bias, cout, pad, *dst, Ho, Wo, relu, tiles_x, tiles_y);
+  else if (dtype == SEG_BF16) hipLaunchKernelGGL(conv_first_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, x, B, H, W, cin, w_hwio, bias, cout, pad, *dst, Ho, Wo, relu, tiles_x, tiles_y);
+  else { seg_set_error("conv_first_fwd: bad dtype"); return SEG_ERR_ARG; }
+  return seg_check_launch("conv_first_fwd");
+}
+
+extern "C" int seg_conv_first_wgrad(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const seg_view* dz, int32_t Ho, int32_t Wo,
+                                    int32_t cout, int32_t pad, float* dw_hwio, int32_t dtype, void* stream) {
+  if (!x || !dw_hwio || !dz || !dz->ptr || cin < 1 || cin > 3 || cout < 1 || B <= 0) { seg_set_error("conv_first_wgrad: bad args (cin must be 1..3)"); return SEG_ERR_ARG; }
+  const int cp = cdiv(cout, 32) * 32;
+  if (dz->oy + Ho > dz->H || dz->ox + Wo > dz->W || dz->coff + cp > dz->cs || dz->cs % 8 || dz->coff % 8) { seg_set_error("conv_first_wgrad: dz window exceeds buffer"); return SEG_ERR_ARG; }
+  const int tiles_x = cdiv(Wo, FT), tiles_y = cdiv(Ho, FT), ntiles = B * tiles_x * tiles_y;
+  dim3 grid(ntiles < 1024 ? ntiles : 1024, cp / 32);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SEG_F32) hipLaunchKernelGGL(conv_first_wgrad_kernel<float>, grid, dim3(256), 0, st, x, B, H, W, cin, *dz, Ho, Wo, cout, pad, dw_hwio, tiles_x, tiles_y, ntiles);
+  else if (dtype == SEG_BF16) hipLaunchKernelGGL(conv_first_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, x, B, H, W, cin, *dz, Ho, Wo, cout, pad, dw_hwio, tiles_x, tiles_y, ntiles);
+  else { seg_set_error("conv_first_wgrad: bad dtype"); return SEG_ERR_ARG; }
+  return seg_check_launch("conv_first_wgrad");
+}

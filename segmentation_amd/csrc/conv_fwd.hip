@@ -1,0 +1,301 @@
+// conv_fwd.hip -- NHWC implicit-GEMM convolution on MFMA, LDS-staged input patch + filter rows.
+//
+// One kernel template serves: 3x3 / 1x1 conv forward (VALID or SAME), its dgrad (a "full"
+// correlation of dZ with flipped, transposed filters), the 2x2/s2 transposed conv forward
+// (4 independent 1x1 GEMMs with a scatter epilogue) and its dgrad (a 2x2/s2 conv).
+// Replaces the TF kernels behind slim.convolution2d / slim.convolution2d_transpose at
+// /root/reference/models/unet.py:111-166 and models/fcn.py:110-128,192,195.
+//
+// GEMM orientation: D[row = out channel][col = pixel] = W[row][k] * X[k][col], so that after the
+// MFMA every lane owns 8 consecutive output channels of one pixel (two 16x16 fragments whose rows
+// are interleaved by the packed-weight row permutation) and stores them with one 16-byte write.
+//
+// Workgroup = 256 threads = 4 waves; output tile = TH x TW pixels of one image x BN channels.
+// Per 32-channel K chunk the WG stages (a) the (TH-1)S+KH x (TW-1)S+KW input patch, (b) all
+// KH*KW filter taps for its BN rows, then runs KH*KW taps x fragments of MFMA out of LDS; the
+// next chunk's global loads are in flight (registers) while the current one computes.
+#include "common.h"
+
+namespace {
+
+struct ConvK {          // kernel-side copy of the descriptor (trivially copyable)
+  seg_conv_desc d;
+  int tiles_x, tiles_y; // spatial tiles per image
+  int nchunks0, nchunks; // K chunks from src0 / total
+};
+
+template <typename T, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
+  using TT = Tr<T>;
+  constexpr int BM = TH * TW;
+  constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW, NPIX = PH * PW;
+  constexpr int NT = KH * KW;
+  constexpr int PIECES = TT::PIECES, EPP = TT::EPP, RSTR = TT::RSTR;
+  constexpr int PATCH_BYTES = ((NPIX * RSTR + 15) / 16) * 16;
+  constexpr int NPP = (NPIX * PIECES + 255) / 256;       // patch pieces per thread
+  constexpr int NWP = (NT * BN * PIECES + 255) / 256;    // weight pieces per thread
+  constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(FN % 2 == 0, "channel fragments come in pairs");
+  static_assert(BM % (WM * 16) == 0 && BN % (WN * 32) == 0, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sP = smem;
+  char* sW = smem + PATCH_BYTES;
+
+  const seg_conv_desc& d = P.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 15, g = lane >> 4;
+
+  int t = blockIdx.x;
+  const int tx = t % P.tiles_x; t /= P.tiles_x;
+  const int ty = t % P.tiles_y; const int b = t / P.tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int n0 = blockIdx.y * BN;                 // within this launch's n range
+
+  // ---- per-thread staging descriptors (constant over the K loop) ----
+  int p_lds[NPP];
+  int p_off0[NPP], p_off1[NPP];                   // element offsets inside image b of each source; -1 = zero fill
+  const int64_t img0 = (int64_t)b * d.src0.H * d.src0.W * d.src0.cs;
+  const int64_t img1 = (int64_t)b * d.src1.H * d.src1.W * d.src1.cs;
+#pragma unroll
+  for (int i = 0; i < NPP; ++i) {
+    const int idx = tid + i * 256;
+    p_lds[i] = -1; p_off0[i] = -1; p_off1[i] = -1;
+    if (idx < NPIX * PIECES) {
+      const int q = idx / PIECES, h = idx % PIECES;
+      const int py = q / PW, px = q % PW;
+      const int iy = oy0 * S - d.pad_t + py, ix = ox0 * S - d.pad_l + px;
+      p_lds[i] = TT::lds_off(q, h);
+      if (iy >= 0 && iy < d.Hi && ix >= 0 && ix < d.Wi) {
+        p_off0[i] = ((iy + d.src0.oy) * d.src0.W + ix + d.src0.ox) * d.src0.cs + d.src0.coff + h * EPP;
+        p_off1[i] = ((iy + d.src1.oy) * d.src1.W + ix + d.src1.ox) * d.src1.cs + d.src1.coff + h * EPP;
+      }
+    }
+  }
+  const T* src0 = reinterpret_cast<const T*>(d.src0.ptr) + img0;
+  const T* src1 = reinterpret_cast<const T*>(d.src1.ptr) + img1;
+  const T* wp = reinterpret_cast<const T*>(d.w_packed);
+
+  u32x4 rp[NPP], rw[NWP];
+
+  auto prefetch = [&](int c) {
+    const bool first = c < P.nchunks0;
+    const T* sb = first ? src0 + c * 32 : src1 + (c - P.nchunks0) * 32;
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+      const int off = first ? p_off0[i] : p_off1[i];
+      rp[i] = u32x4{0, 0, 0, 0};
+      if (off >= 0) rp[i] = *reinterpret_cast<const u32x4*>(sb + off);
+    }
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+      const int idx = tid + i * 256;
+      if (NT * BN * PIECES % 256 == 0 || idx < NT * BN * PIECES) {
+        const int tap = idx / (BN * PIECES), row = (idx / PIECES) % BN, h = idx % PIECES;
+        const int64_t off = ((int64_t)(tap * P.nchunks + c) * d.n_total + d.n_off + n0 + row) * 32 + h * EPP;
+        rw[i] = *reinterpret_cast<const u32x4*>(wp + off);
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPP; ++i)
+      if (p_lds[i] >= 0) *reinterpret_cast<u32x4*>(sP + p_lds[i]) = rp[i];
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+      const int idx = tid + i * 256;
+      if (NT * BN * PIECES % 256 == 0 || idx < NT * BN * PIECES) {
+        const int tap = idx / (BN * PIECES), row = (idx / PIECES) % BN, h = idx % PIECES;
+        *reinterpret_cast<u32x4*>(sW + TT::lds_off(tap * BN + row, h)) = rw[i];
+      }
+    }
+  };
+
+  // ---- per-lane operand addresses ----
+  int a_addr[FN];          // weight rows: packed order => fragment fn reads rows fn*16 + lr
+#pragma unroll
+  for (int fn = 0; fn < FN; ++fn) a_addr[fn] = frag_addr<T>(wn * (BN / WN) + fn * 16 + lr, g);
+  int b_addr[NT][FM];      // pixel rows per tap
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm) {
+    const int m = wm * (BM / WM) + fm * 16 + lr;
+    const int py = (m / TW) * S, px = (m % TW) * S;
+#pragma unroll
+    for (int u = 0; u < KH; ++u)
+#pragma unroll
+      for (int v = 0; v < KW; ++v) b_addr[u * KW + v][fm] = frag_addr<T>((py + u) * PW + px + v, g);
+  }
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = f32x4{0, 0, 0, 0};
+
+  prefetch(0);
+  for (int c = 0; c < P.nchunks; ++c) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (c + 1 < P.nchunks) prefetch(c + 1);
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap) {
+      Frag<T> fa[FN], fb[FM];
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) fa[fn] = lds_read_frag_at<T>(sW + a_addr[fn] + tap * BN * RSTR);
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) fb[fm] = lds_read_frag_at<T>(sP + b_addr[tap][fm]);
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) mma32(acc[fn][fm], fa[fn], fb[fm]);
+    }
+  }
+
+  // ---- epilogue: bias, ReLU, ReLU-grad mask, store 8 channels per lane ----
+#pragma unroll
+  for (int j = 0; j < FN / 2; ++j) {
+    const int nl = n0 + wn * (BN / WN) + j * 32 + 8 * g;     // first of this lane's 8 channels (launch-local)
+    if (nl >= d.n_count) continue;
+    const int np = d.n_off + nl;                               // packed row index
+    int co = nl, ua = 0, uc = 0;
+    if (d.up2) { const int tp = np / d.up_cout; co = np - tp * d.up_cout; ua = tp >> 1; uc = tp & 1; }
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int bi = d.up2 ? co + e : np + e;
+      bv[e] = (d.bias != nullptr && bi < d.bias_n) ? d.bias[bi] : 0.f;
+    }
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+      const int m = wm * (BM / WM) + fm * 16 + lr;
+      const int oy = oy0 + m / TW, ox = ox0 + m % TW;
+      if (oy >= d.Ho || ox >= d.Wo) continue;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = acc[2 * j][fm][e] + bv[e]; v[4 + e] = acc[2 * j + 1][fm][e] + bv[4 + e]; }
+      if (d.relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      const int dy = d.up2 ? 2 * oy + ua : oy, dx = d.up2 ? 2 * ox + uc : ox;
+      if (d.mask.ptr != nullptr) {
+        Vec8<T> mk;
+        mk.load(reinterpret_cast<const T*>(d.mask.ptr) + view_off(d.mask, b, dy, dx) + co);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = mk.get(e) > 0.f ? v[e] : 0.f;
+      }
+      const int64_t doff = view_off(d.dst, b, dy, dx) + co;
+      if (d.out_f32) {
+        Vec8<float> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, v[e]);
+        o.store(reinterpret_cast<float*>(d.dst.ptr) + doff);
+      } else {
+        Vec8<T> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, v[e]);
+        o.store(reinterpret_cast<T*>(d.dst.ptr) + doff);
+      }
+    }
+  }
+}
+
+template <typename T, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S>
+int launch_cfg(const ConvK& P0, hipStream_t st) {
+  using TT = Tr<T>;
+  constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
+  constexpr int PATCH_BYTES = ((PH * PW * TT::RSTR + 15) / 16) * 16;
+  constexpr int LDS = PATCH_BYTES + KH * KW * BN * TT::RSTR;
+  ConvK P = P0;
+  P.tiles_x = cdiv(P.d.Wo, TW);
+  P.tiles_y = cdiv(P.d.Ho, TH);
+  if (P.d.n_count % BN != 0) { seg_set_error("conv: n_count %d not a multiple of BN %d", P.d.n_count, BN); return SEG_ERR_ARG; }
+  auto kern = conv_fwd_kernel<T, TH, TW, BN, WM, WN, KH, KW, S>;
+  static bool attr_done = false;
+  if (!attr_done && LDS > 48 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      seg_set_error("conv: cannot raise dynamic LDS to %d", LDS); return SEG_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  dim3 grid(P.d.B * P.tiles_y * P.tiles_x, P.d.n_count / BN);
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, P);
+  return seg_check_launch("conv_fwd");
+}
+
+// padded output area for a tile shape (smaller = less wasted MFMA work)
+inline long waste(int Ho, int Wo, int th, int tw) { return (long)cdiv(Ho, th) * th * cdiv(Wo, tw) * tw; }
+
+template <typename T, int KH, int KW, int S>
+int launch_k(const ConvK& P, hipStream_t st) {
+  const seg_conv_desc& d = P.d;
+  int cfg = d.cfg;
+  if (cfg == 0) {
+    const bool bn64 = (d.n_count % 64 == 0);
+    const long w816 = waste(d.Ho, d.Wo, 8, 16), w88 = waste(d.Ho, d.Wo, 8, 8);
+    const bool small = w88 < w816;
+    cfg = small ? (bn64 ? 3 : 4) : (bn64 ? 1 : 2);
+  }
+  switch (cfg) {
+    case 1: return launch_cfg<T, 8, 16, 64, 4, 1, KH, KW, S>(P, st);   // 128 px x 64 ch
+    case 2: return launch_cfg<T, 8, 16, 32, 4, 1, KH, KW, S>(P, st);   // 128 px x 32 ch
+    case 3: return launch_cfg<T, 8, 8, 64, 2, 2, KH, KW, S>(P, st);    //  64 px x 64 ch
+    case 4: return launch_cfg<T, 8, 8, 32, 4, 1, KH, KW, S>(P, st);    //  64 px x 32 ch
+    default: seg_set_error("conv: unknown cfg %d", cfg); return SEG_ERR_ARG;
+  }
+}
+
+template <typename T>
+int launch_t(const ConvK& P, hipStream_t st) {
+  const seg_conv_desc& d = P.d;
+  if (d.KH == 3 && d.KW == 3 && d.stride == 1) return launch_k<T, 3, 3, 1>(P, st);
+  if (d.KH == 1 && d.KW == 1 && d.stride == 1) return launch_k<T, 1, 1, 1>(P, st);
+  if (d.KH == 2 && d.KW == 2 && d.stride == 2) return launch_k<T, 2, 2, 2>(P, st);
+  seg_set_error("conv: unsupported kernel %dx%d stride %d", d.KH, d.KW, d.stride);
+  return SEG_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int seg_conv2d(const seg_conv_desc* dp, void* stream) {
+  if (!dp) { seg_set_error("conv: null descriptor"); return SEG_ERR_ARG; }
+  const seg_conv_desc& d = *dp;
+  if (!d.src0.ptr || !d.dst.ptr || !d.w_packed) { seg_set_error("conv: null pointer"); return SEG_ERR_ARG; }
+  if (d.src0.c <= 0 || d.src0.c % 32 || (d.src1.ptr && (d.src1.c <= 0 || d.src1.c % 32))) {
+    seg_set_error("conv: source channels must be positive multiples of 32 (got %d,%d)", d.src0.c, d.src1.c); return SEG_ERR_ARG;
+  }
+  if (d.n_count <= 0 || d.n_count % 32 || d.n_off % 32 || d.n_off + d.n_count > d.n_total) {
+    seg_set_error("conv: bad n range off %d count %d total %d", d.n_off, d.n_count, d.n_total); return SEG_ERR_ARG;
+  }
+  if (d.B <= 0 || d.Ho <= 0 || d.Wo <= 0 || d.Hi <= 0 || d.Wi <= 0) { seg_set_error("conv: empty extent"); return SEG_ERR_ARG; }
+  if (d.src0.oy + d.Hi > d.src0.H || d.src0.ox + d.Wi > d.src0.W || d.src0.coff + d.src0.c > d.src0.cs ||
+      (d.src1.ptr && (d.src1.oy + d.Hi > d.src1.H || d.src1.ox + d.Wi > d.src1.W || d.src1.coff + d.src1.c > d.src1.cs))) {
+    seg_set_error("conv: source window exceeds its buffer"); return SEG_ERR_ARG;
+  }
+  {
+    const int sc = d.up2 ? 2 : 1;
+    const int nch = d.up2 ? d.up_cout : d.n_count;
+    if (d.dst.oy + sc * d.Ho > d.dst.H || d.dst.ox + sc * d.Wo > d.dst.W || d.dst.coff + nch > d.dst.cs) {
+      seg_set_error("conv: destination window exceeds its buffer"); return SEG_ERR_ARG;
+    }
+    if (d.up2 && (d.up_cout <= 0 || d.up_cout % 8)) { seg_set_error("conv: up_cout must be a multiple of 8"); return SEG_ERR_ARG; }
+    if (d.mask.ptr && (d.mask.oy + sc * d.Ho > d.mask.H || d.mask.ox + sc * d.Wo > d.mask.W || d.mask.coff + nch > d.mask.cs)) {
+      seg_set_error("conv: mask window exceeds its buffer"); return SEG_ERR_ARG;
+    }
+  }
+  ConvK P;
+  P.d = d;
+  if (!d.src1.ptr) { P.d.src1 = d.src0; P.d.src1.c = 0; }
+  P.nchunks0 = d.src0.c / 32;
+  P.nchunks = P.nchunks0 + (d.src1.ptr ? d.src1.c / 32 : 0);
+  P.tiles_x = P.tiles_y = 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d.dtype == SEG_F32) return launch_t<float>(P, st);
+  if (d.dtype == SEG_BF16) return launch_t<bf16_t>(P, st);
+  seg_set_error("conv: bad dtype %d", d.dtype);
+  return SEG_ERR_ARG;
+}

@@ -1,0 +1,575 @@
+// elementwise.hip -- the HBM-bound ops of the hot path: max-pool (+fused crop-grad add and
+// ReLU-grad), per-pixel softmax cross-entropy, sigmoid+argmax, bias grad, fused Adam, weight
+// packing, depthwise bilinear transposed conv, dropout, cast.  All NHWC, 16-byte vector access
+// over the channel dimension, wave64 reductions.
+#include "common.h"
+#include <stdarg.h>
+#include <string.h>
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void seg_set_error(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+int seg_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { seg_set_error("%s: launch failed: %s", what, hipGetErrorString(e)); return SEG_ERR_LAUNCH; }
+  return SEG_OK;
+}
+extern "C" const char* seg_last_error(void) { return g_err; }
+extern "C" int seg_version(void) { return 100; }
+
+namespace {
+
+SEG_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+inline int grid_for(int64_t n, int per_block = 256, int cap = 8192) {
+  int64_t g = (n + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+inline bool view_ok(const seg_view* v, int H, int W, int C) {
+  return v && v->ptr && v->oy >= 0 && v->ox >= 0 && v->oy + H <= v->H && v->ox + W <= v->W && v->coff >= 0 &&
+         v->coff + C <= v->cs && (v->cs % 8) == 0 && (v->coff % 8) == 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// max-pool 2x2 / stride 2 / VALID
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool_fwd_kernel(seg_view src, seg_view dst, uint8_t* idx, int B, int Ho, int Wo, int C8) {
+  const int64_t total = (int64_t)B * Ho * Wo * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int c8 = t % C8; t /= C8;
+    const int ox = t % Wo; t /= Wo;
+    const int oy = t % Ho; const int b = t / Ho;
+    const T* sp = reinterpret_cast<const T*>(src.ptr);
+    Vec8<T> v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k].load(sp + view_off(src, b, 2 * oy + (k >> 1), 2 * ox + (k & 1)) + c8 * 8);
+    Vec8<T> o;
+    uint8_t id[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float m = v[0].get(e); int mi = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) { const float x = v[k].get(e); if (x > m) { m = x; mi = k; } }
+      o.set(e, m); id[e] = (uint8_t)mi;
+    }
+    o.store(reinterpret_cast<T*>(dst.ptr) + view_off(dst, b, oy, ox) + c8 * 8);
+    if (idx) {
+      uint64_t pk = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pk |= (uint64_t)id[e] << (8 * e);
+      *reinterpret_cast<uint64_t*>(idx + (((int64_t)(b * Ho + oy) * Wo + ox) * C8 + c8) * 8) = pk;
+    }
+  }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(seg_view yact, seg_view dpool, seg_view add, int add_h, int add_w, int ay0, int ax0,
+                                   seg_view dz, int B, int H, int W, int C8) {
+  const int Hw = (H + 1) / 2, Ww = (W + 1) / 2, Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)B * Hw * Ww * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int c8 = t % C8; t /= C8;
+    const int wx = t % Ww; t /= Ww;
+    const int wy = t % Hw; const int b = t / Hw;
+    const bool full = wy < Ho && wx < Wo;
+    Vec8<T> y[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = 2 * wy + (k >> 1), xx = 2 * wx + (k & 1);
+      ok[k] = yy < H && xx < W;
+      y[k].zero();
+      if (ok[k]) y[k].load(reinterpret_cast<const T*>(yact.ptr) + view_off(yact, b, yy, xx) + c8 * 8);
+    }
+    Vec8<T> dp; dp.zero();
+    const bool route = full && dpool.ptr != nullptr;
+    if (route) dp.load(reinterpret_cast<const T*>(dpool.ptr) + view_off(dpool, b, wy, wx) + c8 * 8);
+    int mi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float m = y[0].get(e); mi[e] = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) { const float x = y[k].get(e); if (x > m) { m = x; mi[e] = k; } }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!ok[k]) continue;
+      const int yy = 2 * wy + (k >> 1), xx = 2 * wx + (k & 1);
+      Vec8<T> ad; ad.zero();
+      const int ay = yy - ay0, ax = xx - ax0;
+      if (add.ptr != nullptr && ay >= 0 && ay < add_h && ax >= 0 && ax < add_w)
+        ad.load(reinterpret_cast<const T*>(add.ptr) + view_off(add, b, ay, ax) + c8 * 8);
+      Vec8<T> o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float gsum = ad.get(e);
+        if (route && mi[e] == k) gsum += dp.get(e);
+        o.set(e, y[k].get(e) > 0.f ? gsum : 0.f);
+      }
+      o.store(reinterpret_cast<T*>(dz.ptr) + view_off(dz, b, yy, xx) + c8 * 8);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// ReLU grad, cast+pad, dropout
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void relu_grad_kernel(seg_view dy, seg_view yact, seg_view dz, int B, int H, int W, int C8) {
+  const int64_t total = (int64_t)B * H * W * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int c8 = t % C8; t /= C8;
+    const int x = t % W; t /= W;
+    const int y = t % H; const int b = t / H;
+    Vec8<T> g, a, o;
+    g.load(reinterpret_cast<const T*>(dy.ptr) + view_off(dy, b, y, x) + c8 * 8);
+    a.load(reinterpret_cast<const T*>(yact.ptr) + view_off(yact, b, y, x) + c8 * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.set(e, a.get(e) > 0.f ? g.get(e) : 0.f);
+    o.store(reinterpret_cast<T*>(dz.ptr) + view_off(dz, b, y, x) + c8 * 8);
+  }
+}
+
+template <typename T>
+__global__ void cast_pad_kernel(const float* x, int64_t npix, int c, seg_view dst) {
+  const int C8 = dst.cs / 8;
+  const int64_t total = npix * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = i / C8; const int c8 = i % C8;
+    Vec8<T> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int ch = c8 * 8 + e; o.set(e, ch < c ? x[pix * c + ch] : 0.f); }
+    o.store(reinterpret_cast<T*>(dst.ptr) + pix * dst.cs + c8 * 8);
+  }
+}
+
+SEG_DEV uint32_t mix32(uint64_t k) {  // splitmix64 finaliser -> 32 random bits per (seed, counter)
+  k += 0x9E3779B97F4A7C15ull; k = (k ^ (k >> 30)) * 0xBF58476D1CE4E5B9ull; k = (k ^ (k >> 27)) * 0x94D049BB133111EBull;
+  return (uint32_t)((k ^ (k >> 31)) >> 16);
+}
+template <typename T>
+__global__ void dropout_kernel(seg_view xin, seg_view yout, int B, int H, int W, int C8, float keep, uint64_t seed, uint64_t offset) {
+  const int64_t total = (int64_t)B * H * W * C8;
+  const float inv = 1.f / keep;
+  const uint32_t thr = (uint32_t)(keep * 4294967295.0);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int c8 = t % C8; t /= C8;
+    const int x = t % W; t /= W;
+    const int y = t % H; const int b = t / H;
+    Vec8<T> v, o;
+    v.load(reinterpret_cast<const T*>(xin.ptr) + view_off(xin, b, y, x) + c8 * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t r = mix32(seed * 0x100000001B3ull + offset + (uint64_t)i * 8 + e);
+      o.set(e, r <= thr ? v.get(e) * inv : 0.f);
+    }
+    o.store(reinterpret_cast<T*>(yout.ptr) + view_off(yout, b, y, x) + c8 * 8);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// softmax cross-entropy (+grad) and sigmoid/argmax
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void softmax_xent_kernel(seg_view lg, const uint8_t* labels, int LH, int LW, int ly0, int lx0, int B, int H, int W,
+                                    int nc, float inv_n, float gscale, float* loss_sum, seg_view dl) {
+  const int64_t total = (int64_t)B * H * W;
+  float local = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int x = t % W; t /= W;
+    const int y = t % H; const int b = t / H;
+    const float* z = reinterpret_cast<const float*>(lg.ptr) + view_off(lg, b, y, x);
+    const int lab = labels[((int64_t)b * LH + y + ly0) * LW + x + lx0];
+    float zv[32];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { zv[c] = c < nc ? z[c] : -INFINITY; m = fmaxf(m, zv[c]); }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { zv[c] = c < nc ? expf(zv[c] - m) : 0.f; s += zv[c]; }
+    const bool valid = lab < nc;
+    const float logs = logf(s);
+    const float zl = valid ? z[lab] : 0.f;
+    if (valid) local += (logs - (zl - m));
+    const float k = inv_n * gscale, rs = 1.f / s;
+    T* o = reinterpret_cast<T*>(dl.ptr) + view_off(dl, b, y, x);
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8) {
+      if (c8 * 8 >= dl.c) break;
+      Vec8<T> ov;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = c8 * 8 + e;
+        const float gv = (c < nc && valid) ? (zv[c] * rs - (c == lab ? 1.f : 0.f)) * k : 0.f;
+        ov.set(e, gv);
+      }
+      ov.store(o + c8 * 8);
+    }
+  }
+  local = wave_sum(local);
+  if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, local * inv_n);
+}
+
+__global__ void sigmoid_argmax_kernel(seg_view lg, int B, int H, int W, int nc, float* sig, float* out) {
+  const int64_t total = (int64_t)B * H * W;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int x = t % W; t /= W;
+    const int y = t % H; const int b = t / H;
+    const float* z = reinterpret_cast<const float*>(lg.ptr) + view_off(lg, b, y, x);
+    float best = -1.f; int bi = 0;
+    for (int c = 0; c < nc; ++c) {
+      // sigmoid evaluated in double and rounded once to float32 (the oracle's definition); the argmax
+      // is over the float32 values, first maximum wins (saturated ties -> lower index).
+      const float s = (float)(1.0 / (1.0 + exp(-(double)z[c])));
+      sig[i * nc + c] = s;
+      if (s > best) { best = s; bi = c; }
+    }
+    out[i] = (float)bi;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// bias grad: column sums of a [B*H*W, C] window
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void bias_grad_kernel(seg_view dz, int B, int H, int W, int C8, int n_log, float* db) {
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x;
+  const int c8 = tid % C8, pl = tid / C8, npl = 256 / C8;     // C8 <= 256 (checked by the launcher)
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t npix = (int64_t)B * H * W;
+  if (pl < npl) {
+    for (int64_t p = (int64_t)blockIdx.x * npl + pl; p < npix; p += (int64_t)gridDim.x * npl) {
+      int64_t t = p;
+      const int x = t % W; t /= W;
+      const int y = t % H; const int b = t / H;
+      Vec8<T> v;
+      v.load(reinterpret_cast<const T*>(dz.ptr) + view_off(dz, b, y, x) + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += v.get(e);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[tid * 8 + e] = s[e];
+  __syncthreads();
+  for (int ch = tid; ch < C8 * 8 && ch < n_log; ch += 256) {
+    const int cc8 = ch / 8, e = ch % 8;
+    float a = 0.f;
+    for (int q = 0; q < npl; ++q) a += red[(q * C8 + cc8) * 8 + e];
+    atomicAdd(db + ch, a);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam (TF variant) on a flat arena
+// ------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                            float eps, float gs, const int64_t* step_dev) {
+  __shared__ float s_lrt;
+  if (threadIdx.x == 0) {
+    const double t = (double)(*step_dev + 1);
+    s_lrt = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+  }
+  __syncthreads();
+  const float lr_t = s_lrt;
+  const int64_t n4 = n / 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = gg[e] * gs;
+      mm[e] = b1 * mm[e] + (1.f - b1) * gr;
+      vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+      pp[e] = pp[e] - lr_t * mm[e] / (sqrtf(vv[e]) + eps);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pp; reinterpret_cast<f32x4*>(m)[i] = mm; reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    const float gr = g[i] * gs;
+    const float mm = b1 * m[i] + (1.f - b1) * gr, vv = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mm; v[i] = vv; p[i] = p[i] - lr_t * mm / (sqrtf(vv) + eps);
+  }
+}
+__global__ void step_inc_kernel(int64_t* s) { if (threadIdx.x == 0 && blockIdx.x == 0) *s += 1; }
+
+// ------------------------------------------------------------------------------------------
+// weight packing: fp32 TF layout -> [taps][K/32][n_total][32] (rows permuted inside each
+// 32-block so that the two MFMA fragments of a block give every lane 8 consecutive channels)
+// ------------------------------------------------------------------------------------------
+SEG_DEV int seg_ci(const seg_pack_entry& e, int kpad) {   // padded concat channel -> logical (or -1)
+  if (kpad < e.seg0_cp) return kpad < e.seg0_c ? kpad : -1;
+  const int k1 = kpad - e.seg0_cp;
+  return (k1 < e.seg1_c) ? e.seg0_c + k1 : -1;
+}
+template <typename T>
+__global__ void pack_kernel(const float* arena, T* packed, const seg_pack_entry* tab, int n_entries) {
+  __shared__ int s_e;
+  if (threadIdx.x == 0) {
+    int lo = 0;
+    for (int i = 0; i < n_entries; ++i) if ((int64_t)blockIdx.x >= tab[i].blk_start) lo = i;
+    s_e = lo;
+  }
+  __syncthreads();
+  const seg_pack_entry e = tab[s_e];
+  const int64_t idx = ((int64_t)blockIdx.x - e.blk_start) * 256 + threadIdx.x;
+  if (idx >= e.n_elems) return;
+  const int kk = idx % 32;
+  int64_t t = idx / 32;
+  const int npk = t % e.n_total; t /= e.n_total;
+  const int nch = e.k_pad / 32;
+  const int chunk = t % nch; const int tap = t / nch;
+  const int pos = npk & 31;
+  const int n = (npk & ~31) | (((pos >> 2) & 3) << 3) | (((pos >> 4) & 1) << 2) | (pos & 3);
+  const int k = chunk * 32 + kk;
+  const float* src = arena + e.src_off;
+  float val = 0.f;
+  if (e.mode == SEG_PACK_CONV_FWD) {
+    const int ci = seg_ci(e, k);
+    if (ci >= 0 && n < e.cout) val = src[((int64_t)tap * e.cin + ci) * e.cout + n];
+  } else if (e.mode == SEG_PACK_CONV_DGRAD) {
+    const int ci = seg_ci(e, n);
+    const int u = e.KH - 1 - tap / e.KW, v = e.KW - 1 - tap % e.KW;
+    if (ci >= 0 && k < e.cout) val = src[((int64_t)(u * e.KW + v) * e.cin + ci) * e.cout + k];
+  } else if (e.mode == SEG_PACK_UP_FWD) {
+    const int ci = seg_ci(e, k);
+    const int tp = n / e.cout_pad, co = n % e.cout_pad;
+    if (ci >= 0 && co < e.cout && tp < 4) val = src[((int64_t)tp * e.cout + co) * e.cin + ci];
+  } else {  // SEG_PACK_UP_DGRAD
+    const int ci = seg_ci(e, n);
+    if (ci >= 0 && k < e.cout) val = src[((int64_t)tap * e.cout + k) * e.cin + ci];
+  }
+  packed[e.dst_off + idx] = from_f32<T>(val);
+}
+
+// ------------------------------------------------------------------------------------------
+// depthwise bilinear transposed conv (+crop/pad, + skip add)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void bilinear_fwd_kernel(seg_view src, int Hs, int Ws, int f, const float* filt, seg_view add, seg_view dst,
+                                    int Hd, int Wd, int cy, int cx, int B, int C8, int dst_f32) {
+  const int k = 2 * f - f % 2, pb = (k - f) / 2;
+  const int64_t total = (int64_t)B * Hd * Wd * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int c8 = t % C8; t /= C8;
+    const int x = t % Wd; t /= Wd;
+    const int y = t % Hd; const int b = t / Hd;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int Y = y + cy, X = x + cx;
+    if (Y >= 0 && Y < Hs * f && X >= 0 && X < Ws * f) {
+      for (int u = (Y + pb) % f; u < k; u += f) {
+        const int iy = (Y + pb - u) / f;
+        if (iy < 0 || iy >= Hs) continue;
+        for (int v = (X + pb) % f; v < k; v += f) {
+          const int ix = (X + pb - v) / f;
+          if (ix < 0 || ix >= Ws) continue;
+          const float w = filt[u * k + v];
+          Vec8<T> s; s.load(reinterpret_cast<const T*>(src.ptr) + view_off(src, b, iy, ix) + c8 * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += w * s.get(e);
+        }
+      }
+    }
+    if (add.ptr != nullptr) {
+      Vec8<T> s; s.load(reinterpret_cast<const T*>(add.ptr) + view_off(add, b, y, x) + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += s.get(e);
+    }
+    const int64_t off = view_off(dst, b, y, x) + c8 * 8;
+    if (dst_f32) { Vec8<float> o; for (int e = 0; e < 8; ++e) o.set(e, a[e]); o.store(reinterpret_cast<float*>(dst.ptr) + off); }
+    else { Vec8<T> o; for (int e = 0; e < 8; ++e) o.set(e, a[e]); o.store(reinterpret_cast<T*>(dst.ptr) + off); }
+  }
+}
+
+template <typename T>
+__global__ void bilinear_bwd_kernel(seg_view dd, int Hd, int Wd, int cy, int cx, int f, const float* filt, seg_view ds,
+                                    int Hs, int Ws, int B, int C8, int dd_f32) {
+  const int k = 2 * f - f % 2, pb = (k - f) / 2;
+  const int64_t total = (int64_t)B * Hs * Ws * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int c8 = t % C8; t /= C8;
+    const int ix = t % Ws; t /= Ws;
+    const int iy = t % Hs; const int b = t / Hs;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int u = 0; u < k; ++u) {
+      const int y = iy * f + u - pb - cy;
+      if (y < 0 || y >= Hd) continue;
+      for (int v = 0; v < k; ++v) {
+        const int x = ix * f + v - pb - cx;
+        if (x < 0 || x >= Wd) continue;
+        const float w = filt[u * k + v];
+        const int64_t off = view_off(dd, b, y, x) + c8 * 8;
+        if (dd_f32) { Vec8<float> s; s.load(reinterpret_cast<const float*>(dd.ptr) + off); for (int e = 0; e < 8; ++e) a[e] += w * s.get(e); }
+        else { Vec8<T> s; s.load(reinterpret_cast<const T*>(dd.ptr) + off); for (int e = 0; e < 8; ++e) a[e] += w * s.get(e); }
+      }
+    }
+    Vec8<T> o; for (int e = 0; e < 8; ++e) o.set(e, a[e]);
+    o.store(reinterpret_cast<T*>(ds.ptr) + view_off(ds, b, iy, ix) + c8 * 8);
+  }
+}
+
+seg_view null_view() { seg_view v; memset(&v, 0, sizeof(v)); return v; }
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+#define DISPATCH(dtype, CALL_F32, CALL_BF16)                      \
+  if ((dtype) == SEG_F32) { CALL_F32; }                           \
+  else if ((dtype) == SEG_BF16) { CALL_BF16; }                    \
+  else { seg_set_error("bad dtype %d", (int)(dtype)); return SEG_ERR_ARG; }
+
+extern "C" int seg_maxpool2x2_fwd(const seg_view* src, const seg_view* dst, uint8_t* idx, int32_t B, int32_t Ho, int32_t Wo,
+                                  int32_t C, int32_t dtype, void* stream) {
+  if (!view_ok(src, 2 * Ho, 2 * Wo, C) || !view_ok(dst, Ho, Wo, C) || C % 8 || B <= 0) { seg_set_error("maxpool_fwd: bad views"); return SEG_ERR_ARG; }
+  const int64_t n = (int64_t)B * Ho * Wo * (C / 8);
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *src, *dst, idx, B, Ho, Wo, C / 8),
+           hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *src, *dst, idx, B, Ho, Wo, C / 8));
+  return seg_check_launch("maxpool_fwd");
+}
+
+extern "C" int seg_maxpool2x2_bwd(const seg_view* y_act, const seg_view* dpool, const seg_view* add, int32_t add_h, int32_t add_w,
+                                  int32_t add_y0, int32_t add_x0, const seg_view* dz, int32_t B, int32_t H, int32_t W, int32_t C,
+                                  int32_t dtype, void* stream) {
+  if (!view_ok(y_act, H, W, C) || !view_ok(dz, H, W, C) || C % 8 || B <= 0) { seg_set_error("maxpool_bwd: bad views"); return SEG_ERR_ARG; }
+  if (dpool && dpool->ptr && !view_ok(dpool, H / 2, W / 2, C)) { seg_set_error("maxpool_bwd: bad dpool view"); return SEG_ERR_ARG; }
+  if (add && add->ptr && (!view_ok(add, add_h, add_w, C) || add_y0 < 0 || add_x0 < 0)) { seg_set_error("maxpool_bwd: bad add view"); return SEG_ERR_ARG; }
+  const seg_view dpv = (dpool && dpool->ptr) ? *dpool : null_view();
+  const seg_view adv = (add && add->ptr) ? *add : null_view();
+  const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *y_act, dpv, adv, add_h, add_w, add_y0, add_x0, *dz, B, H, W, C / 8),
+           hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *y_act, dpv, adv, add_h, add_w, add_y0, add_x0, *dz, B, H, W, C / 8));
+  return seg_check_launch("maxpool_bwd");
+}
+
+extern "C" int seg_relu_grad(const seg_view* dy, const seg_view* y_act, const seg_view* dz, int32_t B, int32_t H, int32_t W, int32_t C,
+                             int32_t dtype, void* stream) {
+  if (!view_ok(dy, H, W, C) || !view_ok(y_act, H, W, C) || !view_ok(dz, H, W, C) || C % 8) { seg_set_error("relu_grad: bad views"); return SEG_ERR_ARG; }
+  const int64_t n = (int64_t)B * H * W * (C / 8);
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(relu_grad_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *dy, *y_act, *dz, B, H, W, C / 8),
+           hipLaunchKernelGGL(relu_grad_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *dy, *y_act, *dz, B, H, W, C / 8));
+  return seg_check_launch("relu_grad");
+}
+
+extern "C" int seg_cast_pad(const float* x, int64_t npix, int32_t c, const seg_view* dst, int32_t dtype, void* stream) {
+  if (!x || !dst || !dst->ptr || dst->cs % 8 || c > dst->cs || npix <= 0) { seg_set_error("cast_pad: bad args"); return SEG_ERR_ARG; }
+  const int64_t n = npix * (dst->cs / 8);
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(cast_pad_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, npix, c, *dst),
+           hipLaunchKernelGGL(cast_pad_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, npix, c, *dst));
+  return seg_check_launch("cast_pad");
+}
+
+extern "C" int seg_dropout(const seg_view* x, const seg_view* y, int32_t B, int32_t H, int32_t W, int32_t C, float keep,
+                           uint64_t seed, uint64_t offset, int32_t dtype, void* stream) {
+  if (!view_ok(x, H, W, C) || !view_ok(y, H, W, C) || C % 8 || !(keep > 0.f && keep <= 1.f)) { seg_set_error("dropout: bad args"); return SEG_ERR_ARG; }
+  const int64_t n = (int64_t)B * H * W * (C / 8);
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *x, *y, B, H, W, C / 8, keep, seed, offset),
+           hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *x, *y, B, H, W, C / 8, keep, seed, offset));
+  return seg_check_launch("dropout");
+}
+
+extern "C" int seg_softmax_xent(const seg_view* logits, const uint8_t* labels, int32_t LH, int32_t LW, int32_t ly0, int32_t lx0,
+                                int32_t B, int32_t H, int32_t W, int32_t n_classes, float inv_n, float grad_scale, float* loss_sum,
+                                const seg_view* dlogits, int32_t dtype, void* stream) {
+  if (!logits || !logits->ptr || !labels || !loss_sum || !view_ok(dlogits, H, W, dlogits ? dlogits->c : 0)) { seg_set_error("softmax_xent: bad args"); return SEG_ERR_ARG; }
+  if (n_classes < 1 || n_classes > 32 || n_classes > dlogits->c || dlogits->c % 8 || dlogits->c > 32) { seg_set_error("softmax_xent: n_classes %d unsupported (1..32)", n_classes); return SEG_ERR_UNSUPPORTED; }
+  if (ly0 < 0 || lx0 < 0 || ly0 + H > LH || lx0 + W > LW) { seg_set_error("softmax_xent: label window out of range"); return SEG_ERR_ARG; }
+  const int64_t n = (int64_t)B * H * W;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(softmax_xent_kernel<float>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, ST(stream), *logits, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, grad_scale, loss_sum, *dlogits),
+           hipLaunchKernelGGL(softmax_xent_kernel<bf16_t>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, ST(stream), *logits, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, grad_scale, loss_sum, *dlogits));
+  return seg_check_launch("softmax_xent");
+}
+
+extern "C" int seg_sigmoid_argmax(const seg_view* logits, int32_t B, int32_t H, int32_t W, int32_t n_classes, float* sig, float* out,
+                                  void* stream) {
+  if (!logits || !logits->ptr || !sig || !out || n_classes < 1 || n_classes > logits->cs) { seg_set_error("sigmoid_argmax: bad args"); return SEG_ERR_ARG; }
+  const int64_t n = (int64_t)B * H * W;
+  hipLaunchKernelGGL(sigmoid_argmax_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), *logits, B, H, W, n_classes, sig, out);
+  return seg_check_launch("sigmoid_argmax");
+}
+
+extern "C" int seg_bias_grad(const seg_view* dz, int32_t B, int32_t H, int32_t W, int32_t n_log, float* db, int32_t dtype, void* stream) {
+  if (!dz || !dz->ptr || !db || dz->c % 8 || dz->c > 2048 || n_log > dz->c || !view_ok(dz, H, W, dz->c)) { seg_set_error("bias_grad: bad args"); return SEG_ERR_ARG; }
+  const int C8 = dz->c / 8;
+  const int64_t npix = (int64_t)B * H * W;
+  int npl = 256 / C8; if (npl < 1) npl = 1;
+  if (C8 > 256) { seg_set_error("bias_grad: more than 2048 channels"); return SEG_ERR_UNSUPPORTED; }
+  const int g = grid_for(npix, npl * 16, 1024);
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(g), dim3(256), 0, ST(stream), *dz, B, H, W, C8, n_log, db),
+           hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(g), dim3(256), 0, ST(stream), *dz, B, H, W, C8, n_log, db));
+  return seg_check_launch("bias_grad");
+}
+
+extern "C" int seg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                        float grad_scale, const int64_t* step_dev, void* stream) {
+  if (!p || !g || !m || !v || !step_dev || n <= 0) { seg_set_error("adam: bad args"); return SEG_ERR_ARG; }
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) { seg_set_error("adam: arenas must be 16-byte aligned"); return SEG_ERR_ARG; }
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, b1, b2, eps, grad_scale, step_dev);
+  return seg_check_launch("adam");
+}
+
+extern "C" int seg_step_increment(int64_t* step_dev, void* stream) {
+  if (!step_dev) { seg_set_error("step_increment: null"); return SEG_ERR_ARG; }
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, ST(stream), step_dev);
+  return seg_check_launch("step_increment");
+}
+
+extern "C" int seg_pack_weights(const float* arena, void* packed, const seg_pack_entry* table_dev, int32_t n_entries,
+                                int64_t total_blocks, int32_t dtype, void* stream) {
+  if (!arena || !packed || !table_dev || n_entries <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffff) { seg_set_error("pack: bad args"); return SEG_ERR_ARG; }
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(pack_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, ST(stream), arena, reinterpret_cast<float*>(packed), table_dev, n_entries),
+           hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3((unsigned)total_blocks), dim3(256), 0, ST(stream), arena, reinterpret_cast<bf16_t*>(packed), table_dev, n_entries));
+  return seg_check_launch("pack_weights");
+}
+
+extern "C" int seg_bilinear_up_fwd(const seg_view* src, int32_t Hs, int32_t Ws, int32_t factor, const float* filt, const seg_view* add,
+                                   const seg_view* dst, int32_t Hd, int32_t Wd, int32_t cy, int32_t cx, int32_t B, int32_t C,
+                                   int32_t dst_f32, int32_t dtype, void* stream) {
+  if (!view_ok(src, Hs, Ws, C) || !view_ok(dst, Hd, Wd, C) || !filt || factor < 1 || C % 8) { seg_set_error("bilinear_fwd: bad args"); return SEG_ERR_ARG; }
+  if (add && add->ptr && !view_ok(add, Hd, Wd, C)) { seg_set_error("bilinear_fwd: bad add view"); return SEG_ERR_ARG; }
+  const seg_view adv = (add && add->ptr) ? *add : null_view();
+  const int64_t n = (int64_t)B * Hd * Wd * (C / 8);
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(bilinear_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *src, Hs, Ws, factor, filt, adv, *dst, Hd, Wd, cy, cx, B, C / 8, dst_f32),
+           hipLaunchKernelGGL(bilinear_fwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *src, Hs, Ws, factor, filt, adv, *dst, Hd, Wd, cy, cx, B, C / 8, dst_f32));
+  return seg_check_launch("bilinear_fwd");
+}
+
+extern "C" int seg_bilinear_up_bwd(const seg_view* ddst, int32_t Hd, int32_t Wd, int32_t cy, int32_t cx, int32_t factor, const float* filt,
+                                   const seg_view* dsrc, int32_t Hs, int32_t Ws, int32_t B, int32_t C, int32_t ddst_f32, int32_t dtype,
+                                   void* stream) {
+  if (!view_ok(ddst, Hd, Wd, C) || !view_ok(dsrc, Hs, Ws, C) || !filt || factor < 1 || C % 8) { seg_set_error("bilinear_bwd: bad args"); return SEG_ERR_ARG; }
+  const int64_t n = (int64_t)B * Hs * Ws * (C / 8);
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(bilinear_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *ddst, Hd, Wd, cy, cx, factor, filt, *dsrc, Hs, Ws, B, C / 8, ddst_f32),
+           hipLaunchKernelGGL(bilinear_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *ddst, Hd, Wd, cy, cx, factor, filt, *dsrc, Hs, Ws, B, C / 8, ddst_f32));
+  return seg_check_launch("bilinear_bwd");
+}

@@ -1,0 +1,359 @@
+"""Host-side engine: parameter arenas, activation buffers and static launch plans.
+
+A model is compiled once into flat lists of C-ABI launches (forward / backward / update); a
+train step replays them on one HIP stream (eagerly, or as a captured hipGraph).  PyTorch only
+provides device memory, streams and torch.distributed here -- every arithmetic op is a kernel
+of libseg_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def rup(c, m=32):
+    return (c + m - 1) // m * m
+
+
+def torch_dtype(dtype):
+    return torch.float32 if dtype == L.SEG_F32 else torch.bfloat16
+
+
+class Act(object):
+    """NHWC activation buffer [B,H,W,Cp]; Cp = channels padded to 32, pad channels stay zero."""
+
+    def __init__(self, B, H, W, C, dtype, device, f32=False, name=''):
+        self.B, self.H, self.W, self.C, self.Cp = B, H, W, C, rup(C)
+        self.name = name
+        self.t = torch.zeros((B, H, W, self.Cp), dtype=torch.float32 if f32 else torch_dtype(dtype), device=device)
+
+    def view(self, oy=0, ox=0):
+        return L.View(self.t.data_ptr(), self.H, self.W, self.Cp, 0, oy, ox, self.Cp)
+
+    def nbytes(self):
+        return self.t.numel() * self.t.element_size()
+
+
+class Layer(object):
+    """One weighted layer.  kind: 'first' (3x3, raw float input), 'conv' (k x k), 'up' (2x2/s2 transposed)."""
+
+    def __init__(self, name, kind, k, cin_segs, cout, padding='VALID', relu=True):
+        self.name, self.kind, self.k, self.cout, self.padding, self.relu = name, kind, k, cout, padding, relu
+        self.cin_segs = list(cin_segs)                       # logical channels of each concat segment
+        self.cin = sum(self.cin_segs)
+        self.cin_p = [rup(c) for c in self.cin_segs]
+        self.cout_p = rup(cout)
+        if kind == 'up':
+            self.wshape = (2, 2, cout, self.cin)              # TF conv2d_transpose filter layout
+        else:
+            self.wshape = (k, k, self.cin, cout)              # HWIO
+        self.pad = 0 if padding == 'VALID' else (k - 1) // 2  # TF SAME, odd k, stride 1: before = (k-1)//2
+        self.w_off = self.b_off = -1
+        self.pk_fwd = self.pk_dgrad = -1
+        self.need_dgrad = True
+
+    @property
+    def wsize(self):
+        return int(np.prod(self.wshape))
+
+
+class ParamStore(object):
+    """Flat fp32 arenas (params, grads, Adam m/v) + the packed MFMA-operand copy in the compute dtype.
+    Tensors are laid out in the order given (the models pass backward-production order so that
+    gradient buckets for the all-reduce are contiguous prefixes)."""
+
+    def __init__(self, layers, dtype, device, training=True):
+        self.layers = {l.name: l for l in layers}
+        self.order = [l.name for l in layers]
+        self.dtype, self.device, self.training = dtype, device, training
+        off = 0
+        for l in layers:
+            l.w_off = off; off += l.wsize
+            l.b_off = off; off += l.cout
+        self.n = off
+        self.p = torch.zeros(off, dtype=torch.float32, device=device)
+        if training:
+            self.g = torch.zeros(off, dtype=torch.float32, device=device)
+            self.m = torch.zeros(off, dtype=torch.float32, device=device)
+            self.v = torch.zeros(off, dtype=torch.float32, device=device)
+        self.step = torch.zeros(1, dtype=torch.int64, device=device)
+        # packed arena + table
+        entries, poff, blk = [], 0, 0
+        for l in layers:
+            if l.kind == 'first':
+                continue
+            seg0, seg1 = l.cin_segs[0], (l.cin_segs[1] if len(l.cin_segs) > 1 else 0)
+            seg0p, seg1p = l.cin_p[0], (l.cin_p[1] if len(l.cin_p) > 1 else 0)
+            kin = seg0p + seg1p
+            modes = []
+            if l.kind == 'conv':
+                modes.append((L.PACK_CONV_FWD, l.k * l.k, kin, l.cout_p, 'pk_fwd'))
+                if training and l.need_dgrad:
+                    modes.append((L.PACK_CONV_DGRAD, l.k * l.k, l.cout_p, kin, 'pk_dgrad'))
+            else:
+                modes.append((L.PACK_UP_FWD, 1, kin, 4 * l.cout_p, 'pk_fwd'))
+                if training and l.need_dgrad:
+                    modes.append((L.PACK_UP_DGRAD, 4, l.cout_p, kin, 'pk_dgrad'))
+            for mode, taps, kpad, ntot, attr in modes:
+                ne = taps * kpad * ntot
+                e = L.PackEntry(l.w_off, poff, mode, l.k if l.kind == 'conv' else 2, l.k if l.kind == 'conv' else 2,
+                                l.cin, l.cout, seg0, seg0p, seg1, seg1p, l.cout_p, kpad, ntot, ne, blk)
+                setattr(l, attr, poff)
+                entries.append(e)
+                poff += ne
+                blk += (ne + 255) // 256
+        self.packed = torch.zeros(max(poff, 8), dtype=torch_dtype(dtype), device=device)
+        self.n_pack_entries, self.pack_blocks = len(entries), blk
+        if entries:
+            raw = b''.join(bytes(e) for e in entries)
+            self.pack_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        else:
+            self.pack_table = None
+
+    # ---- host access (tests, snapshots, weight loading) ----
+    def packed_ptr(self, off):
+        return self.packed.data_ptr() + off * self.packed.element_size()
+
+    def p_ptr(self, off):
+        return self.p.data_ptr() + off * 4
+
+    def g_ptr(self, off):
+        return self.g.data_ptr() + off * 4
+
+    def set_params(self, params):
+        """params: {name: {'weights': ndarray, 'biases': ndarray}} in TF layouts."""
+        host = self.p.cpu().numpy().copy()
+        for name, l in self.layers.items():
+            w = np.asarray(params[name]['weights'], np.float32)
+            b = np.asarray(params[name]['biases'], np.float32)
+            if tuple(w.shape) != tuple(l.wshape) or b.shape != (l.cout,):
+                raise ValueError('shape mismatch for %s: %s vs %s' % (name, w.shape, l.wshape))
+            host[l.w_off:l.w_off + l.wsize] = w.reshape(-1)
+            host[l.b_off:l.b_off + l.cout] = b
+        self.p.copy_(torch.from_numpy(host))
+
+    def _unflatten(self, flat):
+        host = flat.detach().cpu().numpy()
+        out = {}
+        for name, l in self.layers.items():
+            out[name] = {'weights': host[l.w_off:l.w_off + l.wsize].reshape(l.wshape).copy(),
+                         'biases': host[l.b_off:l.b_off + l.cout].copy()}
+        return out
+
+    def get_params(self):
+        return self._unflatten(self.p)
+
+    def get_grads(self):
+        return self._unflatten(self.g)
+
+
+class Plan(object):
+    """Ordered list of C-ABI launches.  Every entry is (name, fn, args-without-stream)."""
+
+    def __init__(self, name=''):
+        self.name = name
+        self.ops = []
+        self.keep = []          # ctypes objects that must outlive the plan
+        self.flops = 0
+
+    def add(self, name, fn, *args):
+        self.ops.append((name, fn, args))
+
+    def run(self, stream):
+        sp = C.c_void_p(stream)
+        for name, fn, args in self.ops:
+            rc = fn(*args, sp)
+            if rc != 0:
+                L.check(rc, '%s/%s' % (self.name, name))
+
+    def __len__(self):
+        return len(self.ops)
+
+
+class Net(object):
+    """Emits launches for one network instance (fixed batch / spatial size / dtype)."""
+
+    def __init__(self, store, B, dtype, device):
+        self.lib = L.load()
+        self.store, self.B, self.dtype, self.device = store, B, dtype, device
+        self.acts = []
+
+    def act(self, H, W, C, f32=False, name=''):
+        a = Act(self.B, H, W, C, self.dtype, self.device, f32=f32, name=name)
+        self.acts.append(a)
+        return a
+
+    def act_bytes(self):
+        return sum(a.nbytes() for a in self.acts)
+
+    # ---------------- forward ----------------
+    def first_fwd(self, plan, layer, x_f32, H, W, dst):
+        Ho, Wo = H + 2 * layer.pad - 2, W + 2 * layer.pad - 2
+        dv = dst.view()
+        plan.keep.append(dv)
+        plan.add(layer.name, self.lib.seg_conv_first_fwd, x_f32.data_ptr(), self.B, H, W, layer.cin,
+                 self.store.p_ptr(layer.w_off), self.store.p_ptr(layer.b_off), layer.cout, layer.pad, C.byref(dv), Ho, Wo,
+                 1 if layer.relu else 0, self.dtype)
+        plan.flops += 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
+
+    def conv_fwd(self, plan, layer, srcs, Hi, Wi, dst, dst_off=(0, 0), out_f32=False, cfg=0):
+        """srcs: list of (Act, oy, ox) (1 or 2 concat segments)."""
+        k, pad = layer.k, layer.pad
+        Ho, Wo = Hi + 2 * pad - k + 1, Wi + 2 * pad - k + 1
+        d = L.ConvDesc()
+        d.src0 = srcs[0][0].view(srcs[0][1], srcs[0][2])
+        d.src1 = srcs[1][0].view(srcs[1][1], srcs[1][2]) if len(srcs) > 1 else L.null_view()
+        d.B, d.Hi, d.Wi = self.B, Hi, Wi
+        d.KH = d.KW = k; d.stride = 1; d.pad_t = d.pad_l = pad
+        d.Ho, d.Wo = Ho, Wo
+        d.w_packed = self.store.packed_ptr(layer.pk_fwd)
+        d.n_total = layer.cout_p; d.n_off = 0; d.n_count = layer.cout_p
+        d.bias = self.store.p_ptr(layer.b_off); d.bias_n = layer.cout
+        d.dst = dst.view(dst_off[0], dst_off[1])
+        d.up2 = 0; d.up_cout = 0; d.mask = L.null_view()
+        d.relu = 1 if layer.relu else 0
+        d.out_f32 = 1 if out_f32 else 0
+        d.dtype = self.dtype; d.cfg = cfg
+        plan.keep.append(d)
+        plan.add(layer.name, self.lib.seg_conv2d, C.byref(d))
+        plan.flops += 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
+        return Ho, Wo
+
+    def up_fwd(self, plan, layer, src, Hi, Wi, dst, cfg=0):
+        d = L.ConvDesc()
+        d.src0 = src.view(); d.src1 = L.null_view()
+        d.B, d.Hi, d.Wi = self.B, Hi, Wi
+        d.KH = d.KW = 1; d.stride = 1; d.pad_t = d.pad_l = 0
+        d.Ho, d.Wo = Hi, Wi
+        d.w_packed = self.store.packed_ptr(layer.pk_fwd)
+        d.n_total = 4 * layer.cout_p; d.n_off = 0; d.n_count = 4 * layer.cout_p
+        d.bias = self.store.p_ptr(layer.b_off); d.bias_n = layer.cout
+        d.dst = dst.view(); d.up2 = 1; d.up_cout = layer.cout_p; d.mask = L.null_view()
+        d.relu = 1 if layer.relu else 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
+        plan.keep.append(d)
+        plan.add(layer.name, self.lib.seg_conv2d, C.byref(d))
+        plan.flops += 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
+
+    def pool_fwd(self, plan, src, dst, Ho, Wo):
+        sv, dv = src.view(), dst.view()
+        plan.keep += [sv, dv]
+        plan.add('pool', self.lib.seg_maxpool2x2_fwd, C.byref(sv), C.byref(dv), None, self.B, Ho, Wo, src.Cp, self.dtype)
+
+    # ---------------- backward ----------------
+    def bias_grad(self, plan, layer, dz, H, W, dz_off=(0, 0)):
+        zv = dz.view(dz_off[0], dz_off[1])
+        plan.keep.append(zv)
+        plan.add(layer.name + '/db', self.lib.seg_bias_grad, C.byref(zv), self.B, H, W, layer.cout, self.store.g_ptr(layer.b_off), self.dtype)
+
+    def first_bwd(self, plan, layer, x_f32, H, W, dz):
+        Ho, Wo = H + 2 * layer.pad - 2, W + 2 * layer.pad - 2
+        zv = dz.view()
+        plan.keep.append(zv)
+        plan.add(layer.name + '/dw', self.lib.seg_conv_first_wgrad, x_f32.data_ptr(), self.B, H, W, layer.cin, C.byref(zv), Ho, Wo,
+                 layer.cout, layer.pad, self.store.g_ptr(layer.w_off), self.dtype)
+        self.bias_grad(plan, layer, dz, Ho, Wo)
+        plan.flops += 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
+
+    def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0):
+        """Filter + bias gradient, then one dgrad launch per entry of dsrcs.
+        dsrcs: list aligned with srcs; each None (no input gradient wanted) or
+        (dst_act, (oy,ox), mask_act_or_None, (moy,mox))."""
+        k, pad = layer.k, layer.pad
+        Ho, Wo = Hi + 2 * pad - k + 1, Wi + 2 * pad - k + 1
+        w = L.WgradDesc()
+        w.src0 = srcs[0][0].view(srcs[0][1], srcs[0][2])
+        w.src1 = srcs[1][0].view(srcs[1][1], srcs[1][2]) if len(srcs) > 1 else L.null_view()
+        w.src0_clog = layer.cin_segs[0]; w.src1_clog = layer.cin_segs[1] if len(srcs) > 1 else 0
+        w.B, w.Hi, w.Wi = self.B, Hi, Wi
+        w.KH = w.KW = k; w.stride = 1; w.pad_t = w.pad_l = pad
+        w.Ho, w.Wo = Ho, Wo
+        w.dz = dz.view(dz_off[0], dz_off[1]); w.n_log = layer.cout
+        w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = cfg
+        plan.keep.append(w)
+        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w))
+        plan.flops += 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
+        self.bias_grad(plan, layer, dz, Ho, Wo, dz_off)
+        n_off = 0
+        for i, ds in enumerate(dsrcs):
+            if ds is not None:
+                dst, doff, mask, moff = ds
+                d = L.ConvDesc()
+                d.src0 = dz.view(dz_off[0], dz_off[1]); d.src1 = L.null_view()
+                d.B, d.Hi, d.Wi = self.B, Ho, Wo
+                d.KH = d.KW = k; d.stride = 1; d.pad_t = d.pad_l = k - 1 - pad
+                d.Ho, d.Wo = Hi, Wi
+                d.w_packed = self.store.packed_ptr(layer.pk_dgrad)
+                d.n_total = sum(layer.cin_p); d.n_off = n_off; d.n_count = layer.cin_p[i]
+                d.bias = None; d.bias_n = 0
+                d.dst = dst.view(doff[0], doff[1]); d.up2 = 0; d.up_cout = 0
+                d.mask = mask.view(moff[0], moff[1]) if mask is not None else L.null_view()
+                d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
+                plan.keep.append(d)
+                plan.add(layer.name + '/dx%d' % i, self.lib.seg_conv2d, C.byref(d))
+                plan.flops += 2 * self.B * Ho * Wo * k * k * layer.cin_segs[i] * layer.cout
+            n_off += layer.cin_p[i]
+
+    def up_bwd(self, plan, layer, src, Hi, Wi, dzu, dsrc, mask, cfg=0):
+        """src: input Act [Hi,Wi,cin]; dzu: masked grad of the upsampled output [2Hi,2Wi,cout]."""
+        w = L.WgradDesc()
+        w.src0 = dzu.view(); w.src1 = L.null_view(); w.src0_clog = layer.cout; w.src1_clog = 0
+        w.B, w.Hi, w.Wi = self.B, 2 * Hi, 2 * Wi
+        w.KH = w.KW = 2; w.stride = 2; w.pad_t = w.pad_l = 0
+        w.Ho, w.Wo = Hi, Wi
+        w.dz = src.view(); w.n_log = layer.cin
+        w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = cfg
+        plan.keep.append(w)
+        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w))
+        self.bias_grad(plan, layer, dzu, 2 * Hi, 2 * Wi)
+        plan.flops += 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
+        if dsrc is not None:
+            d = L.ConvDesc()
+            d.src0 = dzu.view(); d.src1 = L.null_view()
+            d.B, d.Hi, d.Wi = self.B, 2 * Hi, 2 * Wi
+            d.KH = d.KW = 2; d.stride = 2; d.pad_t = d.pad_l = 0
+            d.Ho, d.Wo = Hi, Wi
+            d.w_packed = self.store.packed_ptr(layer.pk_dgrad)
+            d.n_total = layer.cin_p[0]; d.n_off = 0; d.n_count = layer.cin_p[0]
+            d.bias = None; d.bias_n = 0
+            d.dst = dsrc.view(); d.up2 = 0; d.up_cout = 0
+            d.mask = mask.view() if mask is not None else L.null_view()
+            d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
+            plan.keep.append(d)
+            plan.add(layer.name + '/dx', self.lib.seg_conv2d, C.byref(d))
+            plan.flops += 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
+
+    def pool_bwd(self, plan, y_act, dpool, add, add_hw, add_off, dz, H, W):
+        yv, zv = y_act.view(), dz.view()
+        pv = dpool.view() if dpool is not None else L.null_view()
+        av = add.view() if add is not None else L.null_view()
+        plan.keep += [yv, zv, pv, av]
+        plan.add('pool/bwd', self.lib.seg_maxpool2x2_bwd, C.byref(yv), C.byref(pv), C.byref(av), add_hw[0], add_hw[1],
+                 add_off[0], add_off[1], C.byref(zv), self.B, H, W, y_act.Cp, self.dtype)
+
+    # ---------------- loss / outputs / update ----------------
+    def softmax_xent(self, plan, logits, labels_u8, LH, LW, loff, H, W, n_classes, loss_buf, dlogits):
+        lv, dv = logits.view(), dlogits.view()
+        plan.keep += [lv, dv]
+        inv_n = 1.0 / float(self.B * H * W)
+        plan.add('xent', self.lib.seg_softmax_xent, C.byref(lv), labels_u8.data_ptr(), LH, LW, loff[0], loff[1], self.B, H, W,
+                 n_classes, inv_n, 1.0, loss_buf.data_ptr(), C.byref(dv), self.dtype)
+
+    def sigmoid_argmax(self, plan, logits, H, W, n_classes, sig, out):
+        lv = logits.view()
+        plan.keep.append(lv)
+        plan.add('sigmoid_argmax', self.lib.seg_sigmoid_argmax, C.byref(lv), self.B, H, W, n_classes, sig.data_ptr(), out.data_ptr())
+
+    def pack(self, plan):
+        s = self.store
+        if s.pack_table is None:
+            return
+        plan.add('pack', self.lib.seg_pack_weights, s.p.data_ptr(), s.packed.data_ptr(), s.pack_table.data_ptr(),
+                 s.n_pack_entries, s.pack_blocks, self.dtype)
+
+    def adam(self, plan, lr, grad_scale=1.0, b1=0.9, b2=0.999, eps=1e-8):
+        s = self.store
+        plan.add('adam', self.lib.seg_adam, s.p.data_ptr(), s.g.data_ptr(), s.m.data_ptr(), s.v.data_ptr(), s.n, lr, b1, b2, eps,
+                 grad_scale, s.step.data_ptr())
+        plan.add('step++', self.lib.seg_step_increment, s.step.data_ptr())

@@ -1,0 +1,302 @@
+"""UNetModel: the reference's U-Net (/root/reference/models/unet.py:24-175) compiled to HIP launch plans.
+
+Graph facts reproduced on purpose: every conv is 3x3 VALID + bias + ReLU; pool1
+consumes conv1_1 while conv1_2 only feeds the last skip; up-convs are 2x2/s2 transposed convs with
+ReLU; skips are centre-cropped and concatenated skip-first; `output` is a 1x1 conv without activation;
+input_y is centre-cropped to the logits; no BatchNorm, no dropout (`bayesian` is accepted and ignored,
+exactly as in the reference).
+
+MI355X design: concat and crop are views (the consuming conv reads two base pointers with window
+offsets); conv1_2 is evaluated only on the window that survives the crop when crop_aware=True
+(bit-identical results, fewer MACs -- bench.py reports MACs actually executed); ReLU-grad masks are
+fused into the producing dgrad epilogues and the crop-grad zero-pad + add into the max-pool backward.
+"""
+import torch
+
+from . import _lib as L
+from . import engine as E
+from .basemodel import BaseModel
+
+LEVELS = [('upconv1', 'conv4_2', 'conv6_1', 'conv6_2'), ('upconv2', 'conv3_2', 'conv7_1', 'conv7_2'),
+          ('upconv3', 'conv2_2', 'conv8_1', 'conv8_2'), ('upconv4', 'conv1_2', 'conv9_1', 'conv9_2')]
+# gradient arena order = the order backward produces the gradients (all-reduce buckets are prefixes)
+BWD_ORDER = ['output', 'conv9_2', 'conv9_1', 'upconv4', 'conv8_2', 'conv8_1', 'upconv3', 'conv7_2', 'conv7_1', 'upconv2',
+             'conv6_2', 'conv6_1', 'upconv1', 'conv5_2', 'conv5_1', 'conv4_2', 'conv4_1', 'conv3_2', 'conv3_1',
+             'conv2_2', 'conv2_1', 'conv1_2', 'conv1_1']
+
+
+def unet_layers(n_classes, n_kernels, input_channel):
+    nk = n_kernels
+    ls = {}
+
+    def conv(name, segs, co, k=3, relu=True, kind='conv'):
+        ls[name] = E.Layer(name, kind, k, segs, co, 'VALID', relu)
+    conv('conv1_1', [input_channel], nk, kind='first'); conv('conv1_2', [nk], nk)
+    conv('conv2_1', [nk], 2 * nk); conv('conv2_2', [2 * nk], 2 * nk)
+    conv('conv3_1', [2 * nk], 4 * nk); conv('conv3_2', [4 * nk], 4 * nk)
+    conv('conv4_1', [4 * nk], 8 * nk); conv('conv4_2', [8 * nk], 8 * nk)
+    conv('conv5_1', [8 * nk], 16 * nk); conv('conv5_2', [16 * nk], 16 * nk)
+    for i, w in enumerate((8, 4, 2, 1)):
+        ls['upconv%d' % (i + 1)] = E.Layer('upconv%d' % (i + 1), 'up', 2, [2 * w * nk], w * nk, 'VALID', True)
+        conv('conv%d_1' % (6 + i), [w * nk, w * nk], w * nk)
+        conv('conv%d_2' % (6 + i), [w * nk], w * nk)
+    conv('output', [nk], n_classes, k=1, relu=False)
+    ls['conv1_1'].need_dgrad = False
+    return [ls[n] for n in BWD_ORDER]
+
+
+def unet_sizes(n):
+    """Spatial ladder of the all-VALID graph for a square/rect edge n (raises when infeasible, F11)."""
+    s = {}
+
+    def cc(v, name):
+        if v < 3:
+            raise Exception('U-Net (all VALID) infeasible for input %d: %s would see a %dx%d map' % (n, name, v, v))
+        return v - 2
+    s['conv1_1'] = cc(n, 'conv1_1'); s['conv1_2'] = cc(s['conv1_1'], 'conv1_2')
+    v = s['conv1_1'] // 2; s['pool1'] = v
+    for i in (2, 3, 4, 5):
+        s['conv%d_1' % i] = cc(v, 'conv%d_1' % i); s['conv%d_2' % i] = cc(s['conv%d_1' % i], 'conv%d_2' % i)
+        if i < 5:
+            v = s['conv%d_2' % i] // 2; s['pool%d' % i] = v
+            if v < 1:
+                raise Exception('U-Net (all VALID) infeasible for input %d' % n)
+    v = s['conv5_2']
+    for i, (upn, skip, ca, cb) in enumerate(LEVELS):
+        s[upn] = 2 * v
+        if s[skip] < s[upn]:
+            raise Exception('U-Net infeasible for input %d: skip %s smaller than %s' % (n, skip, upn))
+        s[ca] = cc(s[upn], ca); s[cb] = cc(s[ca], cb); v = s[cb]
+    s['output'] = v
+    return s
+
+
+class UNetModel(BaseModel):
+    def __init__(self,
+                 sess=None,
+                 n_classes=2,
+                 log_dir=None,
+                 dataset=None,
+                 save_dir=None,
+                 bayesian=False,
+                 input_dims=512,
+                 mode='TRAINING',
+                 input_channel=3,
+                 test_dataset=None,
+                 learning_rate=1e-4,
+                 load_snapshot=None,
+                 load_snapshot_from=None,
+                 n_kernels=32,
+                 adversarial_training=False,
+                 **mi355x):
+        super(UNetModel, self).__init__(
+            sess=sess, mode=mode, log_dir=log_dir, dataset=dataset, bayesian=bayesian, save_dir=save_dir,
+            n_classes=n_classes, input_dims=input_dims, test_dataset=test_dataset, input_channel=input_channel,
+            load_snapshot=load_snapshot, learning_rate=learning_rate, load_snapshot_from=load_snapshot_from,
+            adversarial_training=adversarial_training, **mi355x)
+        self.model_name = 'unet'
+        self.IN_OUT_CROP = True
+        self.n_kernels = n_kernels
+        if n_classes > 32:
+            raise Exception('n_classes > 32 not supported')
+        self._init_input()
+        training = self.mode != 'INFERENCE'
+        self.layers = unet_layers(n_classes, n_kernels, input_channel)
+        self.store = E.ParamStore(self.layers, self.dtype, self.device, training=training)
+        self._init_weights()
+        self.net = None
+        if training:
+            self._build_training()
+        self._repack_initial()
+        self.inference_ops = ['y_hat_sig', 'output']
+        self._init_saver(self.model_name)
+
+    # ---- weights: slim defaults (xavier-uniform, zero biases), seeded ----
+    def _init_weights(self):
+        import numpy as np
+        rng = np.random.default_rng(self.seed)
+        params = {}
+        order = ['conv1_1', 'conv1_2', 'conv2_1', 'conv2_2', 'conv3_1', 'conv3_2', 'conv4_1', 'conv4_2', 'conv5_1', 'conv5_2',
+                 'upconv1', 'conv6_1', 'conv6_2', 'upconv2', 'conv7_1', 'conv7_2', 'upconv3', 'conv8_1', 'conv8_2',
+                 'upconv4', 'conv9_1', 'conv9_2', 'output']
+        for name in order:
+            l = self.store.layers[name]
+            k2 = l.wshape[0] * l.wshape[1]
+            lim = (6.0 / (k2 * l.wshape[2] + k2 * l.wshape[3])) ** 0.5
+            params[name] = {'weights': rng.uniform(-lim, lim, size=l.wshape).astype(np.float32),
+                            'biases': np.zeros((l.cout,), np.float32)}
+        self.store.set_params(params)
+
+    def _repack_initial(self):
+        if self.net is None:
+            self.net = E.Net(self.store, 1, self.dtype, self.device)
+        self._repack()
+
+    def model(self, input_op=None, reuse=False):
+        """The reference's model() declares the TF graph; here the graph is the compiled launch plan."""
+        return self.fwd_plan
+
+    # ---- forward graph (shared by training and inference builders) ----
+    def _emit_forward(self, net, plan, x_in, H, W, crop_aware):
+        nk, Ly = self.n_kernels, self.store.layers
+        if H != W:
+            sh, sw = unet_sizes(H), unet_sizes(W)
+        else:
+            sh = sw = unet_sizes(H)
+        A = {}
+        A['conv1_1'] = net.act(sh['conv1_1'], sw['conv1_1'], nk, name='conv1_1')
+        net.first_fwd(plan, Ly['conv1_1'], x_in, H, W, A['conv1_1'])
+        # conv1_2: only its centre window survives the crop of the last skip
+        t4h, t4w = sh['upconv4'], sw['upconv4']
+        o4h, o4w = (sh['conv1_2'] - t4h) // 2, (sw['conv1_2'] - t4w) // 2
+        if crop_aware:
+            A['conv1_2'] = net.act(t4h, t4w, nk, name='conv1_2')
+            net.conv_fwd(plan, Ly['conv1_2'], [(A['conv1_1'], o4h, o4w)], t4h + 2, t4w + 2, A['conv1_2'])
+            skip4_off = (0, 0)
+        else:
+            A['conv1_2'] = net.act(sh['conv1_2'], sw['conv1_2'], nk, name='conv1_2')
+            net.conv_fwd(plan, Ly['conv1_2'], [(A['conv1_1'], 0, 0)], sh['conv1_1'], sw['conv1_1'], A['conv1_2'])
+            skip4_off = (o4h, o4w)
+        prev, ph, pw = A['conv1_1'], sh['conv1_1'], sw['conv1_1']
+        for i in (2, 3, 4, 5):
+            P = net.act(sh['pool%d' % (i - 1)], sw['pool%d' % (i - 1)], prev.C, name='pool%d' % (i - 1))
+            net.pool_fwd(plan, prev, P, P.H, P.W)
+            A['pool%d' % (i - 1)] = P
+            c1, c2 = 'conv%d_1' % i, 'conv%d_2' % i
+            A[c1] = net.act(sh[c1], sw[c1], Ly[c1].cout, name=c1)
+            net.conv_fwd(plan, Ly[c1], [(P, 0, 0)], P.H, P.W, A[c1])
+            A[c2] = net.act(sh[c2], sw[c2], Ly[c2].cout, name=c2)
+            net.conv_fwd(plan, Ly[c2], [(A[c1], 0, 0)], sh[c1], sw[c1], A[c2])
+            prev = A[c2]
+        skip_off = {}
+        for i, (upn, skip, ca, cb) in enumerate(LEVELS):
+            A[upn] = net.act(sh[upn], sw[upn], Ly[upn].cout, name=upn)
+            net.up_fwd(plan, Ly[upn], prev, prev.H, prev.W, A[upn])
+            if skip == 'conv1_2':
+                off = skip4_off
+            else:
+                off = ((sh[skip] - sh[upn]) // 2, (sw[skip] - sw[upn]) // 2)      # crop_or_pad: floor offsets
+            skip_off[skip] = off
+            A[ca] = net.act(sh[ca], sw[ca], Ly[ca].cout, name=ca)
+            net.conv_fwd(plan, Ly[ca], [(A[skip], off[0], off[1]), (A[upn], 0, 0)], sh[upn], sw[upn], A[ca])
+            A[cb] = net.act(sh[cb], sw[cb], Ly[cb].cout, name=cb)
+            net.conv_fwd(plan, Ly[cb], [(A[ca], 0, 0)], sh[ca], sw[ca], A[cb])
+            prev = A[cb]
+        A['logits'] = net.act(sh['output'], sw['output'], self.n_classes, f32=True, name='logits')
+        net.conv_fwd(plan, Ly['output'], [(prev, 0, 0)], prev.H, prev.W, A['logits'], out_f32=True)
+        return A, sh, sw, skip_off, (o4h, o4w)
+
+    # ---- training plans ----
+    def _build_training(self):
+        B, (H, W) = self.batch_size, self.input_dims
+        net = self.net = E.Net(self.store, B, self.dtype, self.device)
+        Ly = self.store.layers
+        fwd = self.fwd_plan = E.Plan('fwd')
+        A, sh, sw, skip_off, o4 = self._emit_forward(net, fwd, self.input_x, H, W, self.crop_aware)
+        self.acts = A
+        oh, ow = sh['output'], sw['output']
+        self.out_hw = (oh, ow)
+        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+        dlog = net.act(oh, ow, self.n_classes, name='dlogits')
+        # label crop: resize_image_with_crop_or_pad(input_y, target, target) -> floor offsets (unet.py:171-174)
+        self.label_off = ((H - oh) // 2, (W - ow) // 2)
+        net.softmax_xent(fwd, A['logits'], self.input_y, H, W, self.label_off, oh, ow, self.n_classes, self.loss_buf, dlog)
+        self.dlogits = dlog
+
+        G = {}                                    # masked gradients dZ (same shape as the activation)
+
+        def gz(name):
+            a = A[name]
+            G[name] = net.act(a.H, a.W, a.C, name='d' + name)
+            return G[name]
+
+        seg = E.Plan('bwd0')
+        segs = []
+
+        def close_segment(last_layer):
+            nonlocal seg
+            l = Ly[last_layer]
+            segs.append((seg, l.b_off + l.cout))
+            seg = E.Plan('bwd%d' % len(segs))
+
+        # output layer
+        net.conv_bwd(seg, Ly['output'], [(A['conv9_2'], 0, 0)], A['conv9_2'].H, A['conv9_2'].W, dlog,
+                     [(gz('conv9_2'), (0, 0), A['conv9_2'], (0, 0))])
+        dskip = {}
+        prev_of = {'upconv1': 'conv5_2', 'upconv2': 'conv6_2', 'upconv3': 'conv7_2', 'upconv4': 'conv8_2'}
+        for lvl in (3, 2, 1, 0):
+            upn, skip, ca, cb = LEVELS[lvl]
+            # conv?_2
+            net.conv_bwd(seg, Ly[cb], [(A[ca], 0, 0)], A[ca].H, A[ca].W, G[cb], [(gz(ca), (0, 0), A[ca], (0, 0))])
+            # conv?_1 on [skip_crop | up]: two dgrad launches (skip half, up half)
+            so = skip_off[skip]
+            uh, uw = A[upn].H, A[upn].W
+            if skip == 'conv1_2':
+                # conv1_2's only consumer is this skip: its masked gradient is the skip half itself
+                dsk = net.act(uh, uw, A[skip].C, name='dz_conv1_2')
+                skip_spec = (dsk, (0, 0), A[skip], so)
+            else:
+                dsk = net.act(uh, uw, A[skip].C, name='dskip_' + skip)
+                skip_spec = (dsk, (0, 0), None, (0, 0))
+            dskip[skip] = dsk
+            net.conv_bwd(seg, Ly[ca], [(A[skip], so[0], so[1]), (A[upn], 0, 0)], uh, uw, G[ca],
+                         [skip_spec, (gz(upn), (0, 0), A[upn], (0, 0))])
+            # transposed conv
+            pn = prev_of[upn]
+            net.up_bwd(seg, Ly[upn], A[pn], A[pn].H, A[pn].W, G[upn], gz(pn), A[pn])
+        # bottleneck
+        net.conv_bwd(seg, Ly['conv5_2'], [(A['conv5_1'], 0, 0)], A['conv5_1'].H, A['conv5_1'].W, G['conv5_2'],
+                     [(gz('conv5_1'), (0, 0), A['conv5_1'], (0, 0))])
+        dP = {}
+        dP[4] = net.act(A['pool4'].H, A['pool4'].W, A['pool4'].C, name='dpool4')
+        net.conv_bwd(seg, Ly['conv5_1'], [(A['pool4'], 0, 0)], A['pool4'].H, A['pool4'].W, G['conv5_1'], [(dP[4], (0, 0), None, (0, 0))])
+        close_segment('conv5_1')
+        for i in (4, 3, 2):
+            c1, c2 = 'conv%d_1' % i, 'conv%d_2' % i
+            so = skip_off[c2]
+            net.pool_bwd(seg, A[c2], dP[i], dskip[c2], (dskip[c2].H, dskip[c2].W), so, gz(c2), A[c2].H, A[c2].W)
+            net.conv_bwd(seg, Ly[c2], [(A[c1], 0, 0)], A[c1].H, A[c1].W, G[c2], [(gz(c1), (0, 0), A[c1], (0, 0))])
+            pin = A['pool%d' % (i - 1)]
+            dP[i - 1] = net.act(pin.H, pin.W, pin.C, name='dpool%d' % (i - 1))
+            net.conv_bwd(seg, Ly[c1], [(pin, 0, 0)], pin.H, pin.W, G[c1], [(dP[i - 1], (0, 0), None, (0, 0))])
+        # conv1_2 (window of conv1_1 at o4, extent t4+2) then pool1 + skip add -> dZ(conv1_1)
+        t4h, t4w = A['upconv4'].H, A['upconv4'].W
+        d11s = net.act(t4h + 2, t4w + 2, A['conv1_1'].C, name='d_conv1_1_skip')
+        net.conv_bwd(seg, Ly['conv1_2'], [(A['conv1_1'], o4[0], o4[1])], t4h + 2, t4w + 2, dskip['conv1_2'],
+                     [(d11s, (0, 0), None, (0, 0))])
+        net.pool_bwd(seg, A['conv1_1'], dP[1], d11s, (t4h + 2, t4w + 2), o4, gz('conv1_1'), A['conv1_1'].H, A['conv1_1'].W)
+        net.first_bwd(seg, Ly['conv1_1'], self.input_x, H, W, G['conv1_1'])
+        close_segment('conv1_1')
+        self.grads_act = G
+        # segments -> [(plan, (lo, hi))] gradient slices completed by each
+        self.bwd_segments, lo = [], 0
+        for plan, hi in segs:
+            self.bwd_segments.append((plan, (lo, hi)))
+            lo = hi
+        assert lo == self.store.n
+        self.bwd_plan = E.Plan('bwd')
+        for plan, _ in self.bwd_segments:
+            self.bwd_plan.ops += plan.ops
+            self.bwd_plan.keep += plan.keep
+            self.bwd_plan.flops += plan.flops
+        upd = self.upd_plan = E.Plan('update')
+        net.adam(upd, self.learning_rate, grad_scale=1.0 / self.pg.world)
+        net.pack(upd)
+        # training-time outputs (y_hat_sig, output) on demand
+        self.y_hat = A['logits']
+
+    # ---- inference plan for an arbitrary batch / size ----
+    def _build_infer(self, B, H, W, Cin):
+        if Cin != self.input_channel:
+            raise Exception('infer(): expected %d input channels, got %d' % (self.input_channel, Cin))
+        net = E.Net(self.store, B, self.dtype, self.device)
+        plan = E.Plan('infer')
+        x_in = torch.zeros((B, H, W, Cin), dtype=torch.float32, device=self.device)
+        A, sh, sw, _, _ = self._emit_forward(net, plan, x_in, H, W, self.crop_aware)
+        oh, ow = sh['output'], sw['output']
+        sig = torch.zeros((B, oh, ow, self.n_classes), dtype=torch.float32, device=self.device)
+        out = torch.zeros((B, oh, ow, 1), dtype=torch.float32, device=self.device)
+        net.sigmoid_argmax(plan, A['logits'], oh, ow, self.n_classes, sig, out)
+        plan.net = net
+        plan.acts = A
+        return plan, x_in, sig, out

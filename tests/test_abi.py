@@ -1,0 +1,90 @@
+"""CPU tests of the boundary: libseg_hip.so builds/loads, exports every symbol include/seg_hip.h declares, the
+ctypes mirrors have the C struct layouts, and the product path refuses to run without a GPU (no fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, 'include', 'seg_hip.h')
+
+
+def _declared():
+    txt = open(HDR).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(seg_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from segmentation_amd import _build, _lib
+    _build.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), n
+    bound = set(_lib.SIGNATURES) | {'seg_last_error', 'seg_version'}
+    assert bound == set(names)
+    assert _lib.load().seg_version() == 100
+
+
+def test_ctypes_struct_layouts_match_c(tmp_path):
+    from segmentation_amd import _lib
+    src = tmp_path / 's.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "seg_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(seg_view),sizeof(seg_conv_desc),sizeof(seg_wgrad_desc),sizeof(seg_pack_entry),'
+                   'offsetof(seg_conv_desc,dst),offsetof(seg_conv_desc,cfg),offsetof(seg_wgrad_desc,dw));return 0;}')
+    exe = tmp_path / 's'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    got = list(map(int, subprocess.check_output([str(exe)]).split()))
+    want = [ctypes.sizeof(_lib.View), ctypes.sizeof(_lib.ConvDesc), ctypes.sizeof(_lib.WgradDesc), ctypes.sizeof(_lib.PackEntry),
+            _lib.ConvDesc.dst.offset, _lib.ConvDesc.cfg.offset, _lib.WgradDesc.dw.offset]
+    assert got == want
+
+
+def test_argument_validation_without_gpu():
+    from segmentation_amd import _lib
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    assert lib.seg_conv2d(ctypes.byref(d), None) == -1
+    assert b'null pointer' in lib.seg_last_error()
+    w = _lib.WgradDesc()
+    assert lib.seg_conv2d_wgrad(ctypes.byref(w), None) == -1
+    with pytest.raises(_lib.SegError):
+        _lib.check(-1, 'x')
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from segmentation_amd.unet import UNetModel
+    from segmentation_amd.datasets import ArrayDataSet
+    import numpy as np
+    ds = ArrayDataSet(np.zeros((1, 1, 188, 188, 3), np.float32), np.zeros((1, 1, 188, 188, 1), np.uint8))
+    with pytest.raises(Exception) as e:
+        UNetModel(sess=None, dataset=ds, n_classes=2, input_dims=188, save_dir=None, load_snapshot=False)
+    assert 'no GPU' in str(e.value) or 'HIP' in str(e.value)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'segmentation_amd')
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', txt, flags=re.M), f
+
+
+def test_unet_plan_geometry():
+    from segmentation_amd.unet import unet_sizes, unet_layers
+    s = unet_sizes(256)
+    assert (s['conv1_1'], s['conv1_2'], s['pool1'], s['conv5_2'], s['upconv1'], s['upconv4'], s['output']) == (254, 252, 127, 8, 16, 72, 68)
+    assert unet_sizes(512)['output'] == 324 and unet_sizes(186)['output'] == 4
+    with pytest.raises(Exception):
+        unet_sizes(128)
+    ls = unet_layers(4, 32, 3)
+    assert sum(l.wsize + l.cout for l in ls) == 7760196

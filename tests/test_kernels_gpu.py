@@ -1,0 +1,284 @@
+"""-m gpu parity tests, kernel level: every C-ABI entry point vs the numpy oracle on identical inputs,
+at the odd sizes the VALID U-Net actually produces.  f32 mode: <= 2e-5 relative (exact-f32 MFMA vs float64
+oracle); bf16 mode: inputs/weights pre-rounded to bf16, <= 2e-2 relative (bf16 output rounding)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ops as ops
+from segmentation_amd import _lib as L
+from segmentation_amd import engine as E
+import gpu_util as U
+
+pytestmark = pytest.mark.gpu
+DT = [L.SEG_F32, L.SEG_BF16]
+
+
+def _rand_params(layer, rng, dtype):
+    w = rng.standard_normal(layer.wshape).astype(np.float32) * 0.2
+    b = rng.standard_normal(layer.cout).astype(np.float32) * 0.1
+    return {'weights': w, 'biases': b}
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('case', [
+    # k, padding, segs, cout, H, W, B, relu, cfg
+    (3, 'VALID', [32], 64, 13, 15, 2, True, 0),
+    (3, 'VALID', [32], 64, 13, 15, 2, True, 1),
+    (3, 'VALID', [32], 64, 13, 15, 2, True, 3),
+    (3, 'VALID', [64], 32, 21, 19, 1, True, 2),
+    (3, 'VALID', [64], 32, 10, 10, 2, False, 4),
+    (3, 'SAME', [64], 96, 9, 11, 2, True, 0),
+    (3, 'VALID', [64, 32], 64, 12, 12, 2, True, 0),
+    (3, 'VALID', [16], 24, 11, 11, 1, True, 0),          # unpadded channel counts (n_kernels=16 style)
+    (1, 'SAME', [96], 4, 7, 9, 2, False, 0),
+    (1, 'SAME', [64], 160, 16, 16, 1, True, 0),
+])
+def test_conv_fwd_bwd(dtype, case):
+    k, padding, segs, cout, H, W, B, relu, cfg = case
+    rng = np.random.default_rng(k * 7919 + sum(segs) * 31 + cout * 17 + H * 5 + W + cfg)
+    layer = E.Layer('c', 'conv', k, segs, cout, padding, relu)
+    p = {'c': _rand_params(layer, rng, dtype)}
+    p['c']['weights'] = U.round_dtype(p['c']['weights'], dtype).astype(np.float32)
+    store = U.make_store([layer], dtype, p)
+    net = E.Net(store, B, dtype, U.dev())
+    # sources live inside larger buffers to exercise window offsets
+    srcs, xs = [], []
+    for i, c in enumerate(segs):
+        a = net.act(H + 3 + i, W + 2, c)
+        full = U.round_dtype(rng.standard_normal((B, a.H, a.W, c)), dtype)
+        U.fill_act(a, full)
+        oy, ox = 1 + i, 2 - i
+        srcs.append((a, oy, ox))
+        xs.append(full[:, oy:oy + H, ox:ox + W, :])
+    x = np.concatenate(xs, -1)
+    pad = layer.pad
+    Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
+    out = net.act(Ho, Wo, cout)
+    plan = E.Plan('t')
+    net.conv_fwd(plan, layer, srcs, H, W, out, cfg=cfg)
+    plan.run(U.stream()); U.sync()
+    ref = ops.conv2d(x, p['c']['weights'], p['c']['biases'], padding, 1, relu)
+    got = U.read_act(out)
+    assert U.rel_err(got, ref) < U.tol(dtype), 'fwd'
+    assert U.pad_channels_zero(out)
+
+    # backward: dz random (already "masked"), check dW, db, dX (with and without a ReLU-grad mask)
+    dzv = U.round_dtype(rng.standard_normal((B, Ho, Wo, cout)) * 0.5, dtype)
+    dz = net.act(Ho, Wo, cout); U.fill_act(dz, dzv)
+    dsrc_acts, dspecs, masks = [], [], []
+    for i, c in enumerate(segs):
+        da = net.act(H, W, c)
+        if i == 0:
+            mk = net.act(H, W, c)
+            mv = U.round_dtype(rng.standard_normal((B, H, W, c)), dtype)
+            U.fill_act(mk, mv)
+            masks.append(mv)
+            dspecs.append((da, (0, 0), mk, (0, 0)))
+        else:
+            masks.append(None)
+            dspecs.append((da, (0, 0), None, (0, 0)))
+        dsrc_acts.append(da)
+    store.g.zero_()
+    bplan = E.Plan('b')
+    net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs, cfg=cfg)
+    bplan.run(U.stream()); U.sync()
+    dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (k, k), padding, 1)
+    dx_ref = ops.conv2d_dgrad(dzv, p['c']['weights'], (H, W), padding, 1)
+    g = store.get_grads()['c']
+    assert U.rel_err(g['weights'], dw_ref) < U.tol(dtype, 2e-5, 1e-2), 'wgrad'
+    assert U.rel_err(g['biases'], db_ref) < U.tol(dtype, 2e-5, 1e-2), 'bias grad'
+    c0 = 0
+    for i, c in enumerate(segs):
+        want = dx_ref[..., c0:c0 + c]
+        if masks[i] is not None:
+            want = want * (masks[i] > 0)
+        assert U.rel_err(U.read_act(dsrc_acts[i]), want) < U.tol(dtype), 'dgrad seg %d' % i
+        assert U.pad_channels_zero(dsrc_acts[i])
+        c0 += c
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('case', [(64, 32, 8, 8, 2), (32, 32, 36, 36, 1), (128, 64, 5, 7, 2), (24, 8, 6, 6, 1)])
+def test_upconv_fwd_bwd(dtype, case):
+    cin, cout, H, W, B = case
+    rng = np.random.default_rng(cin * 1000 + H)
+    layer = E.Layer('u', 'up', 2, [cin], cout, 'VALID', True)
+    p = {'u': _rand_params(layer, rng, dtype)}
+    p['u']['weights'] = U.round_dtype(p['u']['weights'], dtype).astype(np.float32)
+    store = U.make_store([layer], dtype, p)
+    net = E.Net(store, B, dtype, U.dev())
+    xa = net.act(H, W, cin)
+    xv = U.round_dtype(rng.standard_normal((B, H, W, cin)), dtype); U.fill_act(xa, xv)
+    out = net.act(2 * H, 2 * W, cout)
+    plan = E.Plan('t'); net.up_fwd(plan, layer, xa, H, W, out); plan.run(U.stream()); U.sync()
+    ref = ops.conv2d_transpose(xv, p['u']['weights'], p['u']['biases'], 2, 'VALID', True)
+    assert U.rel_err(U.read_act(out), ref) < U.tol(dtype), 'up fwd'
+    assert U.pad_channels_zero(out)
+    dzv = U.round_dtype(rng.standard_normal((B, 2 * H, 2 * W, cout)) * 0.5, dtype)
+    dz = net.act(2 * H, 2 * W, cout); U.fill_act(dz, dzv)
+    dx = net.act(H, W, cin)
+    store.g.zero_()
+    bplan = E.Plan('b'); net.up_bwd(bplan, layer, xa, H, W, dz, dx, xa); bplan.run(U.stream()); U.sync()
+    dw_ref, db_ref = ops.conv2d_transpose_wgrad(xv, dzv, (2, 2), 2, 'VALID')
+    dx_ref = ops.conv2d_transpose_dgrad(dzv, p['u']['weights'], (H, W), 2, 'VALID') * (xv > 0)
+    g = store.get_grads()['u']
+    assert U.rel_err(g['weights'], dw_ref) < U.tol(dtype, 2e-5, 1e-2), 'up wgrad'
+    assert U.rel_err(g['biases'], db_ref) < U.tol(dtype, 2e-5, 1e-2), 'up bias grad'
+    assert U.rel_err(U.read_act(dx), dx_ref) < U.tol(dtype), 'up dgrad'
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('pad,cin,cout,H', [(0, 3, 32, 21), (1, 3, 16, 18), (0, 1, 40, 33)])
+def test_conv_first(dtype, pad, cin, cout, H):
+    B, W = 2, H + 3
+    rng = np.random.default_rng(cout + H)
+    layer = E.Layer('f', 'first', 3, [cin], cout, 'VALID' if pad == 0 else 'SAME', True)
+    p = {'f': _rand_params(layer, rng, dtype)}
+    store = U.make_store([layer], dtype, p)
+    net = E.Net(store, B, dtype, U.dev())
+    x = rng.uniform(0, 1, (B, H, W, cin)).astype(np.float32)
+    xt = torch.from_numpy(x).to(U.dev())
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    out = net.act(Ho, Wo, cout)
+    plan = E.Plan('t'); net.first_fwd(plan, layer, xt, H, W, out); plan.run(U.stream()); U.sync()
+    ref = ops.conv2d(x, p['f']['weights'], p['f']['biases'], layer.padding, 1, True)
+    assert U.rel_err(U.read_act(out), ref) < U.tol(dtype, 2e-5, 1e-2)
+    assert U.pad_channels_zero(out)
+    if cin <= 3:
+        dzv = U.round_dtype(rng.standard_normal((B, Ho, Wo, cout)), dtype)
+        dz = net.act(Ho, Wo, cout); U.fill_act(dz, dzv)
+        store.g.zero_()
+        bp = E.Plan('b'); net.first_bwd(bp, layer, xt, H, W, dz); bp.run(U.stream()); U.sync()
+        dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (3, 3), layer.padding, 1)
+        g = store.get_grads()['f']
+        assert U.rel_err(g['weights'], dw_ref) < 2e-5
+        assert U.rel_err(g['biases'], db_ref) < 2e-5
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('H,W,Ch', [(13, 11, 32), (8, 8, 64), (7, 9, 16)])
+def test_maxpool_fwd_bwd(dtype, H, W, Ch):
+    B = 2
+    rng = np.random.default_rng(H * 100 + Ch)
+    lib = L.load()
+    net = E.Net(None, B, dtype, U.dev())
+    ya = net.act(H, W, Ch)
+    yv = np.maximum(U.round_dtype(rng.standard_normal((B, H, W, Ch)), dtype), 0)      # post-ReLU, many exact-zero ties
+    U.fill_act(ya, yv)
+    Ho, Wo = H // 2, W // 2
+    pa = net.act(Ho, Wo, Ch)
+    idx = torch.zeros((B, Ho, Wo, ya.Cp), dtype=torch.uint8, device=U.dev())
+    sv, dv = ya.view(), pa.view()
+    L.check(lib.seg_maxpool2x2_fwd(C.byref(sv), C.byref(dv), idx.data_ptr(), B, Ho, Wo, ya.Cp, dtype, U.stream()))
+    U.sync()
+    pref, iref = ops.max_pool2x2(yv)
+    assert np.array_equal(U.read_act(pa), pref)
+    assert np.array_equal(idx.cpu().numpy()[..., :Ch], iref)
+    # backward with a skip-gradient add window
+    dpv = U.round_dtype(rng.standard_normal((B, Ho, Wo, Ch)), dtype)
+    dpa = net.act(Ho, Wo, Ch); U.fill_act(dpa, dpv)
+    ah, aw, ay, ax = 4, 5, 2, 1
+    addv = U.round_dtype(rng.standard_normal((B, ah, aw, Ch)), dtype)
+    adda = net.act(ah, aw, Ch); U.fill_act(adda, addv)
+    dza = net.act(H, W, Ch)
+    plan = E.Plan('b'); net.pool_bwd(plan, ya, dpa, adda, (ah, aw), (ay, ax), dza, H, W); plan.run(U.stream()); U.sync()
+    ref = ops.max_pool2x2_bwd(dpv, iref, (H, W))
+    pad = np.zeros_like(ref); pad[:, ay:ay + ah, ax:ax + aw, :] = addv
+    ref = (ref + pad) * (yv > 0)
+    got = U.read_act(dza)
+    assert U.rel_err(got, ref) < U.tol(dtype, 1e-6, 1e-2)
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('nc', [2, 4, 21])
+def test_softmax_xent_and_sigmoid_argmax(dtype, nc):
+    B, H, W, LH, LW = 2, 9, 7, 15, 12
+    rng = np.random.default_rng(nc)
+    lib = L.load()
+    net = E.Net(None, B, dtype, U.dev())
+    lg = net.act(H, W, nc, f32=True)
+    z = (rng.standard_normal((B, H, W, nc)) * 3).astype(np.float32)
+    z[0, 0, 0, :] = 25.0           # saturated tie -> index 0
+    z[0, 0, 1, -1] = 30.0; z[0, 0, 1, 0] = 18.0
+    U.fill_act(lg, z)
+    labels = rng.integers(0, nc, (B, LH, LW)).astype(np.uint8)
+    lt = torch.from_numpy(labels).to(U.dev())
+    loss = torch.zeros(1, dtype=torch.float32, device=U.dev())
+    dl = net.act(H, W, nc)
+    plan = E.Plan('x'); net.softmax_xent(plan, lg, lt, LH, LW, (3, 2), H, W, nc, loss, dl); plan.run(U.stream()); U.sync()
+    lref, _, dref = ops.softmax_xent(z, labels[:, 3:3 + H, 2:2 + W])
+    assert abs(float(loss.item()) - lref) < 1e-5 * max(1, abs(lref))
+    assert U.rel_err(U.read_act(dl), dref) < U.tol(dtype, 1e-5, 1e-2)
+    assert U.pad_channels_zero(dl)
+    sig = torch.zeros((B, H, W, nc), dtype=torch.float32, device=U.dev())
+    out = torch.zeros((B, H, W, 1), dtype=torch.float32, device=U.dev())
+    p2 = E.Plan('s'); net.sigmoid_argmax(p2, lg, H, W, nc, sig, out); p2.run(U.stream()); U.sync()
+    sref, oref = ops.sigmoid_argmax(z)
+    assert np.array_equal(sig.cpu().numpy(), sref)          # bit-exact float32 sigmoid
+    assert np.array_equal(out.cpu().numpy(), oref)          # bit-exact argmax incl. saturated ties
+    assert out[0, 0, 0, 0].item() == 0.0
+
+
+def test_adam_matches_tf_variant():
+    n = 1003
+    rng = np.random.default_rng(1)
+    lib = L.load()
+    p0, g0 = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    p = torch.from_numpy(p0.copy()).to(U.dev()); g = torch.from_numpy(g0).to(U.dev())
+    m = torch.zeros(n, device=U.dev()); v = torch.zeros(n, device=U.dev())
+    step = torch.zeros(1, dtype=torch.int64, device=U.dev())
+    pr, mr, vr = p0.astype(np.float64), np.zeros(n), np.zeros(n)
+    for t in (1, 2, 3):
+        L.check(lib.seg_adam(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.5, step.data_ptr(), U.stream()))
+        L.check(lib.seg_step_increment(step.data_ptr(), U.stream()))
+        pr, mr, vr = ops.adam_tf(pr, g0.astype(np.float64) * 0.5, mr, vr, t, lr=1e-3)
+    U.sync()
+    assert int(step.item()) == 3
+    assert np.allclose(p.cpu().numpy(), pr, atol=1e-6)
+    assert np.allclose(m.cpu().numpy(), mr, atol=1e-6) and np.allclose(v.cpu().numpy(), vr, atol=1e-7)
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('f,Hs,Hd,add', [(2, 4, 8, True), (8, 4, 30, False), (2, 5, 9, True), (8, 3, 26, False)])
+def test_bilinear_up(dtype, f, Hs, Hd, add):
+    B, Cc = 2, 5
+    rng = np.random.default_rng(f * 10 + Hs)
+    lib = L.load()
+    net = E.Net(None, B, dtype, U.dev())
+    sa = net.act(Hs, Hs, Cc); sv = U.round_dtype(rng.standard_normal((B, Hs, Hs, Cc)), dtype); U.fill_act(sa, sv)
+    filt = ops.upsample_filt(ops.get_kernel_size(f)).astype(np.float32)
+    ft = torch.from_numpy(filt).to(U.dev())
+    full = ops.conv2d_transpose(sv, ops.bilinear_upsample_weights(f, Cc), None, f, 'SAME')
+    ref = ops.crop_or_pad(full, Hd, Hd)
+    cy = (Hs * f - Hd) // 2 if Hs * f >= Hd else -((Hd - Hs * f) // 2)
+    da = net.act(Hd, Hd, Cc, f32=not add)
+    s_v, d_v = sa.view(), da.view()
+    if add:
+        aa = net.act(Hd, Hd, Cc); av = U.round_dtype(rng.standard_normal((B, Hd, Hd, Cc)), dtype); U.fill_act(aa, av)
+        a_v = aa.view(); ref = ref + av
+        L.check(lib.seg_bilinear_up_fwd(C.byref(s_v), Hs, Hs, f, ft.data_ptr(), C.byref(a_v), C.byref(d_v), Hd, Hd, cy, cy, B, sa.Cp, 0, dtype, U.stream()))
+    else:
+        L.check(lib.seg_bilinear_up_fwd(C.byref(s_v), Hs, Hs, f, ft.data_ptr(), None, C.byref(d_v), Hd, Hd, cy, cy, B, sa.Cp, 1, dtype, U.stream()))
+    U.sync()
+    assert U.rel_err(U.read_act(da), ref) < U.tol(dtype, 1e-6, 1e-2)
+    # adjoint
+    gv = U.round_dtype(rng.standard_normal((B, Hd, Hd, Cc)), dtype)
+    ga = net.act(Hd, Hd, Cc); U.fill_act(ga, gv)
+    dsa = net.act(Hs, Hs, Cc)
+    g_v, ds_v = ga.view(), dsa.view()
+    L.check(lib.seg_bilinear_up_bwd(C.byref(g_v), Hd, Hd, cy, cy, f, ft.data_ptr(), C.byref(ds_v), Hs, Hs, B, sa.Cp, 0, dtype, U.stream()))
+    U.sync()
+    gref = ops.conv2d_transpose_dgrad(ops.crop_or_pad_bwd(gv, (Hs * f, Hs * f)), ops.bilinear_upsample_weights(f, Cc), (Hs, Hs), f, 'SAME')
+    assert U.rel_err(U.read_act(dsa), gref) < U.tol(dtype, 1e-6, 1e-2)
+
+
+def test_error_paths():
+    lib = L.load()
+    d = L.ConvDesc()
+    assert lib.seg_conv2d(C.byref(d), None) != 0
+    assert b'null' in lib.seg_last_error()
+    assert lib.seg_conv2d(None, None) != 0
+    assert lib.seg_adam(None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 0.0, None, None) != 0
