@@ -413,11 +413,11 @@ __global__ void bilinear_bwd_kernel(seg_view dd, int Hd, int Wd, int cy, int cx,
     const int iy = t % Hs; const int b = t / Hs;
     float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int u = 0; u < k; ++u) {
-      const int y = iy * f + u - pb - cy;
-      if (y < 0 || y >= Hd) continue;
+      const int Y = iy * f + u - pb, y = Y - cy;          // Y: position in the SAME-cropped upsampled map
+      if (Y < 0 || Y >= Hs * f || y < 0 || y >= Hd) continue;
       for (int v = 0; v < k; ++v) {
-        const int x = ix * f + v - pb - cx;
-        if (x < 0 || x >= Wd) continue;
+        const int X = ix * f + v - pb, x = X - cx;
+        if (X < 0 || X >= Ws * f || x < 0 || x >= Wd) continue;
         const float w = filt[u * k + v];
         const int64_t off = view_off(dd, b, y, x) + c8 * 8;
         if (dd_f32) { Vec8<float> s; s.load(reinterpret_cast<const float*>(dd.ptr) + off); for (int e = 0; e < 8; ++e) a[e] += w * s.get(e); }

@@ -256,7 +256,7 @@ class Net(object):
         self.bias_grad(plan, layer, dz, Ho, Wo)
         plan.flops += 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
 
-    def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0):
+    def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0):
         """Filter + bias gradient, then one dgrad launch per entry of dsrcs.
         dsrcs: list aligned with srcs; each None (no input gradient wanted) or
         (dst_act, (oy,ox), mask_act_or_None, (moy,mox))."""
@@ -270,7 +270,7 @@ class Net(object):
         w.KH = w.KW = k; w.stride = 1; w.pad_t = w.pad_l = pad
         w.Ho, w.Wo = Ho, Wo
         w.dz = dz.view(dz_off[0], dz_off[1]); w.n_log = layer.cout
-        w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = cfg
+        w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = wcfg
         plan.keep.append(w)
         plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w))
         plan.flops += 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
@@ -295,7 +295,7 @@ class Net(object):
                 plan.flops += 2 * self.B * Ho * Wo * k * k * layer.cin_segs[i] * layer.cout
             n_off += layer.cin_p[i]
 
-    def up_bwd(self, plan, layer, src, Hi, Wi, dzu, dsrc, mask, cfg=0):
+    def up_bwd(self, plan, layer, src, Hi, Wi, dzu, dsrc, mask, cfg=0, wcfg=0):
         """src: input Act [Hi,Wi,cin]; dzu: masked grad of the upsampled output [2Hi,2Wi,cout]."""
         w = L.WgradDesc()
         w.src0 = dzu.view(); w.src1 = L.null_view(); w.src0_clog = layer.cout; w.src1_clog = 0
@@ -303,7 +303,7 @@ class Net(object):
         w.KH = w.KW = 2; w.stride = 2; w.pad_t = w.pad_l = 0
         w.Ho, w.Wo = Hi, Wi
         w.dz = src.view(); w.n_log = layer.cin
-        w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = cfg
+        w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = wcfg
         plan.keep.append(w)
         plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w))
         self.bias_grad(plan, layer, dzu, 2 * Hi, 2 * Wi)

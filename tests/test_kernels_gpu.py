@@ -83,7 +83,7 @@ def test_conv_fwd_bwd(dtype, case):
         dsrc_acts.append(da)
     store.g.zero_()
     bplan = E.Plan('b')
-    net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs, cfg=cfg)
+    net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs)
     bplan.run(U.stream()); U.sync()
     dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (k, k), padding, 1)
     dx_ref = ops.conv2d_dgrad(dzv, p['c']['weights'], (H, W), padding, 1)
