@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- train-step images/sec of the U-Net 256x256x3 -> 4-class config (BASELINE.json configs[1]):
+B=16 images per GPU, bf16 storage / fp32 accumulate, fwd + mean softmax-x-entropy + bwd + TF-Adam + weight repack,
+synthetic data resident in HBM, n_kernels=32, lr 1e-4.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Rank 0 prints ONE JSON line.  Weak scaling: 16 images per rank, gradients SUM-all-reduced over RCCL.
+Extra objects: "roofline" (dominant kernel family, HIP-event timed on the launch stream, algorithmic FLOPs of the
+MACs actually executed) and "cpu_baseline" (the oracle's torch-CPU port timed on this box's host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=16, help='images per GPU')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--classes', type=int, default=4)
+    ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--dense', action='store_true', help='evaluate conv1_2 densely (no crop-aware window)')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--per-op', action='store_true', help='also print the per-op table to stderr')
+    return ap.parse_args()
+
+
+def kernel_table(model, reps=5):
+    """Per-launch durations with HIP events recorded on the stream the kernels run on, aggregated by kernel
+    template instance (the names rocprofv3 --kernel-trace --stats prints)."""
+    stream = torch.cuda.current_stream().cuda_stream
+    agg = {}
+    ops = []
+    for rep in range(reps + 1):
+        model.store.g.zero_(); model.loss_buf.zero_()
+        rows = []
+        for plan in (model.fwd_plan, model.bwd_plan, model.upd_plan):
+            rows += plan.run_profiled(stream, torch)
+        if rep == 0:
+            continue               # warm-up
+        for i, (op, kern, ms, fl) in enumerate(rows):
+            a = agg.setdefault(kern, {'ms': 0.0, 'launches': 0, 'flops': 0})
+            a['ms'] += ms; a['launches'] += 1; a['flops'] += fl
+            if rep == 1:
+                ops.append([op, kern, ms, fl])
+            else:
+                ops[i][2] += ms
+    for o in ops:
+        o[2] /= reps
+    return agg, ops
+
+
+def cpu_baseline(args):
+    """The oracle's torch-CPU port (oracle/torch_ref.py: same graph, TF-Adam, float32, all host threads) on a
+    bounded sample of the same workload.  TensorFlow itself cannot be run here."""
+    from oracle import unet as ounet
+    from oracle import torch_ref
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    bs = 2
+    p = ounet.init_params(args.classes, 32, 3, seed=5555)
+    st = torch_ref.TorchUNetStepper(p, lr=1e-4, threads=threads)
+    rng = np.random.default_rng(5555)
+    x = rng.uniform(0, 1, (bs, args.size, args.size, 3)).astype(np.float32)
+    y = rng.integers(0, args.classes, (bs, args.size, args.size, 1)).astype(np.uint8)
+    st.train_step(x, y)                      # warm-up
+    n, t0 = 0, time.time()
+    while n < 3 or (time.time() - t0 < 10.0 and n < 50):
+        st.train_step(x, y); n += 1
+    dt = time.time() - t0
+    return {'value': round(bs * n / dt, 3), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d train steps of batch %d at %dx%d (oracle/torch_ref.py, float32, oneDNN/torch-CPU stand-in for '
+                      'the TF-CPU path, which cannot run here)' % (n, bs, args.size, args.size)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        # single-process invocation asked for several GPUs: the contract launches us through torch.distributed.run
+        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+
+    from segmentation_amd import _build
+    _build.build(verbose=False)
+    from segmentation_amd.datasets import SyntheticDataSet
+    from segmentation_amd.unet import UNetModel
+
+    ds = SyntheticDataSet(args.batch, args.size, args.classes, seed=5555 + rank, n_batches=2)
+    model = UNetModel(sess=None, dataset=ds, n_classes=args.classes, input_dims=args.size, learning_rate=1e-4,
+                      log_dir=None, save_dir=None, load_snapshot=False, n_kernels=32,
+                      dtype=args.dtype, use_graph=not args.no_graph, crop_aware=not args.dense, seed=5555)
+    if world > 1:
+        model.pg.broadcast_(model.store.p)          # identical replicas (same seed anyway)
+        model._repack()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.train_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.train_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = model.last_loss()
+
+    out = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        flops_step = model.fwd_plan.flops + model.bwd_plan.flops
+        out = {
+            'metric': 'train-step images/sec', 'value': round(world * args.batch * args.steps / dt, 2), 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'U-Net %dx%dx3 %d-class batch=%d/GPU %s train step (fwd+xent+bwd+Adam+repack), n_kernels=32'
+                                   % (args.size, args.size, args.classes, args.batch, args.dtype),
+                       'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
+                       'conv1_2': 'dense' if args.dense else 'crop-aware (only the 72x72 window that survives the skip crop)',
+                       'hip_graph': not args.no_graph,
+                       'executed_gflop_per_step_per_gpu': round(flops_step / 1e9, 2),
+                       'step_tflops_per_gpu': round(flops_step / (ms * 1e-3) / 1e12, 2),
+                       'final_loss': round(loss, 5)},
+        }
+    # roofline / per-kernel table: eager, instrumented, after the timed region (rank 0 only does the reporting)
+    if not args.no_roofline and world == 1:
+        agg, ops = kernel_table(model)
+        fam = {}
+        for k, a in agg.items():
+            f = k.split('<')[0]
+            fa = fam.setdefault(f, {'ms': 0.0, 'flops': 0, 'launches': 0})
+            fa['ms'] += a['ms']; fa['flops'] += a['flops']; fa['launches'] += a['launches']
+        # dominant kernel = the template instance with the largest total time
+        dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
+        name, a = dom
+        avg_ms = a['ms'] / a['launches']
+        ach = a['flops'] / a['launches'] / (avg_ms * 1e-3) / 1e12 if a['flops'] else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(name, {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        total_ms = sum(v['ms'] for v in agg.values())
+        out['roofline'] = {
+            'bound': 'mfma', 'achieved': round(ach, 2), 'peak': BF16_DENSE_PEAK_TFLOPS if args.dtype == 'bf16' else 157.3,
+            'unit': 'TFLOP/s', 'frac': round(ach / (BF16_DENSE_PEAK_TFLOPS if args.dtype == 'bf16' else 157.3), 4),
+            'traffic': traffic, 'kernel': name, 'avg_launch_us': round(avg_ms * 1e3, 2), 'launches_per_step': a['launches'] // 5,
+            'share_of_step_kernel_time': round(a['ms'] / total_ms, 3),
+            'families': {f: {'ms_per_step': round(v['ms'] / 5, 4), 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1) if v['flops'] else None}
+                         for f, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])},
+        }
+        if args.per_op:
+            for op, kern, ms_, fl in ops:
+                sys.stderr.write('%-16s %-52s %9.2f us %8.1f TF/s\n' % (op, kern, ms_ * 1e3, fl / (ms_ * 1e-3) / 1e12 if fl else 0))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -66,6 +66,10 @@ typedef struct seg_conv_desc {
 /* slim.convolution2d / conv2d_transpose fwd, Conv2DBackpropInput: models/unet.py:111-166,
  * models/fcn.py:110-128,192,195 (forward); TF autodiff of the same sites (dgrad). */
 int seg_conv2d(const seg_conv_desc* d, void* stream);
+/* Reports (without launching) the kernel template instance seg_conv2d would run for d, e.g.
+ * "conv_fwd_kernel<bf16,8,16,64,4,1,3,3,1>" -- used by bench.py to key per-kernel roofline numbers
+ * to the names rocprofv3 prints. */
+int seg_conv2d_kernel_name(const seg_conv_desc* d, char* buf, int32_t cap);
 
 /* Filter gradient (Conv2DBackpropFilter) for the same sites.
  * dw[tap][k][n] (+)= sum_pixels src[b, y*s+u-pad_t, x*s+v-pad_l, k] * dz[b,y,x,n], f32, atomically
@@ -85,6 +89,7 @@ typedef struct seg_wgrad_desc {
   int32_t cfg;
 } seg_wgrad_desc;
 int seg_conv2d_wgrad(const seg_wgrad_desc* d, void* stream);
+int seg_conv2d_wgrad_kernel_name(const seg_wgrad_desc* d, char* buf, int32_t cap);
 
 /* First layer (Cin = input_channel <= 4, never padded to 32): models/unet.py:111-116 conv1_1,
  * models/fcn.py:110-115 conv1.  x is float32 NHWC [B,H,W,cin] dense. */

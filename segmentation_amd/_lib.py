@@ -51,6 +51,8 @@ PV = C.POINTER(View)
 SIGNATURES = {
     'seg_conv2d': [C.POINTER(ConvDesc), vp],
     'seg_conv2d_wgrad': [C.POINTER(WgradDesc), vp],
+    'seg_conv2d_kernel_name': [C.POINTER(ConvDesc), C.c_char_p, i32],
+    'seg_conv2d_wgrad_kernel_name': [C.POINTER(WgradDesc), C.c_char_p, i32],
     'seg_conv_first_fwd': [vp, i32, i32, i32, i32, vp, vp, i32, i32, PV, i32, i32, i32, i32, vp],
     'seg_conv_first_wgrad': [vp, i32, i32, i32, i32, PV, i32, i32, i32, i32, vp, i32, vp],
     'seg_maxpool2x2_fwd': [PV, PV, vp, i32, i32, i32, i32, i32, vp],

@@ -204,9 +204,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
   }
 }
 
+thread_local char* g_name_out = nullptr;   // when set, launches are dry: only the kernel name is reported
+thread_local int g_name_cap = 0;
+
 template <typename T, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S>
 int launch_cfg(const ConvK& P0, hipStream_t st) {
   using TT = Tr<T>;
+  if (g_name_out) {
+    snprintf(g_name_out, g_name_cap, "conv_fwd_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, WM, WN, KH, KW, S);
+    return SEG_OK;
+  }
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
   constexpr int PATCH_BYTES = ((PH * PW * TT::RSTR + 15) / 16) * 16;
   constexpr int LDS = PATCH_BYTES + KH * KW * BN * TT::RSTR;
@@ -260,6 +267,16 @@ int launch_t(const ConvK& P, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int seg_conv2d(const seg_conv_desc* dp, void* stream);
+extern "C" int seg_conv2d_kernel_name(const seg_conv_desc* dp, char* buf, int32_t cap) {
+  if (!buf || cap <= 0) { seg_set_error("kernel_name: bad buffer"); return SEG_ERR_ARG; }
+  buf[0] = 0;
+  g_name_out = buf; g_name_cap = cap;
+  const int rc = seg_conv2d(dp, nullptr);
+  g_name_out = nullptr;
+  return rc;
+}
 
 extern "C" int seg_conv2d(const seg_conv_desc* dp, void* stream) {
   if (!dp) { seg_set_error("conv: null descriptor"); return SEG_ERR_ARG; }

@@ -199,9 +199,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   }
 }
 
+thread_local char* g_wname_out = nullptr;
+thread_local int g_wname_cap = 0;
+
 template <typename T, int TH, int TW, int KH, int KW, int S, int WCI, int WCO, int FCI, int FCO>
 int launch_cfg(const WgK& P0, hipStream_t st) {
   constexpr int BN = 16 * FCO * WCO, ES = sizeof(T);
+  if (g_wname_out) {
+    snprintf(g_wname_out, g_wname_cap, "conv_wgrad_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,%d>", ES == 2 ? "bf16" : "f32", TH, TW, KH, KW, S, WCI, WCO, FCI, FCO);
+    return SEG_OK;
+  }
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
   constexpr int PATCH_BYTES = ((PH * PW * (32 * ES + 16) + 15) / 16) * 16;
   constexpr int LDS = PATCH_BYTES + TH * TW * (BN * ES + 16);
@@ -261,6 +268,16 @@ int launch_t(const WgK& P, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int seg_conv2d_wgrad(const seg_wgrad_desc* dp, void* stream);
+extern "C" int seg_conv2d_wgrad_kernel_name(const seg_wgrad_desc* dp, char* buf, int32_t cap) {
+  if (!buf || cap <= 0) { seg_set_error("kernel_name: bad buffer"); return SEG_ERR_ARG; }
+  buf[0] = 0;
+  g_wname_out = buf; g_wname_cap = cap;
+  const int rc = seg_conv2d_wgrad(dp, nullptr);
+  g_wname_out = nullptr;
+  return rc;
+}
 
 extern "C" int seg_conv2d_wgrad(const seg_wgrad_desc* dp, void* stream) {
   if (!dp) { seg_set_error("wgrad: null descriptor"); return SEG_ERR_ARG; }

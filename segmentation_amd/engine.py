@@ -156,10 +156,12 @@ class Plan(object):
         self.name = name
         self.ops = []
         self.keep = []          # ctypes objects that must outlive the plan
+        self.meta = []          # per-op {'flops':, 'bytes':, 'desc':} for the roofline report
         self.flops = 0
 
-    def add(self, name, fn, *args):
+    def add(self, name, fn, *args, **meta):
         self.ops.append((name, fn, args))
+        self.meta.append(meta)
 
     def run(self, stream):
         sp = C.c_void_p(stream)
@@ -170,6 +172,36 @@ class Plan(object):
 
     def __len__(self):
         return len(self.ops)
+
+    def extend(self, other):
+        self.ops += other.ops; self.meta += other.meta; self.keep += other.keep; self.flops += other.flops
+
+    def kernel_name(self, i):
+        """Name of the kernel instance op i launches (as rocprofv3 prints it, without the namespace)."""
+        name, fn, args = self.ops[i]
+        lib = L.load()
+        d = self.meta[i].get('desc')
+        if d is not None:
+            buf = C.create_string_buffer(160)
+            q = lib.seg_conv2d_kernel_name if isinstance(d, L.ConvDesc) else lib.seg_conv2d_wgrad_kernel_name
+            L.check(q(C.byref(d), buf, 160), 'kernel_name')
+            return buf.value.decode()
+        return self.meta[i].get('kernel', fn.__name__)
+
+    def run_profiled(self, stream, torch_mod):
+        """Eager run with a HIP event between consecutive launches on `stream` (the stream the kernels
+        are launched on).  Returns [(op name, kernel name, ms, flops)]."""
+        sp = C.c_void_p(stream)
+        evs = [torch_mod.cuda.Event(enable_timing=True) for _ in range(len(self.ops) + 1)]
+        evs[0].record()
+        for i, (name, fn, args) in enumerate(self.ops):
+            rc = fn(*args, sp)
+            if rc != 0:
+                L.check(rc, '%s/%s' % (self.name, name))
+            evs[i + 1].record()
+        torch_mod.cuda.synchronize()
+        return [(self.ops[i][0], self.kernel_name(i), evs[i].elapsed_time(evs[i + 1]), self.meta[i].get('flops', 0))
+                for i in range(len(self.ops))]
 
 
 class Net(object):
@@ -195,7 +227,7 @@ class Net(object):
         plan.keep.append(dv)
         plan.add(layer.name, self.lib.seg_conv_first_fwd, x_f32.data_ptr(), self.B, H, W, layer.cin,
                  self.store.p_ptr(layer.w_off), self.store.p_ptr(layer.b_off), layer.cout, layer.pad, C.byref(dv), Ho, Wo,
-                 1 if layer.relu else 0, self.dtype)
+                 1 if layer.relu else 0, self.dtype, kernel='conv_first_fwd_kernel', flops=2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout)
         plan.flops += 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
 
     def conv_fwd(self, plan, layer, srcs, Hi, Wi, dst, dst_off=(0, 0), out_f32=False, cfg=0):
@@ -217,8 +249,9 @@ class Net(object):
         d.out_f32 = 1 if out_f32 else 0
         d.dtype = self.dtype; d.cfg = cfg
         plan.keep.append(d)
-        plan.add(layer.name, self.lib.seg_conv2d, C.byref(d))
-        plan.flops += 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
+        fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
+        plan.add(layer.name, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl)
+        plan.flops += fl
         return Ho, Wo
 
     def up_fwd(self, plan, layer, src, Hi, Wi, dst, cfg=0):
@@ -233,26 +266,28 @@ class Net(object):
         d.dst = dst.view(); d.up2 = 1; d.up_cout = layer.cout_p; d.mask = L.null_view()
         d.relu = 1 if layer.relu else 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
         plan.keep.append(d)
-        plan.add(layer.name, self.lib.seg_conv2d, C.byref(d))
-        plan.flops += 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
+        fl = 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
+        plan.add(layer.name, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl)
+        plan.flops += fl
 
     def pool_fwd(self, plan, src, dst, Ho, Wo):
         sv, dv = src.view(), dst.view()
         plan.keep += [sv, dv]
-        plan.add('pool', self.lib.seg_maxpool2x2_fwd, C.byref(sv), C.byref(dv), None, self.B, Ho, Wo, src.Cp, self.dtype)
+        plan.add('pool', self.lib.seg_maxpool2x2_fwd, C.byref(sv), C.byref(dv), None, self.B, Ho, Wo, src.Cp, self.dtype, kernel='maxpool_fwd_kernel')
 
     # ---------------- backward ----------------
     def bias_grad(self, plan, layer, dz, H, W, dz_off=(0, 0)):
         zv = dz.view(dz_off[0], dz_off[1])
         plan.keep.append(zv)
-        plan.add(layer.name + '/db', self.lib.seg_bias_grad, C.byref(zv), self.B, H, W, layer.cout, self.store.g_ptr(layer.b_off), self.dtype)
+        plan.add(layer.name + '/db', self.lib.seg_bias_grad, C.byref(zv), self.B, H, W, layer.cout, self.store.g_ptr(layer.b_off), self.dtype, kernel='bias_grad_kernel')
 
     def first_bwd(self, plan, layer, x_f32, H, W, dz):
         Ho, Wo = H + 2 * layer.pad - 2, W + 2 * layer.pad - 2
         zv = dz.view()
         plan.keep.append(zv)
         plan.add(layer.name + '/dw', self.lib.seg_conv_first_wgrad, x_f32.data_ptr(), self.B, H, W, layer.cin, C.byref(zv), Ho, Wo,
-                 layer.cout, layer.pad, self.store.g_ptr(layer.w_off), self.dtype)
+                 layer.cout, layer.pad, self.store.g_ptr(layer.w_off), self.dtype, kernel='conv_first_wgrad_kernel',
+                 flops=2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout)
         self.bias_grad(plan, layer, dz, Ho, Wo)
         plan.flops += 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
 
@@ -272,8 +307,9 @@ class Net(object):
         w.dz = dz.view(dz_off[0], dz_off[1]); w.n_log = layer.cout
         w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = wcfg
         plan.keep.append(w)
-        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w))
-        plan.flops += 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
+        fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
+        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl)
+        plan.flops += fl
         self.bias_grad(plan, layer, dz, Ho, Wo, dz_off)
         n_off = 0
         for i, ds in enumerate(dsrcs):
@@ -291,8 +327,9 @@ class Net(object):
                 d.mask = mask.view(moff[0], moff[1]) if mask is not None else L.null_view()
                 d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
                 plan.keep.append(d)
-                plan.add(layer.name + '/dx%d' % i, self.lib.seg_conv2d, C.byref(d))
-                plan.flops += 2 * self.B * Ho * Wo * k * k * layer.cin_segs[i] * layer.cout
+                fl = 2 * self.B * Ho * Wo * k * k * layer.cin_segs[i] * layer.cout
+                plan.add(layer.name + '/dx%d' % i, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl)
+                plan.flops += fl
             n_off += layer.cin_p[i]
 
     def up_bwd(self, plan, layer, src, Hi, Wi, dzu, dsrc, mask, cfg=0, wcfg=0):
@@ -305,9 +342,10 @@ class Net(object):
         w.dz = src.view(); w.n_log = layer.cin
         w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = wcfg
         plan.keep.append(w)
-        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w))
+        fl = 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
+        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl)
         self.bias_grad(plan, layer, dzu, 2 * Hi, 2 * Wi)
-        plan.flops += 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
+        plan.flops += fl
         if dsrc is not None:
             d = L.ConvDesc()
             d.src0 = dzu.view(); d.src1 = L.null_view()
@@ -321,8 +359,8 @@ class Net(object):
             d.mask = mask.view() if mask is not None else L.null_view()
             d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
             plan.keep.append(d)
-            plan.add(layer.name + '/dx', self.lib.seg_conv2d, C.byref(d))
-            plan.flops += 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
+            plan.add(layer.name + '/dx', self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl)
+            plan.flops += fl
 
     def pool_bwd(self, plan, y_act, dpool, add, add_hw, add_off, dz, H, W):
         yv, zv = y_act.view(), dz.view()
@@ -330,7 +368,7 @@ class Net(object):
         av = add.view() if add is not None else L.null_view()
         plan.keep += [yv, zv, pv, av]
         plan.add('pool/bwd', self.lib.seg_maxpool2x2_bwd, C.byref(yv), C.byref(pv), C.byref(av), add_hw[0], add_hw[1],
-                 add_off[0], add_off[1], C.byref(zv), self.B, H, W, y_act.Cp, self.dtype)
+                 add_off[0], add_off[1], C.byref(zv), self.B, H, W, y_act.Cp, self.dtype, kernel='maxpool_bwd_kernel')
 
     # ---------------- loss / outputs / update ----------------
     def softmax_xent(self, plan, logits, labels_u8, LH, LW, loff, H, W, n_classes, loss_buf, dlogits):
@@ -338,22 +376,22 @@ class Net(object):
         plan.keep += [lv, dv]
         inv_n = 1.0 / float(self.B * H * W)
         plan.add('xent', self.lib.seg_softmax_xent, C.byref(lv), labels_u8.data_ptr(), LH, LW, loff[0], loff[1], self.B, H, W,
-                 n_classes, inv_n, 1.0, loss_buf.data_ptr(), C.byref(dv), self.dtype)
+                 n_classes, inv_n, 1.0, loss_buf.data_ptr(), C.byref(dv), self.dtype, kernel='softmax_xent_kernel')
 
     def sigmoid_argmax(self, plan, logits, H, W, n_classes, sig, out):
         lv = logits.view()
         plan.keep.append(lv)
-        plan.add('sigmoid_argmax', self.lib.seg_sigmoid_argmax, C.byref(lv), self.B, H, W, n_classes, sig.data_ptr(), out.data_ptr())
+        plan.add('sigmoid_argmax', self.lib.seg_sigmoid_argmax, C.byref(lv), self.B, H, W, n_classes, sig.data_ptr(), out.data_ptr(), kernel='sigmoid_argmax_kernel')
 
     def pack(self, plan):
         s = self.store
         if s.pack_table is None:
             return
         plan.add('pack', self.lib.seg_pack_weights, s.p.data_ptr(), s.packed.data_ptr(), s.pack_table.data_ptr(),
-                 s.n_pack_entries, s.pack_blocks, self.dtype)
+                 s.n_pack_entries, s.pack_blocks, self.dtype, kernel='pack_kernel')
 
     def adam(self, plan, lr, grad_scale=1.0, b1=0.9, b2=0.999, eps=1e-8):
         s = self.store
         plan.add('adam', self.lib.seg_adam, s.p.data_ptr(), s.g.data_ptr(), s.m.data_ptr(), s.v.data_ptr(), s.n, lr, b1, b2, eps,
-                 grad_scale, s.step.data_ptr())
-        plan.add('step++', self.lib.seg_step_increment, s.step.data_ptr())
+                 grad_scale, s.step.data_ptr(), kernel='adam_kernel')
+        plan.add('step++', self.lib.seg_step_increment, s.step.data_ptr(), kernel='step_inc_kernel')

@@ -276,9 +276,7 @@ class UNetModel(BaseModel):
         assert lo == self.store.n
         self.bwd_plan = E.Plan('bwd')
         for plan, _ in self.bwd_segments:
-            self.bwd_plan.ops += plan.ops
-            self.bwd_plan.keep += plan.keep
-            self.bwd_plan.flops += plan.flops
+            self.bwd_plan.extend(plan)
         upd = self.upd_plan = E.Plan('update')
         net.adam(upd, self.learning_rate, grad_scale=1.0 / self.pg.world)
         net.pack(upd)
