@@ -71,11 +71,14 @@ int seg_conv2d(const seg_conv_desc* d, void* stream);
  * to the names rocprofv3 prints. */
 int seg_conv2d_kernel_name(const seg_conv_desc* d, char* buf, int32_t cap);
 
-/* Filter gradient (Conv2DBackpropFilter) for the same sites.
- * dw[tap][k][n] (+)= sum_pixels src[b, y*s+u-pad_t, x*s+v-pad_l, k] * dz[b,y,x,n], f32, atomically
- * accumulated into `dw` which the caller zeroes once per step.  dw layout [KH*KW][k_logical][n_logical]
- * (= TF HWIO for conv; = TF [kh,kw,Cout,Cin] for the transposed conv when src:=dz_big, dz:=x_small).
- * k_logical maps padded concat channels back to logical ones via (src0_clog, src1_clog). */
+/* Filter gradient (Conv2DBackpropFilter) + bias gradient (BiasAddGrad) for the same sites.
+ * dw[tap][k][n] = sum_pixels src[b, y*s+u-pad_t, x*s+v-pad_l, k] * dz[b,y,x,n]   (f32, overwritten).
+ * dw layout [KH*KW][k_logical][n_logical] (= TF HWIO for conv; = TF [kh,kw,Cout,Cin] for the transposed
+ * conv when src:=dz_big, dz:=x_small); k_logical maps padded concat channels back to logical ones via
+ * (src0_clog, src1_clog).  Two launches: workgroups write per-split partial slabs into `ws` with plain
+ * stores, then a reduce kernel sums the ksplit slabs in a fixed order (deterministic, no atomics).
+ * bias_mode 1: db[n] = sum_pixels dz[...,n] (conv); 2: db[k] = sum over pixels and taps of src (transposed conv).
+ * Call seg_conv2d_wgrad_plan first to learn ksplit and the workspace size the launch needs. */
 typedef struct seg_wgrad_desc {
   seg_view src0, src1;
   int32_t src0_clog, src1_clog;   /* logical (unpadded) channels of each source */
@@ -87,8 +90,15 @@ typedef struct seg_wgrad_desc {
   float* dw;
   int32_t dtype;
   int32_t cfg;
+  float* ws;                      /* partial-slab workspace                 */
+  int64_t ws_bytes;
+  int32_t ksplit;                 /* 0 = auto                               */
+  int32_t bias_mode;              /* 0 none, 1 sum dz, 2 sum src            */
+  float* db;
+  int32_t bias_n;
 } seg_wgrad_desc;
 int seg_conv2d_wgrad(const seg_wgrad_desc* d, void* stream);
+int seg_conv2d_wgrad_plan(const seg_wgrad_desc* d, int32_t* ksplit, int64_t* ws_bytes);
 int seg_conv2d_wgrad_kernel_name(const seg_wgrad_desc* d, char* buf, int32_t cap);
 
 /* First layer (Cin = input_channel <= 4, never padded to 32): models/unet.py:111-116 conv1_1,

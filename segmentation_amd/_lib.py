@@ -34,7 +34,9 @@ class WgradDesc(C.Structure):
     _fields_ = [('src0', View), ('src1', View), ('src0_clog', C.c_int32), ('src1_clog', C.c_int32),
                 ('B', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32),
                 ('stride', C.c_int32), ('pad_t', C.c_int32), ('pad_l', C.c_int32), ('Ho', C.c_int32), ('Wo', C.c_int32),
-                ('dz', View), ('n_log', C.c_int32), ('dw', C.c_void_p), ('dtype', C.c_int32), ('cfg', C.c_int32)]
+                ('dz', View), ('n_log', C.c_int32), ('dw', C.c_void_p), ('dtype', C.c_int32), ('cfg', C.c_int32),
+                ('ws', C.c_void_p), ('ws_bytes', C.c_int64), ('ksplit', C.c_int32), ('bias_mode', C.c_int32),
+                ('db', C.c_void_p), ('bias_n', C.c_int32)]
 
 
 class PackEntry(C.Structure):
@@ -53,6 +55,7 @@ SIGNATURES = {
     'seg_conv2d_wgrad': [C.POINTER(WgradDesc), vp],
     'seg_conv2d_kernel_name': [C.POINTER(ConvDesc), C.c_char_p, i32],
     'seg_conv2d_wgrad_kernel_name': [C.POINTER(WgradDesc), C.c_char_p, i32],
+    'seg_conv2d_wgrad_plan': [C.POINTER(WgradDesc), C.POINTER(i32), C.POINTER(i64)],
     'seg_conv_first_fwd': [vp, i32, i32, i32, i32, vp, vp, i32, i32, PV, i32, i32, i32, i32, vp],
     'seg_conv_first_wgrad': [vp, i32, i32, i32, i32, PV, i32, i32, i32, i32, vp, i32, vp],
     'seg_maxpool2x2_fwd': [PV, PV, vp, i32, i32, i32, i32, i32, vp],
@@ -81,6 +84,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise SegError('libseg_hip.so not found at %s: run `python -c "import __graft_entry__ as g; g.build()"` '
                        '(the HIP extension is mandatory; there is no CPU fallback)' % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Load
+    # torch's copy first so that libseg_hip.so binds to the runtime that owns torch's device context and streams.
+    import torch
+    rt = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+    if os.path.exists(rt):
+        C.CDLL(rt, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing

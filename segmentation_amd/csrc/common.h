@@ -13,6 +13,8 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define SEG_DEV __device__ __forceinline__
+// hipGetLastError() is sticky across unrelated runtime calls: clear it before every launch we check.
+#define SEG_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 void seg_set_error(const char* fmt, ...);
 int seg_check_launch(const char* what);

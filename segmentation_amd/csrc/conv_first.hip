@@ -127,8 +127,8 @@ extern "C" int seg_conv_first_fwd(const float* x, int32_t B, int32_t H, int32_t 
   const int tiles_x = cdiv(Wo, FT), tiles_y = cdiv(Ho, FT);
   dim3 grid(B * tiles_x * tiles_y, cp / 32);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SEG_F32) hipLaunchKernelGGL(conv_first_fwd_kernel<float>, grid, dim3(256), 0, st, x, B, H, W, cin, w_hwio, bias, cout, pad, *dst, Ho, Wo, relu, tiles_x, tiles_y);
-  else if (dtype == SEG_BF16) hipLaunchKernelGGL(conv_first_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, x, B, H, W, cin, w_hwio, bias, cout, pad, *dst, Ho, Wo, relu, tiles_x, tiles_y);
+  if (dtype == SEG_F32) SEG_LAUNCH(conv_first_fwd_kernel<float>, grid, dim3(256), 0, st, x, B, H, W, cin, w_hwio, bias, cout, pad, *dst, Ho, Wo, relu, tiles_x, tiles_y);
+  else if (dtype == SEG_BF16) SEG_LAUNCH(conv_first_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, x, B, H, W, cin, w_hwio, bias, cout, pad, *dst, Ho, Wo, relu, tiles_x, tiles_y);
   else { seg_set_error("conv_first_fwd: bad dtype"); return SEG_ERR_ARG; }
   return seg_check_launch("conv_first_fwd");
 }
@@ -141,8 +141,8 @@ extern "C" int seg_conv_first_wgrad(const float* x, int32_t B, int32_t H, int32_
   const int tiles_x = cdiv(Wo, FT), tiles_y = cdiv(Ho, FT), ntiles = B * tiles_x * tiles_y;
   dim3 grid(ntiles < 1024 ? ntiles : 1024, cp / 32);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SEG_F32) hipLaunchKernelGGL(conv_first_wgrad_kernel<float>, grid, dim3(256), 0, st, x, B, H, W, cin, *dz, Ho, Wo, cout, pad, dw_hwio, tiles_x, tiles_y, ntiles);
-  else if (dtype == SEG_BF16) hipLaunchKernelGGL(conv_first_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, x, B, H, W, cin, *dz, Ho, Wo, cout, pad, dw_hwio, tiles_x, tiles_y, ntiles);
+  if (dtype == SEG_F32) SEG_LAUNCH(conv_first_wgrad_kernel<float>, grid, dim3(256), 0, st, x, B, H, W, cin, *dz, Ho, Wo, cout, pad, dw_hwio, tiles_x, tiles_y, ntiles);
+  else if (dtype == SEG_BF16) SEG_LAUNCH(conv_first_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, x, B, H, W, cin, *dz, Ho, Wo, cout, pad, dw_hwio, tiles_x, tiles_y, ntiles);
   else { seg_set_error("conv_first_wgrad: bad dtype"); return SEG_ERR_ARG; }
   return seg_check_launch("conv_first_wgrad");
 }

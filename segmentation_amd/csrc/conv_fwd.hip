@@ -230,7 +230,7 @@ int launch_cfg(const ConvK& P0, hipStream_t st) {
     attr_done = true;
   }
   dim3 grid(P.d.B * P.tiles_y * P.tiles_x, P.d.n_count / BN);
-  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, P);
+  SEG_LAUNCH(kern, grid, dim3(256), LDS, st, P);
   return seg_check_launch("conv_fwd");
 }
 

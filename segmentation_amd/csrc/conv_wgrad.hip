@@ -7,7 +7,10 @@
 // bf16 path reads its fragments with ds_read_b64_tr_b16 (4 pixels x 16 channels, delivered
 // column-major); the f32 path reads single elements.  A workgroup owns one 32-channel chunk of X and
 // BN channels of dZ for ALL taps, keeps the KH*KW*32*BN partial sums in registers while it walks its
-// share of the pixel tiles, and flushes once with f32 atomics (caller zeroes dW once per step).
+// share of the pixel tiles, and flushes them ONCE, with plain coalesced stores, into its own slab of a
+// workspace; a second small kernel sums the `ksplit` slabs in a fixed order into the TF-layout gradient
+// (deterministic, no atomics: 768 workgroups hammering one 36 KB filter with f32 atomics measured 10-30x
+// slower than the MFMA work).  The bias gradient rides along as one extra MFMA against an all-ones fragment.
 #include "common.h"
 
 namespace {
@@ -16,7 +19,19 @@ struct WgK {
   seg_wgrad_desc d;
   int tiles_x, tiles_y, ntiles, ksplit;
   int nchunks0, nchunks, nblk;   // K chunks of src0 / total; BN blocks
+  int k_pad, n_pad;              // slab = [taps][k_pad][n_pad] floats followed by bias[max(k_pad,n_pad)]
+  int64_t slab;                  // floats per split
 };
+
+template <typename T> SEG_DEV Frag<T> ones_frag();
+template <> SEG_DEV Frag<bf16_t> ones_frag<bf16_t>() {
+  Frag<bf16_t> f;
+  for (int i = 0; i < 8; ++i) f.v[i] = (bf16_t)1.0f;
+  return f;
+}
+template <> SEG_DEV Frag<float> ones_frag<float>() {
+  Frag<float> f; f.lo = f32x4{1, 1, 1, 1}; f.hi = f32x4{1, 1, 1, 1}; return f;
+}
 
 template <typename T> struct TrRead;
 template <> struct TrRead<bf16_t> {
@@ -73,6 +88,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
     for (int a = 0; a < FCI; ++a)
 #pragma unroll
       for (int c = 0; c < FCO; ++c) acc[t][a][c] = f32x4{0, 0, 0, 0};
+
+  // bias gradient: mode 1 = column sums of dz (conv; only chunk-0 workgroups), mode 2 = sums of src over
+  // pixels and taps (transposed conv, where src is the big dZ map; only nb-0 workgroups)
+  const bool bias1 = d.bias_mode == 1 && chunk == 0 && wci == 0;
+  const bool bias2 = d.bias_mode == 2 && nb == 0 && wco == 0;
+  f32x4 accb1[FCO], accb2[FCI];
+#pragma unroll
+  for (int c = 0; c < FCO; ++c) accb1[c] = f32x4{0, 0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < FCI; ++a) accb2[a] = f32x4{0, 0, 0, 0};
+  const Frag<T> ones = ones_frag<T>();
 
   u32x4 rp[NPP], rz[NZP];
   auto prefetch = [&](int tile) {
@@ -165,6 +191,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
       Frag<T> fz[FCO];
 #pragma unroll
       for (int c = 0; c < FCO; ++c) fz[c] = read_frag(sZ, za, ks * 32 * RSZ + z_ch + c * 16 * ES);
+      if (bias1) {
+#pragma unroll
+        for (int c = 0; c < FCO; ++c) mma32(accb1[c], ones, fz[c]);
+      }
 #pragma unroll
       for (int u = 0; u < KH; ++u)
 #pragma unroll
@@ -174,33 +204,105 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
             Frag<T> fx = read_frag(sP, pa[ks], (u * PW + v) * RSP + a_ch + a * 16 * ES);
 #pragma unroll
             for (int c = 0; c < FCO; ++c) mma32(acc[u * KW + v][a][c], fx, fz[c]);
+            if (bias2) mma32(accb2[a], fx, ones);
           }
     }
   }
 
-  // ---- flush: D[row = ci][col = co]; lane: co = lr, ci = 4G + r ----
-  const int k_log_n = d.src0_clog + d.src1_clog;
+  // ---- flush into this split's slab: D[row = ci][col = co]; lane: co = lr, ci = 4G + r ----
+  float* slab = d.ws + (int64_t)blockIdx.y * P.slab;
+  const int kbase = chunk * 32;                                    // padded concat channel base
 #pragma unroll
-  for (int a = 0; a < FCI; ++a) {
+  for (int a = 0; a < FCI; ++a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int cil = cbase + (wci * FCI + a) * 16 + 4 * G + r;     // padded channel inside its source
-      const int clog = first ? d.src0_clog : d.src1_clog;
-      if (cil >= clog) continue;
-      const int k = first ? cil : d.src0_clog + cil;
+      const int k = kbase + (wci * FCI + a) * 16 + 4 * G + r;
 #pragma unroll
       for (int c = 0; c < FCO; ++c) {
         const int co = n0 + (wco * FCO + c) * 16 + lr;
-        if (co >= d.n_log) continue;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) atomicAdd(d.dw + ((int64_t)t * k_log_n + k) * d.n_log + co, acc[t][a][c][r]);
+        for (int t = 0; t < NT; ++t) slab[((int64_t)t * P.k_pad + k) * P.n_pad + co] = acc[t][a][c][r];
+      }
+    }
+  float* bslab = slab + (int64_t)NT * P.k_pad * P.n_pad;
+  if (bias1 && G == 0) {
+#pragma unroll
+    for (int c = 0; c < FCO; ++c) bslab[n0 + (wco * FCO + c) * 16 + lr] = accb1[c][0];      // row 0 of D
+  }
+  if (bias2 && lr == 0) {
+#pragma unroll
+    for (int a = 0; a < FCI; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bslab[kbase + (wci * FCI + a) * 16 + 4 * G + r] = accb2[a][r];   // column 0 of D
+  }
+}
+
+// Sums the ksplit slabs (fixed order => bitwise reproducible) and scatters to the logical TF layout.
+// SP = 1: one thread per output (few splits).  SP = 16: a 256-thread block owns 16 consecutive outputs,
+// thread (jj = t/16, oo = t%16) sums splits s = jj, jj+16, ... (4 independent chains), then the 16 partial
+// sums meet in LDS and are added in jj order.
+SEG_DEV void reduce_addr(int64_t i, int64_t nw, int taps, int k_pad, int n_pad, int seg0_c, int seg0_cp, int k_log, int n_log,
+                         float* dw, float* db, int64_t& src, float*& dst) {
+  if (i < nw) {
+    const int n = i % n_log; int64_t t = i / n_log;
+    const int k = t % k_log; const int tap = t / k_log;
+    const int kp = k < seg0_c ? k : seg0_cp + (k - seg0_c);
+    src = ((int64_t)tap * k_pad + kp) * n_pad + n;
+    dst = dw + i;
+  } else {
+    src = (int64_t)taps * k_pad * n_pad + (i - nw);
+    dst = db + (i - nw);
+  }
+}
+
+template <int SP>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int ksplit, int64_t slab, int taps, int k_pad, int n_pad,
+                                                           int seg0_c, int seg0_cp, int seg1_c, int n_log, float* dw, int bias_mode,
+                                                           int bias_n, float* db) {
+  const int k_log = seg0_c + seg1_c;
+  const int64_t nw = (int64_t)taps * k_log * n_log;
+  const int64_t total = nw + (bias_mode ? bias_n : 0);
+  if (SP == 1) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      int64_t src; float* dst;
+      reduce_addr(i, nw, taps, k_pad, n_pad, seg0_c, seg0_cp, k_log, n_log, dw, db, src, dst);
+      float a = 0.f;
+      for (int s = 0; s < ksplit; ++s) a += ws[(int64_t)s * slab + src];
+      *dst = a;
+    }
+  } else {
+    __shared__ float red[16][17];
+    const int oo = threadIdx.x & 15, jj = threadIdx.x >> 4;
+    for (int64_t i0 = (int64_t)blockIdx.x * 16; i0 < total; i0 += (int64_t)gridDim.x * 16) {
+      const int64_t i = i0 + oo;
+      int64_t src = 0; float* dst = nullptr;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      if (i < total) {
+        reduce_addr(i, nw, taps, k_pad, n_pad, seg0_c, seg0_cp, k_log, n_log, dw, db, src, dst);
+        int s = jj;
+        for (; s + 48 < ksplit; s += 64) {
+          a0 += ws[(int64_t)s * slab + src]; a1 += ws[(int64_t)(s + 16) * slab + src];
+          a2 += ws[(int64_t)(s + 32) * slab + src]; a3 += ws[(int64_t)(s + 48) * slab + src];
+        }
+        for (; s < ksplit; s += 16) a0 += ws[(int64_t)s * slab + src];
+      }
+      __syncthreads();
+      red[jj][oo] = (a0 + a1) + (a2 + a3);
+      __syncthreads();
+      if (jj == 0 && i < total) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += red[q][oo];
+        *dst = a;
       }
     }
   }
 }
 
-thread_local char* g_wname_out = nullptr;
+thread_local char* g_wname_out = nullptr;      // name-query mode: report the kernel instance, launch nothing
 thread_local int g_wname_cap = 0;
+thread_local int32_t* g_plan_ks = nullptr;     // planning mode: report ksplit / workspace bytes, launch nothing
+thread_local int64_t* g_plan_bytes = nullptr;
 
 template <typename T, int TH, int TW, int KH, int KW, int S, int WCI, int WCO, int FCI, int FCO>
 int launch_cfg(const WgK& P0, hipStream_t st) {
@@ -218,13 +320,17 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
   P.nblk = cdiv(P.d.dz.c, BN);
   if (P.d.dz.c % BN) { seg_set_error("wgrad: dz channels %d not a multiple of BN %d", P.d.dz.c, BN); return SEG_ERR_ARG; }
   const int base = P.nchunks * P.nblk;
-  int ks = cdiv(768, base);                // aim at ~3 workgroups per CU ...
+  // K split: enough workgroups to fill the chip once (every split costs one slab write + read of this
+  // workgroup tile: ~9*32*BN*4 bytes), never more splits than pixel tiles.
+  int ks = P.d.ksplit > 0 ? P.d.ksplit : cdiv(256, base);
   if (ks > P.ntiles) ks = P.ntiles;
-  // ... but every K split adds one full pass of f32 atomics over dW (~1.3 TB/s chip-wide)
-  const int64_t wbytes = (int64_t)KH * KW * P.nchunks * 32 * P.d.dz.c * 4;
-  while (ks > 1 && ks * wbytes > (48ll << 20)) --ks;
   if (ks < 1) ks = 1;
   P.ksplit = ks;
+  P.k_pad = P.nchunks * 32; P.n_pad = P.d.dz.c;
+  const int64_t bias_len = P.k_pad > P.n_pad ? P.k_pad : P.n_pad;
+  P.slab = (int64_t)KH * KW * P.k_pad * P.n_pad + bias_len;
+  if (g_plan_ks) { *g_plan_ks = ks; *g_plan_bytes = P.slab * ks * 4; return SEG_OK; }
+  if (!P.d.ws || P.d.ws_bytes < P.slab * ks * 4) { seg_set_error("wgrad: workspace too small (%lld < %lld bytes)", (long long)P.d.ws_bytes, (long long)(P.slab * ks * 4)); return SEG_ERR_ARG; }
   auto kern = conv_wgrad_kernel<T, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO>;
   static bool attr_done = false;
   if (!attr_done && LDS > 48 * 1024) {
@@ -233,8 +339,20 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(base, ks), dim3(256), LDS, st, P);
-  return seg_check_launch("conv_wgrad");
+  SEG_LAUNCH(kern, dim3(base, ks), dim3(256), LDS, st, P);
+  int rc = seg_check_launch("conv_wgrad");
+  if (rc) return rc;
+  const int64_t total = (int64_t)KH * KW * (P.d.src0_clog + P.d.src1_clog) * P.d.n_log + (P.d.bias_mode ? P.d.bias_n : 0);
+  if (ks <= 4) {
+    int rg = (int)((total + 255) / 256); if (rg > 4096) rg = 4096;
+    SEG_LAUNCH(wgrad_reduce_kernel<1>, dim3(rg), dim3(256), 0, st, P.d.ws, ks, P.slab, KH * KW, P.k_pad, P.n_pad, P.d.src0_clog, P.d.src0.c,
+               P.d.src1_clog, P.d.n_log, P.d.dw, P.d.bias_mode, P.d.bias_n, P.d.db);
+  } else {
+    int rg = (int)((total + 15) / 16); if (rg > 8192) rg = 8192;
+    SEG_LAUNCH(wgrad_reduce_kernel<16>, dim3(rg), dim3(256), 0, st, P.d.ws, ks, P.slab, KH * KW, P.k_pad, P.n_pad, P.d.src0_clog, P.d.src0.c,
+               P.d.src1_clog, P.d.n_log, P.d.dw, P.d.bias_mode, P.d.bias_n, P.d.db);
+  }
+  return seg_check_launch("wgrad_reduce");
 }
 
 template <typename T, int KH, int KW, int S>
@@ -279,10 +397,20 @@ extern "C" int seg_conv2d_wgrad_kernel_name(const seg_wgrad_desc* dp, char* buf,
   return rc;
 }
 
+extern "C" int seg_conv2d_wgrad_plan(const seg_wgrad_desc* dp, int32_t* ksplit, int64_t* ws_bytes) {
+  if (!ksplit || !ws_bytes) { seg_set_error("wgrad_plan: null output"); return SEG_ERR_ARG; }
+  g_plan_ks = ksplit; g_plan_bytes = ws_bytes;
+  const int rc = seg_conv2d_wgrad(dp, nullptr);
+  g_plan_ks = nullptr; g_plan_bytes = nullptr;
+  return rc;
+}
+
 extern "C" int seg_conv2d_wgrad(const seg_wgrad_desc* dp, void* stream) {
   if (!dp) { seg_set_error("wgrad: null descriptor"); return SEG_ERR_ARG; }
   const seg_wgrad_desc& d = *dp;
   if (!d.src0.ptr || !d.dz.ptr || !d.dw) { seg_set_error("wgrad: null pointer"); return SEG_ERR_ARG; }
+  if (d.bias_mode < 0 || d.bias_mode > 2 || (d.bias_mode && (!d.db || d.bias_n <= 0))) { seg_set_error("wgrad: bad bias request"); return SEG_ERR_ARG; }
+  if ((d.bias_mode == 1 && d.bias_n > d.dz.c) || (d.bias_mode == 2 && d.bias_n > d.src0.c)) { seg_set_error("wgrad: bias_n exceeds channels"); return SEG_ERR_ARG; }
   if (d.src0.c <= 0 || d.src0.c % 32 || (d.src1.ptr && (d.src1.c <= 0 || d.src1.c % 32)) || d.dz.c <= 0 || d.dz.c % 32) {
     seg_set_error("wgrad: channel counts must be positive multiples of 32"); return SEG_ERR_ARG;
   }

@@ -444,8 +444,8 @@ extern "C" int seg_maxpool2x2_fwd(const seg_view* src, const seg_view* dst, uint
   if (!view_ok(src, 2 * Ho, 2 * Wo, C) || !view_ok(dst, Ho, Wo, C) || C % 8 || B <= 0) { seg_set_error("maxpool_fwd: bad views"); return SEG_ERR_ARG; }
   const int64_t n = (int64_t)B * Ho * Wo * (C / 8);
   DISPATCH(dtype,
-           hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *src, *dst, idx, B, Ho, Wo, C / 8),
-           hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *src, *dst, idx, B, Ho, Wo, C / 8));
+           SEG_LAUNCH(maxpool_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *src, *dst, idx, B, Ho, Wo, C / 8),
+           SEG_LAUNCH(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *src, *dst, idx, B, Ho, Wo, C / 8));
   return seg_check_launch("maxpool_fwd");
 }
 
@@ -459,8 +459,8 @@ extern "C" int seg_maxpool2x2_bwd(const seg_view* y_act, const seg_view* dpool, 
   const seg_view adv = (add && add->ptr) ? *add : null_view();
   const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
   DISPATCH(dtype,
-           hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *y_act, dpv, adv, add_h, add_w, add_y0, add_x0, *dz, B, H, W, C / 8),
-           hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *y_act, dpv, adv, add_h, add_w, add_y0, add_x0, *dz, B, H, W, C / 8));
+           SEG_LAUNCH(maxpool_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *y_act, dpv, adv, add_h, add_w, add_y0, add_x0, *dz, B, H, W, C / 8),
+           SEG_LAUNCH(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *y_act, dpv, adv, add_h, add_w, add_y0, add_x0, *dz, B, H, W, C / 8));
   return seg_check_launch("maxpool_bwd");
 }
 
@@ -469,8 +469,8 @@ extern "C" int seg_relu_grad(const seg_view* dy, const seg_view* y_act, const se
   if (!view_ok(dy, H, W, C) || !view_ok(y_act, H, W, C) || !view_ok(dz, H, W, C) || C % 8) { seg_set_error("relu_grad: bad views"); return SEG_ERR_ARG; }
   const int64_t n = (int64_t)B * H * W * (C / 8);
   DISPATCH(dtype,
-           hipLaunchKernelGGL(relu_grad_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *dy, *y_act, *dz, B, H, W, C / 8),
-           hipLaunchKernelGGL(relu_grad_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *dy, *y_act, *dz, B, H, W, C / 8));
+           SEG_LAUNCH(relu_grad_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *dy, *y_act, *dz, B, H, W, C / 8),
+           SEG_LAUNCH(relu_grad_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *dy, *y_act, *dz, B, H, W, C / 8));
   return seg_check_launch("relu_grad");
 }
 
@@ -478,8 +478,8 @@ extern "C" int seg_cast_pad(const float* x, int64_t npix, int32_t c, const seg_v
   if (!x || !dst || !dst->ptr || dst->cs % 8 || c > dst->cs || npix <= 0) { seg_set_error("cast_pad: bad args"); return SEG_ERR_ARG; }
   const int64_t n = npix * (dst->cs / 8);
   DISPATCH(dtype,
-           hipLaunchKernelGGL(cast_pad_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, npix, c, *dst),
-           hipLaunchKernelGGL(cast_pad_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, npix, c, *dst));
+           SEG_LAUNCH(cast_pad_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, npix, c, *dst),
+           SEG_LAUNCH(cast_pad_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, npix, c, *dst));
   return seg_check_launch("cast_pad");
 }
 
@@ -488,8 +488,8 @@ extern "C" int seg_dropout(const seg_view* x, const seg_view* y, int32_t B, int3
   if (!view_ok(x, H, W, C) || !view_ok(y, H, W, C) || C % 8 || !(keep > 0.f && keep <= 1.f)) { seg_set_error("dropout: bad args"); return SEG_ERR_ARG; }
   const int64_t n = (int64_t)B * H * W * (C / 8);
   DISPATCH(dtype,
-           hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *x, *y, B, H, W, C / 8, keep, seed, offset),
-           hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *x, *y, B, H, W, C / 8, keep, seed, offset));
+           SEG_LAUNCH(dropout_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *x, *y, B, H, W, C / 8, keep, seed, offset),
+           SEG_LAUNCH(dropout_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *x, *y, B, H, W, C / 8, keep, seed, offset));
   return seg_check_launch("dropout");
 }
 
@@ -501,8 +501,8 @@ extern "C" int seg_softmax_xent(const seg_view* logits, const uint8_t* labels, i
   if (ly0 < 0 || lx0 < 0 || ly0 + H > LH || lx0 + W > LW) { seg_set_error("softmax_xent: label window out of range"); return SEG_ERR_ARG; }
   const int64_t n = (int64_t)B * H * W;
   DISPATCH(dtype,
-           hipLaunchKernelGGL(softmax_xent_kernel<float>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, ST(stream), *logits, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, grad_scale, loss_sum, *dlogits),
-           hipLaunchKernelGGL(softmax_xent_kernel<bf16_t>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, ST(stream), *logits, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, grad_scale, loss_sum, *dlogits));
+           SEG_LAUNCH(softmax_xent_kernel<float>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, ST(stream), *logits, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, grad_scale, loss_sum, *dlogits),
+           SEG_LAUNCH(softmax_xent_kernel<bf16_t>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, ST(stream), *logits, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, grad_scale, loss_sum, *dlogits));
   return seg_check_launch("softmax_xent");
 }
 
@@ -510,7 +510,7 @@ extern "C" int seg_sigmoid_argmax(const seg_view* logits, int32_t B, int32_t H, 
                                   void* stream) {
   if (!logits || !logits->ptr || !sig || !out || n_classes < 1 || n_classes > logits->cs) { seg_set_error("sigmoid_argmax: bad args"); return SEG_ERR_ARG; }
   const int64_t n = (int64_t)B * H * W;
-  hipLaunchKernelGGL(sigmoid_argmax_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), *logits, B, H, W, n_classes, sig, out);
+  SEG_LAUNCH(sigmoid_argmax_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), *logits, B, H, W, n_classes, sig, out);
   return seg_check_launch("sigmoid_argmax");
 }
 
@@ -522,8 +522,8 @@ extern "C" int seg_bias_grad(const seg_view* dz, int32_t B, int32_t H, int32_t W
   if (C8 > 256) { seg_set_error("bias_grad: more than 2048 channels"); return SEG_ERR_UNSUPPORTED; }
   const int g = grid_for(npix, npl * 16, 1024);
   DISPATCH(dtype,
-           hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(g), dim3(256), 0, ST(stream), *dz, B, H, W, C8, n_log, db),
-           hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(g), dim3(256), 0, ST(stream), *dz, B, H, W, C8, n_log, db));
+           SEG_LAUNCH(bias_grad_kernel<float>, dim3(g), dim3(256), 0, ST(stream), *dz, B, H, W, C8, n_log, db),
+           SEG_LAUNCH(bias_grad_kernel<bf16_t>, dim3(g), dim3(256), 0, ST(stream), *dz, B, H, W, C8, n_log, db));
   return seg_check_launch("bias_grad");
 }
 
@@ -531,13 +531,13 @@ extern "C" int seg_adam(float* p, const float* g, float* m, float* v, int64_t n,
                         float grad_scale, const int64_t* step_dev, void* stream) {
   if (!p || !g || !m || !v || !step_dev || n <= 0) { seg_set_error("adam: bad args"); return SEG_ERR_ARG; }
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) { seg_set_error("adam: arenas must be 16-byte aligned"); return SEG_ERR_ARG; }
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, b1, b2, eps, grad_scale, step_dev);
+  SEG_LAUNCH(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, b1, b2, eps, grad_scale, step_dev);
   return seg_check_launch("adam");
 }
 
 extern "C" int seg_step_increment(int64_t* step_dev, void* stream) {
   if (!step_dev) { seg_set_error("step_increment: null"); return SEG_ERR_ARG; }
-  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, ST(stream), step_dev);
+  SEG_LAUNCH(step_inc_kernel, dim3(1), dim3(64), 0, ST(stream), step_dev);
   return seg_check_launch("step_increment");
 }
 
@@ -545,8 +545,8 @@ extern "C" int seg_pack_weights(const float* arena, void* packed, const seg_pack
                                 int64_t total_blocks, int32_t dtype, void* stream) {
   if (!arena || !packed || !table_dev || n_entries <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffff) { seg_set_error("pack: bad args"); return SEG_ERR_ARG; }
   DISPATCH(dtype,
-           hipLaunchKernelGGL(pack_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, ST(stream), arena, reinterpret_cast<float*>(packed), table_dev, n_entries),
-           hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3((unsigned)total_blocks), dim3(256), 0, ST(stream), arena, reinterpret_cast<bf16_t*>(packed), table_dev, n_entries));
+           SEG_LAUNCH(pack_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, ST(stream), arena, reinterpret_cast<float*>(packed), table_dev, n_entries),
+           SEG_LAUNCH(pack_kernel<bf16_t>, dim3((unsigned)total_blocks), dim3(256), 0, ST(stream), arena, reinterpret_cast<bf16_t*>(packed), table_dev, n_entries));
   return seg_check_launch("pack_weights");
 }
 
@@ -558,8 +558,8 @@ extern "C" int seg_bilinear_up_fwd(const seg_view* src, int32_t Hs, int32_t Ws, 
   const seg_view adv = (add && add->ptr) ? *add : null_view();
   const int64_t n = (int64_t)B * Hd * Wd * (C / 8);
   DISPATCH(dtype,
-           hipLaunchKernelGGL(bilinear_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *src, Hs, Ws, factor, filt, adv, *dst, Hd, Wd, cy, cx, B, C / 8, dst_f32),
-           hipLaunchKernelGGL(bilinear_fwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *src, Hs, Ws, factor, filt, adv, *dst, Hd, Wd, cy, cx, B, C / 8, dst_f32));
+           SEG_LAUNCH(bilinear_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *src, Hs, Ws, factor, filt, adv, *dst, Hd, Wd, cy, cx, B, C / 8, dst_f32),
+           SEG_LAUNCH(bilinear_fwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *src, Hs, Ws, factor, filt, adv, *dst, Hd, Wd, cy, cx, B, C / 8, dst_f32));
   return seg_check_launch("bilinear_fwd");
 }
 
@@ -569,7 +569,7 @@ extern "C" int seg_bilinear_up_bwd(const seg_view* ddst, int32_t Hd, int32_t Wd,
   if (!view_ok(ddst, Hd, Wd, C) || !view_ok(dsrc, Hs, Ws, C) || !filt || factor < 1 || C % 8) { seg_set_error("bilinear_bwd: bad args"); return SEG_ERR_ARG; }
   const int64_t n = (int64_t)B * Hs * Ws * (C / 8);
   DISPATCH(dtype,
-           hipLaunchKernelGGL(bilinear_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *ddst, Hd, Wd, cy, cx, factor, filt, *dsrc, Hs, Ws, B, C / 8, ddst_f32),
-           hipLaunchKernelGGL(bilinear_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *ddst, Hd, Wd, cy, cx, factor, filt, *dsrc, Hs, Ws, B, C / 8, ddst_f32));
+           SEG_LAUNCH(bilinear_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *ddst, Hd, Wd, cy, cx, factor, filt, *dsrc, Hs, Ws, B, C / 8, ddst_f32),
+           SEG_LAUNCH(bilinear_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *ddst, Hd, Wd, cy, cx, factor, filt, *dsrc, Hs, Ws, B, C / 8, ddst_f32));
   return seg_check_launch("bilinear_bwd");
 }

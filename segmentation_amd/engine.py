@@ -281,6 +281,16 @@ class Net(object):
         plan.keep.append(zv)
         plan.add(layer.name + '/db', self.lib.seg_bias_grad, C.byref(zv), self.B, H, W, layer.cout, self.store.g_ptr(layer.b_off), self.dtype, kernel='bias_grad_kernel')
 
+    def _wgrad_ws(self, w, plan, ksplit=0):
+        """Asks the library for the K split / partial-slab workspace of this wgrad and allocates it."""
+        ks, nbytes = C.c_int32(0), C.c_int64(0)
+        w.ksplit = ksplit
+        L.check(self.lib.seg_conv2d_wgrad_plan(C.byref(w), C.byref(ks), C.byref(nbytes)), 'wgrad_plan')
+        ws = torch.empty(max(nbytes.value // 4, 4), dtype=torch.float32, device=self.device)
+        w.ws = ws.data_ptr(); w.ws_bytes = nbytes.value; w.ksplit = ks.value
+        self.ws_bytes = getattr(self, 'ws_bytes', 0) + nbytes.value
+        plan.keep += [w, ws]
+
     def first_bwd(self, plan, layer, x_f32, H, W, dz):
         Ho, Wo = H + 2 * layer.pad - 2, W + 2 * layer.pad - 2
         zv = dz.view()
@@ -306,11 +316,11 @@ class Net(object):
         w.Ho, w.Wo = Ho, Wo
         w.dz = dz.view(dz_off[0], dz_off[1]); w.n_log = layer.cout
         w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = wcfg
-        plan.keep.append(w)
+        w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
+        self._wgrad_ws(w, plan)
         fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
         plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl)
         plan.flops += fl
-        self.bias_grad(plan, layer, dz, Ho, Wo, dz_off)
         n_off = 0
         for i, ds in enumerate(dsrcs):
             if ds is not None:
@@ -341,10 +351,10 @@ class Net(object):
         w.Ho, w.Wo = Hi, Wi
         w.dz = src.view(); w.n_log = layer.cin
         w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = wcfg
-        plan.keep.append(w)
+        w.bias_mode = 2; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
+        self._wgrad_ws(w, plan)
         fl = 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
         plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl)
-        self.bias_grad(plan, layer, dzu, 2 * Hi, 2 * Wi)
         plan.flops += fl
         if dsrc is not None:
             d = L.ConvDesc()
