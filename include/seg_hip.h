@@ -106,9 +106,11 @@ int seg_conv2d_wgrad_kernel_name(const seg_wgrad_desc* d, char* buf, int32_t cap
 int seg_conv_first_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin,
                        const float* w_hwio, const float* bias, int32_t cout, int32_t pad,
                        const seg_view* dst, int32_t Ho, int32_t Wo, int32_t relu, int32_t dtype, void* stream);
-int seg_conv_first_wgrad(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin,
-                         const seg_view* dz, int32_t Ho, int32_t Wo, int32_t cout, int32_t pad,
-                         float* dw_hwio, int32_t dtype, void* stream);
+
+/* im2col of the raw float input (3x3 window, k = (u*3+v)*cin + c, zero-padded to 32 channels): lets the first
+ * layer's Conv2DBackpropFilter run as a 1x1 seg_conv2d_wgrad on the MFMA path (dw comes out in HWIO order). */
+int seg_im2col3x3(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, int32_t pad, const seg_view* dst,
+                  int32_t Ho, int32_t Wo, int32_t dtype, void* stream);
 
 /* slim.max_pool2d(x, 2) (kernel 2, stride 2, VALID): models/unet.py:120,124,128,132; models/fcn.py:116-126.
  * idx (nullable): uint8 plane [B,Ho,Wo,C] with the first-max position 0..3 in window order. */

@@ -62,60 +62,46 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* x, int
   }
 }
 
-// dW[u,v,c,co] += sum_pixels x[b, y+u-pad, x+v-pad, c] * dz[b,y,x,co].
-// Thread (k = tid/8 -> (tap, c), co4 = (tid%8)*4) owns 4 outputs and walks the tile's 256 pixels from LDS.
+// im2col of the raw input for the first layer's filter gradient: dst[b,y,x,k] = x[b, y+u-pad, x+v-pad, c] with
+// k = (u*3+v)*cin + c (k < 9*cin, zero above), so that dW(HWIO) = the 1x1 "wgrad" of dst against dZ on the MFMA path.
 template <typename T>
-__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* x, int B, int H, int W, int cin, seg_view dz, int Ho, int Wo,
-                                                               int cout, int pad, float* dw, int tiles_x, int tiles_y, int ntiles) {
-  __shared__ float sx[FP * FP * 4];
-  __shared__ __attribute__((aligned(16))) float sz[256 * 36];     // [pixel][32 co] padded to 36
-  const int tid = threadIdx.x;
-  const int co0 = blockIdx.y * 32;
-  const int k = tid / 8, co4 = (tid % 8) * 4;
+__global__ void im2col3x3_kernel(const float* x, int B, int H, int W, int cin, int pad, seg_view dst, int Ho, int Wo) {
+  const int64_t total = (int64_t)B * Ho * Wo * 4;
   const int nk = 9 * cin;
-  const int tap = k / cin, c = k % cin;
-  const int u = tap / 3, v = tap % 3;
-  f32x4 acc = {0, 0, 0, 0};
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    int t = tile;
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y; const int b = t / tiles_y;
-    const int oy0 = ty * FT, ox0 = tx * FT;
-    __syncthreads();
-    for (int i = tid; i < FP * FP * cin; i += 256) {
-      const int cc = i % cin, q = i / cin;
-      const int iy = oy0 - pad + q / FP, ix = ox0 - pad + q % FP;
-      sx[q * 4 + cc] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((int64_t)b * H + iy) * W + ix) * cin + cc] : 0.f;
-    }
-    {
-      const int py = tid / FT, px = tid % FT;
-      const int oy = oy0 + py, ox = ox0 + px;
-      const bool ok = oy < Ho && ox < Wo;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int piece = i & 3; int64_t t = i >> 2;
+    const int ox = t % Wo; t /= Wo;
+    const int oy = t % Ho; const int b = t / Ho;
+    Vec8<T> o;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        Vec8<T> zv; zv.zero();
-        if (ok) zv.load(reinterpret_cast<const T*>(dz.ptr) + view_off(dz, b, oy, ox) + co0 + q * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sz[tid * 36 + q * 8 + e] = zv.get(e);
+    for (int e = 0; e < 8; ++e) {
+      const int k = piece * 8 + e;
+      float v = 0.f;
+      if (k < nk) {
+        const int tap = k / cin, c = k - tap * cin;
+        const int iy = oy - pad + tap / 3, ix = ox - pad + tap % 3;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((int64_t)b * H + iy) * W + ix) * cin + c];
       }
+      o.set(e, v);
     }
-    __syncthreads();
-    if (k < nk) {
-      for (int p = 0; p < 256; ++p) {
-        const float xv = sx[((p / FT + u) * FP + (p % FT) + v) * 4 + c];
-        const f32x4 zz = *reinterpret_cast<const f32x4*>(sz + p * 36 + co4);
-        acc[0] += xv * zz[0]; acc[1] += xv * zz[1]; acc[2] += xv * zz[2]; acc[3] += xv * zz[3];
-      }
-    }
-  }
-  if (k < nk) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (co0 + co4 + e < cout) atomicAdd(dw + (int64_t)k * cout + co0 + co4 + e, acc[e]);
+    o.store(reinterpret_cast<T*>(dst.ptr) + view_off(dst, b, oy, ox) + piece * 8);
   }
 }
 
 }  // namespace
+
+extern "C" int seg_im2col3x3(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, int32_t pad, const seg_view* dst,
+                             int32_t Ho, int32_t Wo, int32_t dtype, void* stream) {
+  if (!x || !dst || !dst->ptr || cin < 1 || cin > 3 || B <= 0 || Ho != H + 2 * pad - 2 || Wo != W + 2 * pad - 2) { seg_set_error("im2col3x3: bad args (cin 1..3)"); return SEG_ERR_ARG; }
+  if (dst->oy + Ho > dst->H || dst->ox + Wo > dst->W || dst->coff + 32 > dst->cs || dst->cs % 8 || dst->coff % 8) { seg_set_error("im2col3x3: destination window exceeds buffer"); return SEG_ERR_ARG; }
+  const int64_t n = (int64_t)B * Ho * Wo * 4;
+  int g = (int)((n + 255) / 256); if (g > 16384) g = 16384;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SEG_F32) SEG_LAUNCH(im2col3x3_kernel<float>, dim3(g), dim3(256), 0, st, x, B, H, W, cin, pad, *dst, Ho, Wo);
+  else if (dtype == SEG_BF16) SEG_LAUNCH(im2col3x3_kernel<bf16_t>, dim3(g), dim3(256), 0, st, x, B, H, W, cin, pad, *dst, Ho, Wo);
+  else { seg_set_error("im2col3x3: bad dtype"); return SEG_ERR_ARG; }
+  return seg_check_launch("im2col3x3");
+}
 
 extern "C" int seg_conv_first_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const float* w_hwio, const float* bias,
                                   int32_t cout, int32_t pad, const seg_view* dst, int32_t Ho, int32_t Wo, int32_t relu, int32_t dtype,
@@ -131,18 +117,4 @@ extern "C" int seg_conv_first_fwd(const float* x, int32_t B, int32_t H, int32_t 
   else if (dtype == SEG_BF16) SEG_LAUNCH(conv_first_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, x, B, H, W, cin, w_hwio, bias, cout, pad, *dst, Ho, Wo, relu, tiles_x, tiles_y);
   else { seg_set_error("conv_first_fwd: bad dtype"); return SEG_ERR_ARG; }
   return seg_check_launch("conv_first_fwd");
-}
-
-extern "C" int seg_conv_first_wgrad(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const seg_view* dz, int32_t Ho, int32_t Wo,
-                                    int32_t cout, int32_t pad, float* dw_hwio, int32_t dtype, void* stream) {
-  if (!x || !dw_hwio || !dz || !dz->ptr || cin < 1 || cin > 3 || cout < 1 || B <= 0) { seg_set_error("conv_first_wgrad: bad args (cin must be 1..3)"); return SEG_ERR_ARG; }
-  const int cp = cdiv(cout, 32) * 32;
-  if (dz->oy + Ho > dz->H || dz->ox + Wo > dz->W || dz->coff + cp > dz->cs || dz->cs % 8 || dz->coff % 8) { seg_set_error("conv_first_wgrad: dz window exceeds buffer"); return SEG_ERR_ARG; }
-  const int tiles_x = cdiv(Wo, FT), tiles_y = cdiv(Ho, FT), ntiles = B * tiles_x * tiles_y;
-  dim3 grid(ntiles < 1024 ? ntiles : 1024, cp / 32);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SEG_F32) SEG_LAUNCH(conv_first_wgrad_kernel<float>, grid, dim3(256), 0, st, x, B, H, W, cin, *dz, Ho, Wo, cout, pad, dw_hwio, tiles_x, tiles_y, ntiles);
-  else if (dtype == SEG_BF16) SEG_LAUNCH(conv_first_wgrad_kernel<bf16_t>, grid, dim3(256), 0, st, x, B, H, W, cin, *dz, Ho, Wo, cout, pad, dw_hwio, tiles_x, tiles_y, ntiles);
-  else { seg_set_error("conv_first_wgrad: bad dtype"); return SEG_ERR_ARG; }
-  return seg_check_launch("conv_first_wgrad");
 }

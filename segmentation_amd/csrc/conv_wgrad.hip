@@ -21,6 +21,7 @@ struct WgK {
   int nchunks0, nchunks, nblk;   // K chunks of src0 / total; BN blocks
   int k_pad, n_pad;              // slab = [taps][k_pad][n_pad] floats followed by bias[max(k_pad,n_pad)]
   int64_t slab;                  // floats per split
+  int direct;                    // ksplit == 1: store straight into dw/db, no reduce pass
 };
 
 template <typename T> SEG_DEV Frag<T> ones_frag();
@@ -47,11 +48,16 @@ template <> struct TrRead<bf16_t> {
   }
 };
 
-template <typename T, int TH, int TW, int KH, int KW, int S, int WCI, int WCO, int FCI, int FCO>
+// RS = 1: "row split" -- blockIdx.z selects one filter row u, the workgroup keeps only KW taps in registers.
+// Used for the deep layers (few pixel tiles, big filters) where splitting K cannot create enough workgroups:
+// it multiplies the workgroup count by KH without any partial-sum traffic.
+template <typename T, int TH, int TW, int KH, int KW, int S, int WCI, int WCO, int FCI, int FCO, int RS>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   constexpr int BM = TH * TW;
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW, NPIX = PH * PW;
-  constexpr int NT = KH * KW;
+  constexpr int NU = RS ? 1 : KH;
+  constexpr int NT = NU * KW;                 // taps held by this workgroup
+  constexpr int NTF = KH * KW;                // taps of the filter
   constexpr int ES = sizeof(T);
   constexpr int BN = 16 * FCO * WCO;
   constexpr int RSP = 32 * ES + 16;            // patch row stride (bytes)
@@ -74,6 +80,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   const int lr = lane & 15, G = lane >> 4;
 
   const int chunk = blockIdx.x / P.nblk, nb = blockIdx.x % P.nblk;
+  const int u0 = RS ? blockIdx.z : 0;
   const bool first = chunk < P.nchunks0;
   const seg_view& sv = first ? d.src0 : d.src1;
   const int cbase = first ? chunk * 32 : (chunk - P.nchunks0) * 32;   // padded channel base inside its source
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
 
   // bias gradient: mode 1 = column sums of dz (conv; only chunk-0 workgroups), mode 2 = sums of src over
   // pixels and taps (transposed conv, where src is the big dZ map; only nb-0 workgroups)
-  const bool bias1 = d.bias_mode == 1 && chunk == 0 && wci == 0;
+  const bool bias1 = d.bias_mode == 1 && chunk == 0 && wci == 0 && u0 == 0;
   const bool bias2 = d.bias_mode == 2 && nb == 0 && wco == 0;
   f32x4 accb1[FCO], accb2[FCI];
 #pragma unroll
@@ -196,12 +203,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
         for (int c = 0; c < FCO; ++c) mma32(accb1[c], ones, fz[c]);
       }
 #pragma unroll
-      for (int u = 0; u < KH; ++u)
+      for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int v = 0; v < KW; ++v)
 #pragma unroll
           for (int a = 0; a < FCI; ++a) {
-            Frag<T> fx = read_frag(sP, pa[ks], (u * PW + v) * RSP + a_ch + a * 16 * ES);
+            Frag<T> fx = read_frag(sP, pa[ks], ((u0 + u) * PW + v) * RSP + a_ch + a * 16 * ES);
 #pragma unroll
             for (int c = 0; c < FCO; ++c) mma32(acc[u * KW + v][a][c], fx, fz[c]);
             if (bias2) mma32(accb2[a], fx, ones);
@@ -209,91 +216,134 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
     }
   }
 
-  // ---- flush into this split's slab: D[row = ci][col = co]; lane: co = lr, ci = 4G + r ----
-  float* slab = d.ws + (int64_t)blockIdx.y * P.slab;
+  // ---- flush: D[row = ci][col = co]; lane: co = lr, ci = 4G + r ----
+  // ksplit == 1: straight into the TF-layout gradient; else into this split's slab (plain stores).
   const int kbase = chunk * 32;                                    // padded concat channel base
+  const int k_log_n = d.src0_clog + d.src1_clog;
+  float* slab = d.ws + (int64_t)blockIdx.y * P.slab;
 #pragma unroll
   for (int a = 0; a < FCI; ++a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int k = kbase + (wci * FCI + a) * 16 + 4 * G + r;
+      const int cil = k - (first ? 0 : d.src0.c);                  // padded channel inside its source
+      const int kl = first ? (cil < d.src0_clog ? cil : -1) : (cil < d.src1_clog ? d.src0_clog + cil : -1);
 #pragma unroll
       for (int c = 0; c < FCO; ++c) {
         const int co = n0 + (wco * FCO + c) * 16 + lr;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) slab[((int64_t)t * P.k_pad + k) * P.n_pad + co] = acc[t][a][c][r];
+        for (int t = 0; t < NT; ++t) {
+          const int tg = u0 * KW + t;
+          if (P.direct) {
+            if (kl >= 0 && co < d.n_log) d.dw[((int64_t)tg * k_log_n + kl) * d.n_log + co] = acc[t][a][c][r];
+          } else {
+            slab[((int64_t)tg * P.k_pad + k) * P.n_pad + co] = acc[t][a][c][r];
+          }
+        }
       }
     }
-  float* bslab = slab + (int64_t)NT * P.k_pad * P.n_pad;
+  float* bslab = slab + (int64_t)NTF * P.k_pad * P.n_pad;
   if (bias1 && G == 0) {
 #pragma unroll
-    for (int c = 0; c < FCO; ++c) bslab[n0 + (wco * FCO + c) * 16 + lr] = accb1[c][0];      // row 0 of D
+    for (int c = 0; c < FCO; ++c) {                                // row 0 of D = column sums of dz
+      const int co = n0 + (wco * FCO + c) * 16 + lr;
+      if (P.direct) { if (co < d.bias_n) d.db[co] = accb1[c][0]; }
+      else bslab[co] = accb1[c][0];
+    }
   }
   if (bias2 && lr == 0) {
 #pragma unroll
     for (int a = 0; a < FCI; ++a)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bslab[kbase + (wci * FCI + a) * 16 + 4 * G + r] = accb2[a][r];   // column 0 of D
+      for (int r = 0; r < 4; ++r) {                                // column 0 of D = row sums of src
+        const int k = kbase + (wci * FCI + a) * 16 + 4 * G + r;
+        if (P.direct) { if (k < d.bias_n) d.db[k] = accb2[a][r]; }
+        else bslab[k] = accb2[a][r];
+      }
   }
 }
 
-// Sums the ksplit slabs (fixed order => bitwise reproducible) and scatters to the logical TF layout.
-// SP = 1: one thread per output (few splits).  SP = 16: a 256-thread block owns 16 consecutive outputs,
-// thread (jj = t/16, oo = t%16) sums splits s = jj, jj+16, ... (4 independent chains), then the 16 partial
-// sums meet in LDS and are added in jj order.
-SEG_DEV void reduce_addr(int64_t i, int64_t nw, int taps, int k_pad, int n_pad, int seg0_c, int seg0_cp, int k_log, int n_log,
-                         float* dw, float* db, int64_t& src, float*& dst) {
-  if (i < nw) {
-    const int n = i % n_log; int64_t t = i / n_log;
-    const int k = t % k_log; const int tap = t / k_log;
-    const int kp = k < seg0_c ? k : seg0_cp + (k - seg0_c);
-    src = ((int64_t)tap * k_pad + kp) * n_pad + n;
-    dst = dw + i;
-  } else {
-    src = (int64_t)taps * k_pad * n_pad + (i - nw);
-    dst = db + (i - nw);
-  }
-}
-
-template <int SP>
+// Sums the ksplit slabs (fixed association => bitwise reproducible) and scatters to the logical TF layout.
+// One thread owns V consecutive n (V = 4: 16-byte coalesced loads, needs n_log % 4 == 0).  SG = 16: a block =
+// 16 outputs x 16 split groups, group g sums splits g, g+16, ... (8 loads in flight), partials meet in LDS and
+// are added in group order; SG = 1 (few splits): one thread per output.
+template <int V, int SG>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int ksplit, int64_t slab, int taps, int k_pad, int n_pad,
                                                            int seg0_c, int seg0_cp, int seg1_c, int n_log, float* dw, int bias_mode,
                                                            int bias_n, float* db) {
+  __shared__ float red[SG][16 * V + 1];
   const int k_log = seg0_c + seg1_c;
-  const int64_t nw = (int64_t)taps * k_log * n_log;
-  const int64_t total = nw + (bias_mode ? bias_n : 0);
-  if (SP == 1) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-      int64_t src; float* dst;
-      reduce_addr(i, nw, taps, k_pad, n_pad, seg0_c, seg0_cp, k_log, n_log, dw, db, src, dst);
-      float a = 0.f;
-      for (int s = 0; s < ksplit; ++s) a += ws[(int64_t)s * slab + src];
-      *dst = a;
+  const int nq = n_log / V;
+  const int64_t nw = (int64_t)taps * k_log * nq;
+  const int64_t nb = bias_mode ? (bias_n + V - 1) / V : 0;          // bias handled in units of V as well
+  const int64_t total = nw + nb;
+  constexpr int OPB = 256 / SG;                                     // outputs (units of V) per block
+  const int ol = threadIdx.x % OPB, g = threadIdx.x / OPB;
+  for (int64_t i0 = (int64_t)blockIdx.x * OPB; i0 < total; i0 += (int64_t)gridDim.x * OPB) {
+    const int64_t i = i0 + ol;
+    const float* src = ws;
+    float* dst = nullptr;
+    int valid = 0;                                                  // elements of this unit that exist
+    if (i < nw) {
+      const int q = i % nq; int64_t t = i / nq;
+      const int k = t % k_log; const int tap = t / k_log;
+      const int kp = k < seg0_c ? k : seg0_cp + (k - seg0_c);
+      src = ws + ((int64_t)tap * k_pad + kp) * n_pad + q * V;
+      dst = dw + ((int64_t)tap * k_log + k) * n_log + q * V;
+      valid = V;
+    } else if (i < total) {
+      const int j0 = (int)(i - nw) * V;
+      src = ws + (int64_t)taps * k_pad * n_pad + j0;
+      dst = db + j0;
+      valid = bias_n - j0 < V ? bias_n - j0 : V;
     }
-  } else {
-    __shared__ float red[16][17];
-    const int oo = threadIdx.x & 15, jj = threadIdx.x >> 4;
-    for (int64_t i0 = (int64_t)blockIdx.x * 16; i0 < total; i0 += (int64_t)gridDim.x * 16) {
-      const int64_t i = i0 + oo;
-      int64_t src = 0; float* dst = nullptr;
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      if (i < total) {
-        reduce_addr(i, nw, taps, k_pad, n_pad, seg0_c, seg0_cp, k_log, n_log, dw, db, src, dst);
-        int s = jj;
-        for (; s + 48 < ksplit; s += 64) {
-          a0 += ws[(int64_t)s * slab + src]; a1 += ws[(int64_t)(s + 16) * slab + src];
-          a2 += ws[(int64_t)(s + 32) * slab + src]; a3 += ws[(int64_t)(s + 48) * slab + src];
-        }
-        for (; s < ksplit; s += 16) a0 += ws[(int64_t)s * slab + src];
-      }
-      __syncthreads();
-      red[jj][oo] = (a0 + a1) + (a2 + a3);
-      __syncthreads();
-      if (jj == 0 && i < total) {
-        float a = 0.f;
+    float a[V];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) a += red[q][oo];
-        *dst = a;
+    for (int e = 0; e < V; ++e) a[e] = 0.f;
+    if (valid > 0) {
+      int s = g;
+      for (; s + 7 * SG < ksplit; s += 8 * SG) {
+        float v[8][V];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float* p = src + (int64_t)(s + j * SG) * slab;
+          if (V == 4 && valid == 4) { const f32x4 x = *reinterpret_cast<const f32x4*>(p); v[j][0] = x[0]; v[j][1 % V] = x[1]; v[j][2 % V] = x[2]; v[j][3 % V] = x[3]; }
+          else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[j][e] = e < valid ? p[e] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int e = 0; e < V; ++e) a[e] += v[j][e];
+      }
+      for (; s < ksplit; s += SG) {
+        const float* p = src + (int64_t)s * slab;
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] += e < valid ? p[e] : 0.f;
+      }
+    }
+    if (SG > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < V; ++e) red[g][ol * V + e] = a[e];
+      __syncthreads();
+      if (g == 0) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          float r = 0.f;
+#pragma unroll
+          for (int q = 0; q < SG; ++q) r += red[q][ol * V + e];
+          a[e] = r;
+        }
+      }
+    }
+    if (g == 0 && valid > 0) {
+      if (V == 4 && valid == 4 && (((uintptr_t)dst) & 15) == 0) *reinterpret_cast<f32x4*>(dst) = f32x4{a[0], a[1 % V], a[2 % V], a[3 % V]};
+      else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) if (e < valid) dst[e] = a[e];
       }
     }
   }
@@ -307,10 +357,6 @@ thread_local int64_t* g_plan_bytes = nullptr;
 template <typename T, int TH, int TW, int KH, int KW, int S, int WCI, int WCO, int FCI, int FCO>
 int launch_cfg(const WgK& P0, hipStream_t st) {
   constexpr int BN = 16 * FCO * WCO, ES = sizeof(T);
-  if (g_wname_out) {
-    snprintf(g_wname_out, g_wname_cap, "conv_wgrad_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,%d>", ES == 2 ? "bf16" : "f32", TH, TW, KH, KW, S, WCI, WCO, FCI, FCO);
-    return SEG_OK;
-  }
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
   constexpr int PATCH_BYTES = ((PH * PW * (32 * ES + 16) + 15) / 16) * 16;
   constexpr int LDS = PATCH_BYTES + TH * TW * (BN * ES + 16);
@@ -320,38 +366,51 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
   P.nblk = cdiv(P.d.dz.c, BN);
   if (P.d.dz.c % BN) { seg_set_error("wgrad: dz channels %d not a multiple of BN %d", P.d.dz.c, BN); return SEG_ERR_ARG; }
   const int base = P.nchunks * P.nblk;
-  // K split: enough workgroups to fill the chip once (every split costs one slab write + read of this
-  // workgroup tile: ~9*32*BN*4 bytes), never more splits than pixel tiles.
-  int ks = P.d.ksplit > 0 ? P.d.ksplit : cdiv(256, base);
+  // Parallelism: (1) deep layers (few pixel tiles, big filters): split the KH filter rows over blockIdx.z -- no
+  // partial sums; (2) split K (pixel tiles) until ~256 workgroups exist; every split costs one slab write + read
+  // of the workgroup tile, so never more than needed and never more than there are tiles.
+  const bool rs = KH > 1 && P.d.bias_mode != 2 && P.ntiles <= 64 && base < 192;
+  const int wg = base * (rs ? KH : 1);
+  int ks = P.d.ksplit > 0 ? P.d.ksplit : cdiv(256, wg);
   if (ks > P.ntiles) ks = P.ntiles;
   if (ks < 1) ks = 1;
   P.ksplit = ks;
+  P.direct = ks == 1;
   P.k_pad = P.nchunks * 32; P.n_pad = P.d.dz.c;
   const int64_t bias_len = P.k_pad > P.n_pad ? P.k_pad : P.n_pad;
   P.slab = (int64_t)KH * KW * P.k_pad * P.n_pad + bias_len;
-  if (g_plan_ks) { *g_plan_ks = ks; *g_plan_bytes = P.slab * ks * 4; return SEG_OK; }
-  if (!P.d.ws || P.d.ws_bytes < P.slab * ks * 4) { seg_set_error("wgrad: workspace too small (%lld < %lld bytes)", (long long)P.d.ws_bytes, (long long)(P.slab * ks * 4)); return SEG_ERR_ARG; }
-  auto kern = conv_wgrad_kernel<T, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO>;
+  if (g_wname_out) {
+    snprintf(g_wname_out, g_wname_cap, "conv_wgrad_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", ES == 2 ? "bf16" : "f32", TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, rs ? 1 : 0);
+    return SEG_OK;
+  }
+  if (g_plan_ks) { *g_plan_ks = ks; *g_plan_bytes = P.direct ? 0 : P.slab * ks * 4; return SEG_OK; }
+  if (!P.direct && (!P.d.ws || P.d.ws_bytes < P.slab * ks * 4)) { seg_set_error("wgrad: workspace too small (%lld < %lld bytes)", (long long)P.d.ws_bytes, (long long)(P.slab * ks * 4)); return SEG_ERR_ARG; }
+  auto k0 = conv_wgrad_kernel<T, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, 0>;
+  auto k1 = conv_wgrad_kernel<T, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, (KH > 1 ? 1 : 0)>;
   static bool attr_done = false;
   if (!attr_done && LDS > 48 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       seg_set_error("wgrad: cannot raise dynamic LDS to %d", LDS); return SEG_ERR_LAUNCH;
     }
     attr_done = true;
   }
-  SEG_LAUNCH(kern, dim3(base, ks), dim3(256), LDS, st, P);
+  if (rs) SEG_LAUNCH(k1, dim3(base, ks, KH), dim3(256), LDS, st, P);
+  else SEG_LAUNCH(k0, dim3(base, ks, 1), dim3(256), LDS, st, P);
   int rc = seg_check_launch("conv_wgrad");
-  if (rc) return rc;
-  const int64_t total = (int64_t)KH * KW * (P.d.src0_clog + P.d.src1_clog) * P.d.n_log + (P.d.bias_mode ? P.d.bias_n : 0);
-  if (ks <= 4) {
-    int rg = (int)((total + 255) / 256); if (rg > 4096) rg = 4096;
-    SEG_LAUNCH(wgrad_reduce_kernel<1>, dim3(rg), dim3(256), 0, st, P.d.ws, ks, P.slab, KH * KW, P.k_pad, P.n_pad, P.d.src0_clog, P.d.src0.c,
-               P.d.src1_clog, P.d.n_log, P.d.dw, P.d.bias_mode, P.d.bias_n, P.d.db);
-  } else {
-    int rg = (int)((total + 15) / 16); if (rg > 8192) rg = 8192;
-    SEG_LAUNCH(wgrad_reduce_kernel<16>, dim3(rg), dim3(256), 0, st, P.d.ws, ks, P.slab, KH * KW, P.k_pad, P.n_pad, P.d.src0_clog, P.d.src0.c,
-               P.d.src1_clog, P.d.n_log, P.d.dw, P.d.bias_mode, P.d.bias_n, P.d.db);
-  }
+  if (rc || P.direct) return rc;
+  const int taps = KH * KW, k_log = P.d.src0_clog + P.d.src1_clog;
+  const bool v4 = (P.d.n_log % 4 == 0) && (P.n_pad % 4 == 0);
+  const int V = v4 ? 4 : 1;
+  const int64_t units = (int64_t)taps * k_log * (P.d.n_log / V) + (P.d.bias_mode ? (P.d.bias_n + V - 1) / V : 0);
+  const bool par = ks > 8;
+  int rg = (int)((units + (par ? 15 : 255)) / (par ? 16 : 256)); if (rg > 8192) rg = 8192;
+#define RED_ARGS P.d.ws, ks, P.slab, taps, P.k_pad, P.n_pad, P.d.src0_clog, P.d.src0.c, P.d.src1_clog, P.d.n_log, P.d.dw, P.d.bias_mode, P.d.bias_n, P.d.db
+  if (v4 && par) SEG_LAUNCH((wgrad_reduce_kernel<4, 16>), dim3(rg), dim3(256), 0, st, RED_ARGS);
+  else if (v4) SEG_LAUNCH((wgrad_reduce_kernel<4, 1>), dim3(rg), dim3(256), 0, st, RED_ARGS);
+  else if (par) SEG_LAUNCH((wgrad_reduce_kernel<1, 16>), dim3(rg), dim3(256), 0, st, RED_ARGS);
+  else SEG_LAUNCH((wgrad_reduce_kernel<1, 1>), dim3(rg), dim3(256), 0, st, RED_ARGS);
+#undef RED_ARGS
   return seg_check_launch("wgrad_reduce");
 }
 

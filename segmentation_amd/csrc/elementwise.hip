@@ -321,9 +321,12 @@ SEG_DEV int seg_ci(const seg_pack_entry& e, int kpad) {   // padded concat chann
   const int k1 = kpad - e.seg0_cp;
   return (k1 < e.seg1_c) ? e.seg0_c + k1 : -1;
 }
+// One 256-thread block per 32(k) x 32(n) tile of one tap: reads run along the source's fastest axis, the tile is
+// transposed through LDS when that axis is n, writes are one contiguous 32x32 block of the packed arena.
 template <typename T>
-__global__ void pack_kernel(const float* arena, T* packed, const seg_pack_entry* tab, int n_entries) {
+__global__ __launch_bounds__(256) void pack_kernel(const float* arena, T* packed, const seg_pack_entry* tab, int n_entries) {
   __shared__ int s_e;
+  __shared__ float tile[32][33];
   if (threadIdx.x == 0) {
     int lo = 0;
     for (int i = 0; i < n_entries; ++i) if ((int64_t)blockIdx.x >= tab[i].blk_start) lo = i;
@@ -331,34 +334,46 @@ __global__ void pack_kernel(const float* arena, T* packed, const seg_pack_entry*
   }
   __syncthreads();
   const seg_pack_entry e = tab[s_e];
-  const int64_t idx = ((int64_t)blockIdx.x - e.blk_start) * 256 + threadIdx.x;
-  if (idx >= e.n_elems) return;
-  const int kk = idx % 32;
-  int64_t t = idx / 32;
-  const int npk = t % e.n_total; t /= e.n_total;
-  const int nch = e.k_pad / 32;
+  // tile index -> (tap, chunk, n block)
+  int64_t t = (int64_t)blockIdx.x - e.blk_start;
+  const int nblk = e.n_total / 32, nch = e.k_pad / 32;
+  const int nb = t % nblk; t /= nblk;
   const int chunk = t % nch; const int tap = t / nch;
-  const int pos = npk & 31;
-  const int n = (npk & ~31) | (((pos >> 2) & 3) << 3) | (((pos >> 4) & 1) << 2) | (pos & 3);
-  const int k = chunk * 32 + kk;
   const float* src = arena + e.src_off;
-  float val = 0.f;
-  if (e.mode == SEG_PACK_CONV_FWD) {
-    const int ci = seg_ci(e, k);
-    if (ci >= 0 && n < e.cout) val = src[((int64_t)tap * e.cin + ci) * e.cout + n];
-  } else if (e.mode == SEG_PACK_CONV_DGRAD) {
-    const int ci = seg_ci(e, n);
-    const int u = e.KH - 1 - tap / e.KW, v = e.KW - 1 - tap % e.KW;
-    if (ci >= 0 && k < e.cout) val = src[((int64_t)(u * e.KW + v) * e.cin + ci) * e.cout + k];
-  } else if (e.mode == SEG_PACK_UP_FWD) {
-    const int ci = seg_ci(e, k);
-    const int tp = n / e.cout_pad, co = n % e.cout_pad;
-    if (ci >= 0 && co < e.cout && tp < 4) val = src[((int64_t)tp * e.cout + co) * e.cin + ci];
-  } else {  // SEG_PACK_UP_DGRAD
-    const int ci = seg_ci(e, n);
-    if (ci >= 0 && k < e.cout) val = src[((int64_t)tap * e.cout + k) * e.cin + ci];
+  const bool n_fast = (e.mode == SEG_PACK_CONV_FWD || e.mode == SEG_PACK_UP_DGRAD);   // source index runs fastest along n
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    const int fast = idx & 31, slow = idx >> 5;
+    const int kk = n_fast ? slow : fast, nn = n_fast ? fast : slow;     // element (k = chunk*32+kk, logical n = nb*32+nn)
+    const int k = chunk * 32 + kk, n = nb * 32 + nn;
+    float val = 0.f;
+    if (e.mode == SEG_PACK_CONV_FWD) {
+      const int ci = seg_ci(e, k);
+      if (ci >= 0 && n < e.cout) val = src[((int64_t)tap * e.cin + ci) * e.cout + n];
+    } else if (e.mode == SEG_PACK_CONV_DGRAD) {
+      const int ci = seg_ci(e, n);
+      const int u = e.KH - 1 - tap / e.KW, v = e.KW - 1 - tap % e.KW;
+      if (ci >= 0 && k < e.cout) val = src[((int64_t)(u * e.KW + v) * e.cin + ci) * e.cout + k];
+    } else if (e.mode == SEG_PACK_UP_FWD) {
+      const int ci = seg_ci(e, k);
+      const int tp = n / e.cout_pad, co = n % e.cout_pad;
+      if (ci >= 0 && co < e.cout && tp < 4) val = src[((int64_t)tp * e.cout + co) * e.cin + ci];
+    } else {  // SEG_PACK_UP_DGRAD
+      const int ci = seg_ci(e, n);
+      if (ci >= 0 && k < e.cout) val = src[((int64_t)tap * e.cout + k) * e.cin + ci];
+    }
+    tile[nn][kk] = val;
   }
-  packed[e.dst_off + idx] = from_f32<T>(val);
+  __syncthreads();
+  T* dst = packed + e.dst_off + (((int64_t)tap * nch + chunk) * e.n_total + nb * 32) * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    const int kk = idx & 31, pos = idx >> 5;                             // packed row position inside the 32-block
+    const int nn = (((pos >> 2) & 3) << 3) | (((pos >> 4) & 1) << 2) | (pos & 3);   // -> logical row
+    dst[pos * 32 + kk] = from_f32<T>(tile[nn][kk]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -103,7 +103,7 @@ class ParamStore(object):
                 setattr(l, attr, poff)
                 entries.append(e)
                 poff += ne
-                blk += (ne + 255) // 256
+                blk += ne // 1024                 # one block per 32x32 tile
         self.packed = torch.zeros(max(poff, 8), dtype=torch_dtype(dtype), device=device)
         self.n_pack_entries, self.pack_blocks = len(entries), blk
         if entries:
@@ -292,14 +292,28 @@ class Net(object):
         plan.keep += [w, ws]
 
     def first_bwd(self, plan, layer, x_f32, H, W, dz):
+        """First-layer filter/bias gradient: im2col of the raw input (27 -> 32 channels) + the generic 1x1 MFMA wgrad;
+        the [1][9*cin][cout] result is exactly the HWIO filter gradient."""
         Ho, Wo = H + 2 * layer.pad - 2, W + 2 * layer.pad - 2
-        zv = dz.view()
-        plan.keep.append(zv)
-        plan.add(layer.name + '/dw', self.lib.seg_conv_first_wgrad, x_f32.data_ptr(), self.B, H, W, layer.cin, C.byref(zv), Ho, Wo,
-                 layer.cout, layer.pad, self.store.g_ptr(layer.w_off), self.dtype, kernel='conv_first_wgrad_kernel',
-                 flops=2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout)
-        self.bias_grad(plan, layer, dz, Ho, Wo)
-        plan.flops += 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
+        if layer.cin > 3:
+            raise L.SegError('first-layer gradient supports input_channel <= 3')
+        col = self.act(Ho, Wo, 9 * layer.cin, name='im2col')
+        cv = col.view()
+        plan.keep.append(cv)
+        plan.add(layer.name + '/im2col', self.lib.seg_im2col3x3, x_f32.data_ptr(), self.B, H, W, layer.cin, layer.pad, C.byref(cv), Ho, Wo,
+                 self.dtype, kernel='im2col3x3_kernel')
+        w = L.WgradDesc()
+        w.src0 = col.view(); w.src1 = L.null_view(); w.src0_clog = 9 * layer.cin; w.src1_clog = 0
+        w.B, w.Hi, w.Wi = self.B, Ho, Wo
+        w.KH = w.KW = 1; w.stride = 1; w.pad_t = w.pad_l = 0
+        w.Ho, w.Wo = Ho, Wo
+        w.dz = dz.view(); w.n_log = layer.cout
+        w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = 0
+        w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
+        self._wgrad_ws(w, plan)
+        fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
+        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl)
+        plan.flops += fl
 
     def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0):
         """Filter + bias gradient, then one dgrad launch per entry of dsrcs.

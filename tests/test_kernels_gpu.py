@@ -154,8 +154,9 @@ def test_conv_first(dtype, pad, cin, cout, H):
         bp = E.Plan('b'); net.first_bwd(bp, layer, xt, H, W, dz); bp.run(U.stream()); U.sync()
         dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (3, 3), layer.padding, 1)
         g = store.get_grads()['f']
-        assert U.rel_err(g['weights'], dw_ref) < 2e-5
-        assert U.rel_err(g['biases'], db_ref) < 2e-5
+        # bf16 mode rounds the im2col'd input to bf16 (the MFMA operand type)
+        assert U.rel_err(g['weights'], dw_ref) < U.tol(dtype, 2e-5, 1e-2)
+        assert U.rel_err(g['biases'], db_ref) < U.tol(dtype, 2e-5, 1e-2)
 
 
 @pytest.mark.parametrize('dtype', DT)
