@@ -39,7 +39,7 @@ class BaseModel(object):
                  load_snapshot_from=None,
                  adversarial_training=False,
                  dtype='bf16', use_graph=True, crop_aware=True, device=None, process_group=None, seed=5555,
-                 overlap_allreduce=True):
+                 overlap_allreduce=True, wgrad_streams=2):
         self.mode = mode
         self.log_dir = log_dir
         self.dataset = dataset
@@ -88,6 +88,7 @@ class BaseModel(object):
         self.seed = seed
         self.pg = D.DataParallel(process_group, overlap=overlap_allreduce)
         self._graphs = {}
+        self._side = [torch.cuda.Stream(self.device) for _ in range(wgrad_streams)] if wgrad_streams > 0 else None
         self._infer_cache = {}
         self.sess = sess
         self._gs_host = 0
@@ -170,7 +171,7 @@ class BaseModel(object):
         self.store.g.zero_()
         self.loss_buf.zero_()
         self.fwd_plan.run(s)
-        self.bwd_plan.run(s)
+        self.bwd_plan.run(s, self._side)
 
     def _run_update(self):
         self.upd_plan.run(self._stream())
@@ -220,11 +221,11 @@ class BaseModel(object):
         def head():
             self.store.g.zero_(); self.loss_buf.zero_()
             self.fwd_plan.run(self._stream())
-            self.bwd_segments[0][0].run(self._stream())
+            self.bwd_segments[0][0].run(self._stream(), self._side)
         self._replay('dp0', head)
         self.pg.all_reduce_bucket(self.store.g, *self.bwd_segments[0][1])
         for i, (plan, (lo, hi)) in enumerate(self.bwd_segments[1:], 1):
-            self._replay('dp%d' % i, lambda plan=plan: plan.run(self._stream()))
+            self._replay('dp%d' % i, lambda plan=plan: plan.run(self._stream(), self._side))
             self.pg.all_reduce_bucket(self.store.g, lo, hi)
         self.pg.wait_all()
         self._replay('upd', self._run_update)

@@ -15,6 +15,7 @@
 // KH*KW filter taps for its BN rows, then runs KH*KW taps x fragments of MFMA out of LDS; the
 // next chunk's global loads are in flight (registers) while the current one computes.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -23,6 +24,58 @@ struct ConvK {          // kernel-side copy of the descriptor (trivially copyabl
   int tiles_x, tiles_y; // spatial tiles per image
   int nchunks0, nchunks; // K chunks from src0 / total
 };
+
+// ---- epilogue: bias, ReLU, ReLU-grad mask, store 8 channels per lane ----
+template <typename T, int TH, int TW, int BN, int WM, int WN, int FM, int FN>
+SEG_DEV void conv_epilogue(const seg_conv_desc& d, f32x4 (&acc)[FN][FM], int b, int oy0, int ox0, int n0, int wm, int wn, int lr, int g) {
+  constexpr int BM = TH * TW;
+#pragma unroll
+  for (int j = 0; j < FN / 2; ++j) {
+    const int nl = n0 + wn * (BN / WN) + j * 32 + 8 * g;     // first of this lane's 8 channels (launch-local)
+    if (nl >= d.n_count) continue;
+    const int np = d.n_off + nl;                               // packed row index
+    int co = nl, ua = 0, uc = 0;
+    if (d.up2) { const int tp = np / d.up_cout; co = np - tp * d.up_cout; ua = tp >> 1; uc = tp & 1; }
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int bi = d.up2 ? co + e : np + e;
+      bv[e] = (d.bias != nullptr && bi < d.bias_n) ? d.bias[bi] : 0.f;
+    }
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+      const int m = wm * (BM / WM) + fm * 16 + lr;
+      const int oy = oy0 + m / TW, ox = ox0 + m % TW;
+      if (oy >= d.Ho || ox >= d.Wo) continue;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = acc[2 * j][fm][e] + bv[e]; v[4 + e] = acc[2 * j + 1][fm][e] + bv[4 + e]; }
+      if (d.relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      const int dy = d.up2 ? 2 * oy + ua : oy, dx = d.up2 ? 2 * ox + uc : ox;
+      if (d.mask.ptr != nullptr) {
+        Vec8<T> mk;
+        mk.load(reinterpret_cast<const T*>(d.mask.ptr) + view_off(d.mask, b, dy, dx) + co);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = mk.get(e) > 0.f ? v[e] : 0.f;
+      }
+      const int64_t doff = view_off(d.dst, b, dy, dx) + co;
+      if (d.out_f32) {
+        Vec8<float> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, v[e]);
+        o.store(reinterpret_cast<float*>(d.dst.ptr) + doff);
+      } else {
+        Vec8<T> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, v[e]);
+        o.store(reinterpret_cast<T*>(d.dst.ptr) + doff);
+      }
+    }
+  }
+}
 
 template <typename T, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
@@ -155,53 +208,138 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
     }
   }
 
-  // ---- epilogue: bias, ReLU, ReLU-grad mask, store 8 channels per lane ----
+  conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN>(d, acc, b, oy0, ox0, n0, wm, wn, lr, g);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bf16 fast path: same tiling, but the patch and filter rows go global -> LDS directly (global_load_lds_dwordx4,
+// no staging VGPRs, no ds_write), into TWO LDS buffers: chunk c+1 is in flight while chunk c feeds the MFMAs, one
+// barrier per chunk.  The LDS image of a load is lane-linear (wave base + lane*16), so the bank swizzle of
+// Tr<bf16>::lds_off is applied to the SOURCE address of each lane; out-of-image pixels read a 16-byte zero word.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0, 0, 0, 0};
+
+SEG_DEV void glds16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S>
+__global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
+  using T = bf16_t;
+  using TT = Tr<T>;
+  constexpr int BM = TH * TW;
+  constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW, NPIX = PH * PW;
+  constexpr int NT = KH * KW;
+  constexpr int RSTR = TT::RSTR;
+  constexpr int PINST = (NPIX * 4 + 63) / 64;             // wave-instructions (1 KiB each) for the patch
+  constexpr int WINST = NT * BN * 4 / 64;                 // ... for the filter rows
+  constexpr int PPW = (PINST + 3) / 4, WPW = (WINST + 3) / 4;   // per wave
+  constexpr int PATCH_BYTES = PINST * 1024;
+  constexpr int BUF = PATCH_BYTES + WINST * 1024;
+  constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+  static_assert(WM * WN == 4 && FN % 2 == 0, "wave layout");
+  static_assert((NT * BN * 4) % 64 == 0, "filter rows fill whole wave-instructions");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const seg_conv_desc& d = P.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 15, g = lane >> 4;
+
+  int t = blockIdx.x;
+  const int tx = t % P.tiles_x; t /= P.tiles_x;
+  const int ty = t % P.tiles_y; const int b = t / P.tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- per-lane source descriptors: instruction i of this wave covers LDS pieces [(i*4+wave)*64, +64) ----
+  int p_off0[PPW], p_off1[PPW];                 // element offsets inside image b; -1 = zero word
 #pragma unroll
-  for (int j = 0; j < FN / 2; ++j) {
-    const int nl = n0 + wn * (BN / WN) + j * 32 + 8 * g;     // first of this lane's 8 channels (launch-local)
-    if (nl >= d.n_count) continue;
-    const int np = d.n_off + nl;                               // packed row index
-    int co = nl, ua = 0, uc = 0;
-    if (d.up2) { const int tp = np / d.up_cout; co = np - tp * d.up_cout; ua = tp >> 1; uc = tp & 1; }
-    float bv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int bi = d.up2 ? co + e : np + e;
-      bv[e] = (d.bias != nullptr && bi < d.bias_n) ? d.bias[bi] : 0.f;
-    }
-#pragma unroll
-    for (int fm = 0; fm < FM; ++fm) {
-      const int m = wm * (BM / WM) + fm * 16 + lr;
-      const int oy = oy0 + m / TW, ox = ox0 + m % TW;
-      if (oy >= d.Ho || ox >= d.Wo) continue;
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = acc[2 * j][fm][e] + bv[e]; v[4 + e] = acc[2 * j + 1][fm][e] + bv[4 + e]; }
-      if (d.relu) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      const int dy = d.up2 ? 2 * oy + ua : oy, dx = d.up2 ? 2 * ox + uc : ox;
-      if (d.mask.ptr != nullptr) {
-        Vec8<T> mk;
-        mk.load(reinterpret_cast<const T*>(d.mask.ptr) + view_off(d.mask, b, dy, dx) + co);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = mk.get(e) > 0.f ? v[e] : 0.f;
-      }
-      const int64_t doff = view_off(d.dst, b, dy, dx) + co;
-      if (d.out_f32) {
-        Vec8<float> o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o.set(e, v[e]);
-        o.store(reinterpret_cast<float*>(d.dst.ptr) + doff);
-      } else {
-        Vec8<T> o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o.set(e, v[e]);
-        o.store(reinterpret_cast<T*>(d.dst.ptr) + doff);
+  for (int i = 0; i < PPW; ++i) {
+    const int piece = (i * 4 + wave) * 64 + lane;
+    const int q = piece >> 2, h = (piece & 3) ^ ((q >> 1) & 2);          // un-swizzle: which 8 channels land here
+    p_off0[i] = -1; p_off1[i] = -1;
+    if (q < NPIX) {
+      const int py = q / PW, px = q % PW;
+      const int iy = oy0 * S - d.pad_t + py, ix = ox0 * S - d.pad_l + px;
+      if (iy >= 0 && iy < d.Hi && ix >= 0 && ix < d.Wi) {
+        p_off0[i] = ((iy + d.src0.oy) * d.src0.W + ix + d.src0.ox) * d.src0.cs + d.src0.coff + h * 8;
+        p_off1[i] = ((iy + d.src1.oy) * d.src1.W + ix + d.src1.ox) * d.src1.cs + d.src1.coff + h * 8;
       }
     }
   }
+  int w_off[WPW];                               // element offset inside one (tap-major) chunk slab of the packed filters
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int piece = (i * 4 + wave) * 64 + lane;
+    const int rowg = piece >> 2, h = (piece & 3) ^ ((rowg >> 1) & 2);    // rowg = tap*BN + row
+    const int tap = rowg / BN, row = rowg % BN;
+    w_off[i] = (i * 4 + wave < WINST) ? ((tap * P.nchunks) * d.n_total + d.n_off + n0 + row) * 32 + h * 8 : -1;
+  }
+  const T* src0 = reinterpret_cast<const T*>(d.src0.ptr) + (int64_t)b * d.src0.H * d.src0.W * d.src0.cs;
+  const T* src1 = reinterpret_cast<const T*>(d.src1.ptr) + (int64_t)b * d.src1.H * d.src1.W * d.src1.cs;
+  const T* wp = reinterpret_cast<const T*>(d.w_packed);
+
+  auto issue = [&](int c, char* buf) {
+    const bool first = c < P.nchunks0;
+    const T* sb = first ? src0 + c * 32 : src1 + (c - P.nchunks0) * 32;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      if (i * 4 + wave < PINST) {
+        const int off = first ? p_off0[i] : p_off1[i];
+        const void* gp = off >= 0 ? (const void*)(sb + off) : (const void*)g_zero16;
+        glds16(gp, buf + (i * 4 + wave) * 1024);
+      }
+    }
+    const T* wc = wp + (int64_t)c * d.n_total * 32;
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+      if (i * 4 + wave < WINST) glds16(wc + w_off[i], buf + PATCH_BYTES + (i * 4 + wave) * 1024);
+    }
+  };
+
+  int a_addr[FN];
+#pragma unroll
+  for (int fn = 0; fn < FN; ++fn) a_addr[fn] = PATCH_BYTES + frag_addr<T>(wn * (BN / WN) + fn * 16 + lr, g);
+  int b_addr[NT][FM];
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm) {
+    const int m = wm * (BM / WM) + fm * 16 + lr;
+    const int py = (m / TW) * S, px = (m % TW) * S;
+#pragma unroll
+    for (int u = 0; u < KH; ++u)
+#pragma unroll
+      for (int v = 0; v < KW; ++v) b_addr[u * KW + v][fm] = frag_addr<T>((py + u) * PW + px + v, g);
+  }
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = f32x4{0, 0, 0, 0};
+
+  issue(0, smem);
+  for (int c = 0; c < P.nchunks; ++c) {
+    char* cur = smem + (c & 1) * BUF;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of chunk c has landed
+    __syncthreads();                                       // ... everyone's has, and nobody still reads the other buffer
+    if (c + 1 < P.nchunks) issue(c + 1, smem + ((c + 1) & 1) * BUF);
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap) {
+      Frag<T> fa[FN], fb[FM];
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) fa[fn] = lds_read_frag_at<T>(cur + a_addr[fn] + tap * BN * RSTR);
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) fb[fm] = lds_read_frag_at<T>(cur + b_addr[tap][fm]);
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) mma32(acc[fn][fm], fa[fn], fb[fm]);
+    }
+  }
+  conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN>(d, acc, b, oy0, ox0, n0, wm, wn, lr, g);
 }
 
 thread_local char* g_name_out = nullptr;   // when set, launches are dry: only the kernel name is reported
@@ -234,6 +372,33 @@ int launch_cfg(const ConvK& P0, hipStream_t st) {
   return seg_check_launch("conv_fwd");
 }
 
+template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S>
+int launch_glds(const ConvK& P0, hipStream_t st) {
+  if (g_name_out) {
+    snprintf(g_name_out, g_name_cap, "conv_fwd_glds_kernel<%d,%d,%d,%d,%d,%d,%d,%d>", TH, TW, BN, WM, WN, KH, KW, S);
+    return SEG_OK;
+  }
+  constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
+  constexpr int PINST = (PH * PW * 4 + 63) / 64, WINST = KH * KW * BN * 4 / 64;
+  constexpr int LDS = 2 * (PINST + WINST) * 1024;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  ConvK P = P0;
+  P.tiles_x = cdiv(P.d.Wo, TW);
+  P.tiles_y = cdiv(P.d.Ho, TH);
+  if (P.d.n_count % BN != 0) { seg_set_error("conv: n_count %d not a multiple of BN %d", P.d.n_count, BN); return SEG_ERR_ARG; }
+  auto kern = conv_fwd_glds_kernel<TH, TW, BN, WM, WN, KH, KW, S>;
+  static bool attr_done = false;
+  if (!attr_done && LDS > 48 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      seg_set_error("conv: cannot raise dynamic LDS to %d", LDS); return SEG_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  dim3 grid(P.d.B * P.tiles_y * P.tiles_x, P.d.n_count / BN);
+  SEG_LAUNCH(kern, grid, dim3(256), LDS, st, P);
+  return seg_check_launch("conv_fwd_glds");
+}
+
 // padded output area for a tile shape (smaller = less wasted MFMA work)
 inline long waste(int Ho, int Wo, int th, int tw) { return (long)cdiv(Ho, th) * th * cdiv(Wo, tw) * tw; }
 
@@ -246,13 +411,33 @@ int launch_k(const ConvK& P, hipStream_t st) {
     const long w816 = waste(d.Ho, d.Wo, 8, 16), w88 = waste(d.Ho, d.Wo, 8, 8);
     const bool small = w88 < w816;
     cfg = small ? (bn64 ? 3 : 4) : (bn64 ? 1 : 2);
+    if (sizeof(T) == 2) {
+      // bf16: direct-to-LDS double-buffered variants (SEG_CONV_MODE=0 keeps the register-staged ones; 2 also uses
+      // the 256-pixel tile on maps that are at least 32 wide)
+      static const int mode = getenv("SEG_CONV_MODE") ? atoi(getenv("SEG_CONV_MODE")) : 0;
+      if (mode >= 1) cfg += 10;
+      if (mode >= 2 && cfg == 11 && d.Ho >= 32 && d.Wo >= 32) cfg = 15;
+    }
   }
   switch (cfg) {
     case 1: return launch_cfg<T, 8, 16, 64, 4, 1, KH, KW, S>(P, st);   // 128 px x 64 ch
     case 2: return launch_cfg<T, 8, 16, 32, 4, 1, KH, KW, S>(P, st);   // 128 px x 32 ch
     case 3: return launch_cfg<T, 8, 8, 64, 2, 2, KH, KW, S>(P, st);    //  64 px x 64 ch
     case 4: return launch_cfg<T, 8, 8, 32, 4, 1, KH, KW, S>(P, st);    //  64 px x 32 ch
-    default: seg_set_error("conv: unknown cfg %d", cfg); return SEG_ERR_ARG;
+    default: break;
+  }
+  if (sizeof(T) == 2) {
+    switch (cfg) {      // bf16 direct-to-LDS double-buffered variants
+      case 11: return launch_glds<8, 16, 64, 4, 1, KH, KW, S>(P, st);
+      case 12: return launch_glds<8, 16, 32, 4, 1, KH, KW, S>(P, st);
+      case 13: return launch_glds<8, 8, 64, 2, 2, KH, KW, S>(P, st);
+      case 14: return launch_glds<8, 8, 32, 4, 1, KH, KW, S>(P, st);
+      case 15: return launch_glds<16, 16, 64, 4, 1, KH, KW, S>(P, st);  // 256 px x 64 ch
+      default: break;
+    }
+  }
+  {
+    seg_set_error("conv: unknown cfg %d", cfg); return SEG_ERR_ARG;
   }
 }
 

@@ -163,12 +163,34 @@ class Plan(object):
         self.ops.append((name, fn, args))
         self.meta.append(meta)
 
-    def run(self, stream):
+    def run(self, stream, side=None):
+        """Launches every op in order.  Ops tagged side=1 (filter gradients: nothing on the backward critical path
+        consumes them) go round-robin onto the `side` torch streams; each first waits for an event recorded on the
+        main stream at its program position (so everything launched before it is its dependency) and the side
+        streams are joined back into the main stream at the end -- under hipGraph capture this becomes a fork/join."""
         sp = C.c_void_p(stream)
-        for name, fn, args in self.ops:
-            rc = fn(*args, sp)
+        if not side:
+            for name, fn, args in self.ops:
+                rc = fn(*args, sp)
+                if rc != 0:
+                    L.check(rc, '%s/%s' % (self.name, name))
+            return
+        main = torch.cuda.current_stream()
+        used, rr = {}, 0
+        for i, (name, fn, args) in enumerate(self.ops):
+            if self.meta[i].get('side', 0):
+                if not self.meta[i].get('follow', 0):
+                    rr += 1
+                st = side[rr % len(side)]
+                ev = torch.cuda.Event(); ev.record(main); st.wait_event(ev)
+                used[id(st)] = st
+                rc = fn(*args, C.c_void_p(st.cuda_stream))
+            else:
+                rc = fn(*args, sp)
             if rc != 0:
                 L.check(rc, '%s/%s' % (self.name, name))
+        for st in used.values():
+            ev = torch.cuda.Event(); ev.record(st); main.wait_event(ev)
 
     def __len__(self):
         return len(self.ops)
@@ -301,7 +323,7 @@ class Net(object):
         cv = col.view()
         plan.keep.append(cv)
         plan.add(layer.name + '/im2col', self.lib.seg_im2col3x3, x_f32.data_ptr(), self.B, H, W, layer.cin, layer.pad, C.byref(cv), Ho, Wo,
-                 self.dtype, kernel='im2col3x3_kernel')
+                 self.dtype, kernel='im2col3x3_kernel', side=1)
         w = L.WgradDesc()
         w.src0 = col.view(); w.src1 = L.null_view(); w.src0_clog = 9 * layer.cin; w.src1_clog = 0
         w.B, w.Hi, w.Wi = self.B, Ho, Wo
@@ -312,7 +334,7 @@ class Net(object):
         w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
-        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl)
+        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=1, follow=1)
         plan.flops += fl
 
     def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0):
@@ -333,7 +355,7 @@ class Net(object):
         w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
-        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl)
+        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=1)
         plan.flops += fl
         n_off = 0
         for i, ds in enumerate(dsrcs):
@@ -368,7 +390,7 @@ class Net(object):
         w.bias_mode = 2; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
-        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl)
+        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=1)
         plan.flops += fl
         if dsrc is not None:
             d = L.ConvDesc()

@@ -30,6 +30,12 @@ def _rand_params(layer, rng, dtype):
     (3, 'VALID', [32], 64, 13, 15, 2, True, 3),
     (3, 'VALID', [64], 32, 21, 19, 1, True, 2),
     (3, 'VALID', [64], 32, 10, 10, 2, False, 4),
+    (3, 'VALID', [32], 64, 13, 15, 2, True, 11),
+    (3, 'VALID', [64], 32, 21, 19, 1, True, 12),
+    (3, 'VALID', [32], 64, 13, 15, 2, True, 13),
+    (3, 'VALID', [64], 32, 10, 10, 2, False, 14),
+    (3, 'VALID', [64, 32], 64, 35, 37, 2, True, 15),
+    (3, 'SAME', [64], 64, 19, 33, 1, True, 15),
     (3, 'SAME', [64], 96, 9, 11, 2, True, 0),
     (3, 'VALID', [64, 32], 64, 12, 12, 2, True, 0),
     (3, 'VALID', [16], 24, 11, 11, 1, True, 0),          # unpadded channel counts (n_kernels=16 style)
@@ -38,6 +44,8 @@ def _rand_params(layer, rng, dtype):
 ])
 def test_conv_fwd_bwd(dtype, case):
     k, padding, segs, cout, H, W, B, relu, cfg = case
+    if cfg > 10 and dtype != L.SEG_BF16:
+        pytest.skip('direct-to-LDS variants are bf16 only')
     rng = np.random.default_rng(k * 7919 + sum(segs) * 31 + cout * 17 + H * 5 + W + cfg)
     layer = E.Layer('c', 'conv', k, segs, cout, padding, relu)
     p = {'c': _rand_params(layer, rng, dtype)}
