@@ -61,6 +61,7 @@ typedef struct seg_conv_desc {
   int32_t out_f32;         /* store float even when dtype==SEG_BF16 (logits)  */
   int32_t dtype;
   int32_t cfg;             /* 0 = auto tile choice; else forced config id (tuning/tests) */
+  int32_t accum;           /* 1: add to what dst already holds (second consumer of a tensor in backward) */
 } seg_conv_desc;
 
 /* slim.convolution2d / conv2d_transpose fwd, Conv2DBackpropInput: models/unet.py:111-166,

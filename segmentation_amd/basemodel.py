@@ -292,6 +292,38 @@ class BaseModel(object):
         p.run(self._stream())
         torch.cuda.synchronize(self.device)
 
+    def _xavier_init(self, order):
+        """slim defaults: xavier-uniform weights (limit sqrt(6/(fan_in+fan_out)), fans = k*k*C), zero biases; one
+        numpy Generator seeded with self.seed draws the tensors in `order` (graph declaration order)."""
+        rng = np.random.default_rng(self.seed)
+        params = {}
+        for name in order:
+            l = self.store.layers[name]
+            k2 = l.wshape[0] * l.wshape[1]
+            lim = (6.0 / (k2 * l.wshape[2] + k2 * l.wshape[3])) ** 0.5
+            params[name] = {'weights': rng.uniform(-lim, lim, size=l.wshape).astype(np.float32),
+                            'biases': np.zeros((l.cout,), np.float32)}
+        self.store.set_params(params)
+
+    def _repack_initial(self):
+        if getattr(self, 'net', None) is None:
+            self.net = E.Net(self.store, 1, self.dtype, self.device)
+        self._repack()
+
+    def _finish_training_plans(self, segs):
+        """segs: [(plan, arena_end_offset)] in backward order -> bwd_segments / bwd_plan / upd_plan."""
+        self.bwd_segments, lo = [], 0
+        for plan, hi in segs:
+            self.bwd_segments.append((plan, (lo, hi)))
+            lo = hi
+        assert lo == self.store.n
+        self.bwd_plan = E.Plan('bwd')
+        for plan, _ in self.bwd_segments:
+            self.bwd_plan.extend(plan)
+        upd = self.upd_plan = E.Plan('update')
+        self.net.adam(upd, self.learning_rate, grad_scale=1.0 / self.pg.world)
+        self.net.pack(upd)
+
     def set_weights(self, params):
         """Load {scope: {'weights','biases'}} in TF layouts (tests / interchange)."""
         self.store.set_params(params)

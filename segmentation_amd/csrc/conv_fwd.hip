@@ -55,6 +55,12 @@ SEG_DEV void conv_epilogue(const seg_conv_desc& d, f32x4 (&acc)[FN][FM], int b, 
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
       }
       const int dy = d.up2 ? 2 * oy + ua : oy, dx = d.up2 ? 2 * ox + uc : ox;
+      if (d.accum) {
+        Vec8<T> old;
+        old.load(reinterpret_cast<const T*>(d.dst.ptr) + view_off(d.dst, b, dy, dx) + co);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += old.get(e);
+      }
       if (d.mask.ptr != nullptr) {
         Vec8<T> mk;
         mk.load(reinterpret_cast<const T*>(d.mask.ptr) + view_off(d.mask, b, dy, dx) + co);

@@ -360,8 +360,9 @@ class Net(object):
         n_off = 0
         for i, ds in enumerate(dsrcs):
             if ds is not None:
-                dst, doff, mask, moff = ds
+                dst, doff, mask, moff = ds[:4]
                 d = L.ConvDesc()
+                d.accum = 1 if (len(ds) > 4 and ds[4]) else 0
                 d.src0 = dz.view(dz_off[0], dz_off[1]); d.src1 = L.null_view()
                 d.B, d.Hi, d.Wi = self.B, Ho, Wo
                 d.KH = d.KW = k; d.stride = 1; d.pad_t = d.pad_l = k - 1 - pad
@@ -415,6 +416,32 @@ class Net(object):
         plan.keep += [yv, zv, pv, av]
         plan.add('pool/bwd', self.lib.seg_maxpool2x2_bwd, C.byref(yv), C.byref(pv), C.byref(av), add_hw[0], add_hw[1],
                  add_off[0], add_off[1], C.byref(zv), self.B, H, W, y_act.Cp, self.dtype, kernel='maxpool_bwd_kernel')
+
+    def relu_grad(self, plan, dy, y_act, dz, H, W):
+        a, b, c = dy.view(), y_act.view(), dz.view()
+        plan.keep += [a, b, c]
+        plan.add('relu_grad', self.lib.seg_relu_grad, C.byref(a), C.byref(b), C.byref(c), self.B, H, W, y_act.Cp, self.dtype,
+                 kernel='relu_grad_kernel')
+
+    def bilinear_fwd(self, plan, src, Hs, Ws, factor, filt, add, dst, Hd, Wd, dst_f32=False):
+        """dst = crop_or_pad(conv2d_transpose(src, bilinear(factor), SAME), Hd, Wd) (+ add)"""
+        cy = (Hs * factor - Hd) // 2 if Hs * factor >= Hd else -((Hd - Hs * factor) // 2)
+        cx = (Ws * factor - Wd) // 2 if Ws * factor >= Wd else -((Wd - Ws * factor) // 2)
+        sv, dv = src.view(), dst.view()
+        av = add.view() if add is not None else None
+        plan.keep += [sv, dv, av, filt]
+        plan.add('bilinear_up%d' % factor, self.lib.seg_bilinear_up_fwd, C.byref(sv), Hs, Ws, factor, filt.data_ptr(),
+                 C.byref(av) if av is not None else None, C.byref(dv), Hd, Wd, cy, cx, self.B, src.Cp, 1 if dst_f32 else 0, self.dtype,
+                 kernel='bilinear_fwd_kernel')
+        return cy, cx
+
+    def bilinear_bwd(self, plan, ddst, Hd, Wd, factor, filt, dsrc, Hs, Ws):
+        cy = (Hs * factor - Hd) // 2 if Hs * factor >= Hd else -((Hd - Hs * factor) // 2)
+        cx = (Ws * factor - Wd) // 2 if Ws * factor >= Wd else -((Wd - Ws * factor) // 2)
+        gv, sv = ddst.view(), dsrc.view()
+        plan.keep += [gv, sv, filt]
+        plan.add('bilinear_up%d/bwd' % factor, self.lib.seg_bilinear_up_bwd, C.byref(gv), Hd, Wd, cy, cx, factor, filt.data_ptr(),
+                 C.byref(sv), Hs, Ws, self.B, dsrc.Cp, 0, self.dtype, kernel='bilinear_bwd_kernel')
 
     # ---------------- loss / outputs / update ----------------
     def softmax_xent(self, plan, logits, labels_u8, LH, LW, loff, H, W, n_classes, loss_buf, dlogits):

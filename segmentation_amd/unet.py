@@ -111,26 +111,10 @@ class UNetModel(BaseModel):
         self.inference_ops = ['y_hat_sig', 'output']
         self._init_saver(self.model_name)
 
-    # ---- weights: slim defaults (xavier-uniform, zero biases), seeded ----
     def _init_weights(self):
-        import numpy as np
-        rng = np.random.default_rng(self.seed)
-        params = {}
-        order = ['conv1_1', 'conv1_2', 'conv2_1', 'conv2_2', 'conv3_1', 'conv3_2', 'conv4_1', 'conv4_2', 'conv5_1', 'conv5_2',
-                 'upconv1', 'conv6_1', 'conv6_2', 'upconv2', 'conv7_1', 'conv7_2', 'upconv3', 'conv8_1', 'conv8_2',
-                 'upconv4', 'conv9_1', 'conv9_2', 'output']
-        for name in order:
-            l = self.store.layers[name]
-            k2 = l.wshape[0] * l.wshape[1]
-            lim = (6.0 / (k2 * l.wshape[2] + k2 * l.wshape[3])) ** 0.5
-            params[name] = {'weights': rng.uniform(-lim, lim, size=l.wshape).astype(np.float32),
-                            'biases': np.zeros((l.cout,), np.float32)}
-        self.store.set_params(params)
-
-    def _repack_initial(self):
-        if self.net is None:
-            self.net = E.Net(self.store, 1, self.dtype, self.device)
-        self._repack()
+        self._xavier_init(['conv1_1', 'conv1_2', 'conv2_1', 'conv2_2', 'conv3_1', 'conv3_2', 'conv4_1', 'conv4_2', 'conv5_1',
+                           'conv5_2', 'upconv1', 'conv6_1', 'conv6_2', 'upconv2', 'conv7_1', 'conv7_2', 'upconv3', 'conv8_1',
+                           'conv8_2', 'upconv4', 'conv9_1', 'conv9_2', 'output'])
 
     def model(self, input_op=None, reuse=False):
         """The reference's model() declares the TF graph; here the graph is the compiled launch plan."""
@@ -268,18 +252,7 @@ class UNetModel(BaseModel):
         net.first_bwd(seg, Ly['conv1_1'], self.input_x, H, W, G['conv1_1'])
         close_segment('conv1_1')
         self.grads_act = G
-        # segments -> [(plan, (lo, hi))] gradient slices completed by each
-        self.bwd_segments, lo = [], 0
-        for plan, hi in segs:
-            self.bwd_segments.append((plan, (lo, hi)))
-            lo = hi
-        assert lo == self.store.n
-        self.bwd_plan = E.Plan('bwd')
-        for plan, _ in self.bwd_segments:
-            self.bwd_plan.extend(plan)
-        upd = self.upd_plan = E.Plan('update')
-        net.adam(upd, self.learning_rate, grad_scale=1.0 / self.pg.world)
-        net.pack(upd)
+        self._finish_training_plans(segs)
         # training-time outputs (y_hat_sig, output) on demand
         self.y_hat = A['logits']
 
