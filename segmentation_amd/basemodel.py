@@ -122,8 +122,11 @@ class BaseModel(object):
         B, (H, W), Cin = self.batch_size, self.input_dims, self.input_channel
         self.input_x = torch.zeros((B, H, W, Cin), dtype=torch.float32, device=self.device)
         self.input_y = torch.zeros((B, H, W), dtype=torch.uint8, device=self.device)
-        self._pin_x = torch.zeros((B, H, W, Cin), dtype=torch.float32).pin_memory()
-        self._pin_y = torch.zeros((B, H, W), dtype=torch.uint8).pin_memory()
+        # ring of pinned staging buffers drained by async H2D copies on the compute stream; a slot is reused only after
+        # the event recorded behind its copy has completed (the host runs several graph replays ahead of the GPU)
+        self._pin = [[torch.zeros((B, H, W, Cin), dtype=torch.float32).pin_memory(),
+                      torch.zeros((B, H, W), dtype=torch.uint8).pin_memory(), None] for _ in range(3)]
+        self._pin_i = 0
 
     def _init_saver(self, name='model'):
         if self.save_dir is None:
@@ -157,10 +160,16 @@ class BaseModel(object):
             y_dev.copy_(y.reshape(y_dev.shape), non_blocking=True)
             return
         img, mask = dataset.get_batch()
-        self._pin_x.copy_(torch.from_numpy(np.ascontiguousarray(img, np.float32)).reshape(self._pin_x.shape))
-        self._pin_y.copy_(torch.from_numpy(np.ascontiguousarray(mask, np.uint8)).reshape(self._pin_y.shape))
-        x_dev.copy_(self._pin_x, non_blocking=True)
-        y_dev.copy_(self._pin_y, non_blocking=True)
+        slot = self._pin[self._pin_i]
+        self._pin_i = (self._pin_i + 1) % len(self._pin)
+        if slot[2] is not None:
+            slot[2].synchronize()
+        slot[0].copy_(torch.from_numpy(np.ascontiguousarray(img, np.float32)).reshape(slot[0].shape))
+        slot[1].copy_(torch.from_numpy(np.ascontiguousarray(mask, np.uint8)).reshape(slot[1].shape))
+        x_dev.copy_(slot[0], non_blocking=True)
+        y_dev.copy_(slot[1], non_blocking=True)
+        slot[2] = torch.cuda.Event()
+        slot[2].record()
 
     # ------------------------------------------------------------------ hot loop
     def _stream(self):
@@ -205,7 +214,7 @@ class BaseModel(object):
         if self.mode == 'INFERENCE':
             raise Exception('train_step() with INFERENCE mode invalid')
         self._load_batch(self.dataset, self.input_x, self.input_y)
-        if self.pg.world == 1:
+        if not self.pg.enabled:
             self._replay('step', lambda: (self._run_fwd_bwd(), self._run_update()))
         else:
             self._train_step_dp()

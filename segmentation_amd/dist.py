@@ -21,7 +21,7 @@ class DataParallel(object):
         self.pending = []
 
     def all_reduce_bucket(self, flat, lo, hi):
-        if self.world == 1 or hi <= lo:
+        if not self.enabled or hi <= lo:        # world 1 still runs the collective when a group exists (1-GPU RCCL path)
             return
         w = dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if self.overlap:
@@ -35,7 +35,7 @@ class DataParallel(object):
         self.pending = []
 
     def broadcast_(self, flat, src=0):
-        if self.world > 1:
+        if self.enabled and self.world > 1:
             dist.broadcast(flat, src=src, group=self.group)
 
 

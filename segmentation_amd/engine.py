@@ -417,6 +417,14 @@ class Net(object):
         plan.add('pool/bwd', self.lib.seg_maxpool2x2_bwd, C.byref(yv), C.byref(pv), C.byref(av), add_hw[0], add_hw[1],
                  add_off[0], add_off[1], C.byref(zv), self.B, H, W, y_act.Cp, self.dtype, kernel='maxpool_bwd_kernel')
 
+    def dropout(self, plan, act, keep, seed, offset_ref):
+        """In-place slim.dropout-style mask: x * Bernoulli(keep) / keep.  offset_ref is a ctypes c_uint64 whose current
+        value is read at every launch (a fresh mask per stochastic pass without rebuilding the plan)."""
+        v = act.view()
+        plan.keep += [v, offset_ref]
+        plan.add('dropout', self.lib.seg_dropout, C.byref(v), C.byref(v), self.B, act.H, act.W, act.Cp, float(keep), int(seed), offset_ref,
+                 self.dtype, kernel='dropout_kernel')
+
     def relu_grad(self, plan, dy, y_act, dz, H, W):
         a, b, c = dy.view(), y_act.view(), dz.view()
         plan.keep += [a, b, c]

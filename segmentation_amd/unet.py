@@ -11,6 +11,7 @@ offsets); conv1_2 is evaluated only on the window that survives the crop when cr
 (bit-identical results, fewer MACs -- bench.py reports MACs actually executed); ReLU-grad masks are
 fused into the producing dgrad epilogues and the crop-grad zero-pad + add into the max-pool backward.
 """
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -121,7 +122,7 @@ class UNetModel(BaseModel):
         return self.fwd_plan
 
     # ---- forward graph (shared by training and inference builders) ----
-    def _emit_forward(self, net, plan, x_in, H, W, crop_aware):
+    def _emit_forward(self, net, plan, x_in, H, W, crop_aware, dropout=None):
         nk, Ly = self.n_kernels, self.store.layers
         if H != W:
             sh, sw = unet_sizes(H), unet_sizes(W)
@@ -151,6 +152,8 @@ class UNetModel(BaseModel):
             net.conv_fwd(plan, Ly[c1], [(P, 0, 0)], P.H, P.W, A[c1])
             A[c2] = net.act(sh[c2], sw[c2], Ly[c2].cout, name=c2)
             net.conv_fwd(plan, Ly[c2], [(A[c1], 0, 0)], sh[c1], sw[c1], A[c2])
+            if dropout is not None and c2 in dropout['sites']:
+                net.dropout(plan, A[c2], dropout['keep'], dropout['seed'] + i, dropout['offset'])
             prev = A[c2]
         skip_off = {}
         for i, (upn, skip, ca, cb) in enumerate(LEVELS):
@@ -165,6 +168,8 @@ class UNetModel(BaseModel):
             net.conv_fwd(plan, Ly[ca], [(A[skip], off[0], off[1]), (A[upn], 0, 0)], sh[upn], sw[upn], A[ca])
             A[cb] = net.act(sh[cb], sw[cb], Ly[cb].cout, name=cb)
             net.conv_fwd(plan, Ly[cb], [(A[ca], 0, 0)], sh[ca], sw[ca], A[cb])
+            if dropout is not None and cb in dropout['sites']:
+                net.dropout(plan, A[cb], dropout['keep'], dropout['seed'] + 10 + i, dropout['offset'])
             prev = A[cb]
         A['logits'] = net.act(sh['output'], sw['output'], self.n_classes, f32=True, name='logits')
         net.conv_fwd(plan, Ly['output'], [(prev, 0, 0)], prev.H, prev.W, A['logits'], out_f32=True)
@@ -271,3 +276,44 @@ class UNetModel(BaseModel):
         plan.net = net
         plan.acts = A
         return plan, x_in, sig, out
+
+    # ---- Monte-Carlo dropout inference (BASELINE config 5; BUILD-DEFINED, parity unpinned) ----
+    MC_SITES = ('conv2_2', 'conv5_2', 'conv6_2')      # stage-2 encoder, bottleneck, first decoder
+
+    def infer_mc(self, imgs, passes=30, keep_prob=0.5, seed=5555):
+        """The reference U-Net accepts `bayesian` and ignores it; no Kendall-Gal head or dropout exists in it (SURVEY
+        F13).  This method DEFINES the stochastic variant: slim.dropout-style masks x*Bernoulli(keep)/keep, always on,
+        after conv2_2, conv5_2 and conv6_2 (the placement pattern of models/deconvolution.py:128-154), `passes`
+        forward passes with fresh masks; returns [mean sigmoid, variance of sigmoid, float32 argmax of the mean].
+        Every pass recomputes the whole graph (layers ahead of the first dropout are not cached)."""
+        import ctypes as C
+        imgs = np.ascontiguousarray(imgs, np.float32)
+        key = ('mc',) + tuple(imgs.shape) + (keep_prob,)
+        ent = self._infer_cache.get(key)
+        if ent is None:
+            B, H, W, Cin = imgs.shape
+            net = E.Net(self.store, B, self.dtype, self.device)
+            plan = E.Plan('infer_mc')
+            x_in = torch.zeros((B, H, W, Cin), dtype=torch.float32, device=self.device)
+            off = C.c_uint64(0)
+            A, sh, sw, _, _ = self._emit_forward(net, plan, x_in, H, W, self.crop_aware,
+                                                 dropout={'sites': self.MC_SITES, 'keep': keep_prob, 'seed': seed, 'offset': off})
+            oh, ow = sh['output'], sw['output']
+            sig = torch.zeros((B, oh, ow, self.n_classes), dtype=torch.float32, device=self.device)
+            out = torch.zeros((B, oh, ow, 1), dtype=torch.float32, device=self.device)
+            net.sigmoid_argmax(plan, A['logits'], oh, ow, self.n_classes, sig, out)
+            plan.net, plan.acts = net, A
+            ent = (plan, x_in, sig, out, off)
+            self._infer_cache[key] = ent
+        plan, x_in, sig, out, off = ent
+        x_in.copy_(torch.from_numpy(imgs))
+        s1 = torch.zeros_like(sig); s2 = torch.zeros_like(sig)
+        for t in range(passes):
+            off.value = (t + 1) * (1 << 40)              # disjoint counter ranges per pass
+            plan.run(self._stream())
+            s1 += sig; s2 += sig * sig                   # moments of the outputs (post-processing)
+        mean = s1 / passes
+        var = torch.clamp(s2 / passes - mean * mean, min=0)
+        amax = mean.argmax(dim=-1, keepdim=True).to(torch.float32)
+        torch.cuda.synchronize(self.device)
+        return [mean.cpu().numpy(), var.cpu().numpy(), amax.cpu().numpy()]
