@@ -12,6 +12,7 @@
 // (deterministic, no atomics: 768 workgroups hammering one 36 KB filter with f32 atomics measured 10-30x
 // slower than the MFMA work).  The bias gradient rides along as one extra MFMA against an all-ones fragment.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -60,8 +61,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   constexpr int NTF = KH * KW;                // taps of the filter
   constexpr int ES = sizeof(T);
   constexpr int BN = 16 * FCO * WCO;
-  constexpr int RSP = 32 * ES + 16;            // patch row stride (bytes)
-  constexpr int RSZ = BN * ES + 16;            // dZ tile row stride
+  // LDS row strides.  bf16: +32 B of padding and the pixel<->k permutation below make every ds_read_b64_tr_b16
+  // conflict-free (each 32-lane half then reads 8 consecutive pixel rows whose 32-byte chunks fall in 8 distinct
+  // bank groups: 96 B and BN*2+32 B strides are 3 resp. odd multiples of 32 B); f32 (parity mode): +16 B.
+  constexpr int RSP = 32 * ES + (ES == 2 ? 32 : 16);   // patch row stride (bytes)
+  constexpr int RSZ = BN * ES + (ES == 2 ? 32 : 16);   // dZ tile row stride
   constexpr int PPIECES = 32 * ES / 16, ZPIECES = BN * ES / 16, EPP = 16 / ES;
   constexpr int PATCH_BYTES = ((NPIX * RSP + 15) / 16) * 16;
   constexpr int NPP = (NPIX * PPIECES + 255) / 256;
@@ -98,8 +102,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
 
   // bias gradient: mode 1 = column sums of dz (conv; only chunk-0 workgroups), mode 2 = sums of src over
   // pixels and taps (transposed conv, where src is the big dZ map; only nb-0 workgroups)
-  const bool bias1 = d.bias_mode == 1 && chunk == 0 && wci == 0 && u0 == 0;
-  const bool bias2 = d.bias_mode == 2 && nb == 0 && wco == 0;
+  // bias sums are always accumulated (one extra MFMA per K step / per tap for the stride-2 form) and only written
+  // by the workgroups that own them: keeps the MFMA loop free of branches
+  constexpr bool B2 = (S == 2);                 // stride-2 instantiations serve the transposed conv (bias = sums of src)
+  const bool bias1 = !B2 && d.bias_mode == 1 && chunk == 0 && wci == 0 && u0 == 0;
+  const bool bias2 = B2 && d.bias_mode == 2 && nb == 0 && wco == 0;
   f32x4 accb1[FCO], accb2[FCI];
 #pragma unroll
   for (int c = 0; c < FCO; ++c) accb1[c] = f32x4{0, 0, 0, 0};
@@ -107,49 +114,69 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   for (int a = 0; a < FCI; ++a) accb2[a] = f32x4{0, 0, 0, 0};
   const Frag<T> ones = ones_frag<T>();
 
+  // ---- staging: everything that does not depend on the tile is computed once per thread ----
+  // piece i of this thread: patch pixel (py,px) / dZ pixel (ty,tx), 16-byte piece h; element offset relative to the
+  // tile origin and the LDS byte address are tile-invariant.  Interior tiles (the vast majority) take the
+  // unconditional path; edge tiles re-derive the pixel coordinates and zero-fill.
+  int sp_off[NPP], sp_lds[NPP], sz_off[NZP], sz_lds[NZP];
+#pragma unroll
+  for (int i = 0; i < NPP; ++i) {
+    const int idx = tid + i * 256;
+    const int q = idx / PPIECES, h = idx % PPIECES;
+    sp_off[i] = ((q / PW) * sv.W + (q % PW)) * sv.cs + h * EPP;
+    sp_lds[i] = idx < NPIX * PPIECES ? q * RSP + h * 16 : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < NZP; ++i) {
+    const int idx = tid + i * 256;
+    const int m = idx / ZPIECES, h = idx % ZPIECES;
+    sz_off[i] = ((m / TW) * d.dz.W + (m % TW)) * d.dz.cs + h * EPP;
+    sz_lds[i] = (BM * ZPIECES % 256 == 0 || idx < BM * ZPIECES) ? m * RSZ + h * 16 : -1;
+  }
   u32x4 rp[NPP], rz[NZP];
   auto prefetch = [&](int tile) {
     int t = tile;
     const int tx = t % P.tiles_x; t /= P.tiles_x;
     const int ty = t % P.tiles_y; const int b = t / P.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const T* sb = srcp + (int64_t)b * sv.H * sv.W * sv.cs + sv.coff + cbase;
+    const int iy0 = oy0 * S - d.pad_t, ix0 = ox0 * S - d.pad_l;
+    const T* sb = srcp + (int64_t)b * sv.H * sv.W * sv.cs + sv.coff + cbase + ((int64_t)(iy0 + sv.oy) * sv.W + ix0 + sv.ox) * sv.cs;
+    const T* zb = dzp + (int64_t)b * d.dz.H * d.dz.W * d.dz.cs + d.dz.coff + n0 + ((int64_t)(oy0 + d.dz.oy) * d.dz.W + ox0 + d.dz.ox) * d.dz.cs;
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + PH <= d.Hi && ix0 + PW <= d.Wi && oy0 + TH <= d.Ho && ox0 + TW <= d.Wo;
+    if (interior) {
 #pragma unroll
-    for (int i = 0; i < NPP; ++i) {
-      const int idx = tid + i * 256;
-      rp[i] = u32x4{0, 0, 0, 0};
-      if (idx < NPIX * PPIECES) {
-        const int q = idx / PPIECES, h = idx % PPIECES;
-        const int iy = oy0 * S - d.pad_t + q / PW, ix = ox0 * S - d.pad_l + q % PW;
-        if (iy >= 0 && iy < d.Hi && ix >= 0 && ix < d.Wi)
-          rp[i] = *reinterpret_cast<const u32x4*>(sb + ((int64_t)(iy + sv.oy) * sv.W + ix + sv.ox) * sv.cs + h * EPP);
+      for (int i = 0; i < NPP; ++i) {
+        rp[i] = u32x4{0, 0, 0, 0};
+        if (sp_lds[i] >= 0) rp[i] = *reinterpret_cast<const u32x4*>(sb + sp_off[i]);
       }
-    }
-    const T* zb = dzp + (int64_t)b * d.dz.H * d.dz.W * d.dz.cs + d.dz.coff + n0;
 #pragma unroll
-    for (int i = 0; i < NZP; ++i) {
-      const int idx = tid + i * 256;
-      rz[i] = u32x4{0, 0, 0, 0};
-      if (BM * ZPIECES % 256 == 0 || idx < BM * ZPIECES) {
-        const int m = idx / ZPIECES, h = idx % ZPIECES;
-        const int oy = oy0 + m / TW, ox = ox0 + m % TW;
-        if (oy < d.Ho && ox < d.Wo)
-          rz[i] = *reinterpret_cast<const u32x4*>(zb + ((int64_t)(oy + d.dz.oy) * d.dz.W + ox + d.dz.ox) * d.dz.cs + h * EPP);
+      for (int i = 0; i < NZP; ++i) {
+        rz[i] = u32x4{0, 0, 0, 0};
+        if (sz_lds[i] >= 0) rz[i] = *reinterpret_cast<const u32x4*>(zb + sz_off[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPP; ++i) {
+        const int q = (tid + i * 256) / PPIECES;
+        const int iy = iy0 + q / PW, ix = ix0 + q % PW;
+        rp[i] = u32x4{0, 0, 0, 0};
+        if (sp_lds[i] >= 0 && iy >= 0 && iy < d.Hi && ix >= 0 && ix < d.Wi) rp[i] = *reinterpret_cast<const u32x4*>(sb + sp_off[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < NZP; ++i) {
+        const int m = (tid + i * 256) / ZPIECES;
+        rz[i] = u32x4{0, 0, 0, 0};
+        if (sz_lds[i] >= 0 && oy0 + m / TW < d.Ho && ox0 + m % TW < d.Wo) rz[i] = *reinterpret_cast<const u32x4*>(zb + sz_off[i]);
       }
     }
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int i = 0; i < NPP; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < NPIX * PPIECES) *reinterpret_cast<u32x4*>(sP + (idx / PPIECES) * RSP + (idx % PPIECES) * 16) = rp[i];
-    }
+    for (int i = 0; i < NPP; ++i)
+      if (sp_lds[i] >= 0) *reinterpret_cast<u32x4*>(sP + sp_lds[i]) = rp[i];
 #pragma unroll
-    for (int i = 0; i < NZP; ++i) {
-      const int idx = tid + i * 256;
-      if (BM * ZPIECES % 256 == 0 || idx < BM * ZPIECES)
-        *reinterpret_cast<u32x4*>(sZ + (idx / ZPIECES) * RSZ + (idx % ZPIECES) * 16) = rz[i];
-    }
+    for (int i = 0; i < NZP; ++i)
+      if (sz_lds[i] >= 0) *reinterpret_cast<u32x4*>(sZ + sz_lds[i]) = rz[i];
   };
 
   // ---- per-lane fragment addresses ----
@@ -161,7 +188,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
     const int qr = lr >> 2, p = lr & 3;
 #pragma unroll
     for (int e = 0; e < NA; ++e) {
-      const int mloc = BF ? (8 * G + 4 * e + qr) : (8 * G + e);       // pixel within a 32-pixel K step
+      // pixel within a 32-pixel K step that feeds MFMA k-slot (8G + 4e + qr) [bf16] / (8G + e) [f32]; both operands use
+      // the same map, so any bijection is valid -- this one keeps a 32-lane half on 8 consecutive pixels
+      const int mloc = BF ? (16 * (G >> 1) + 8 * e + 4 * (G & 1) + qr) : (8 * G + e);
       za[e] = mloc * RSZ + (BF ? 8 * p : 4 * lr);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -193,26 +222,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
     commit();
     __syncthreads();
     if (tile + P.ksplit < P.ntiles) prefetch(tile + P.ksplit);
+    // Software-pipelined over the flattened (K step, tap) sequence: the transposed LDS reads of step s+1 are issued
+    // before the MFMAs of step s (with one wave per SIMD nothing else hides the ~100-cycle LDS latency; measured:
+    // un-pipelined, the waves sat in s_waitcnt for >50 % of their lifetime).
+    constexpr int NSTEP = KS * NT;
+    Frag<T> fx[2][FCI], fz[2][FCO];
+    const int rs_off = u0 * PW * RSP;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      Frag<T> fz[FCO];
+    for (int c = 0; c < FCO; ++c) fz[0][c] = read_frag(sZ, za, z_ch + c * 16 * ES);
 #pragma unroll
-      for (int c = 0; c < FCO; ++c) fz[c] = read_frag(sZ, za, ks * 32 * RSZ + z_ch + c * 16 * ES);
-      if (bias1) {
+    for (int a = 0; a < FCI; ++a) fx[0][a] = read_frag(sP, pa[0], rs_off + a_ch + a * 16 * ES);
 #pragma unroll
-        for (int c = 0; c < FCO; ++c) mma32(accb1[c], ones, fz[c]);
+    for (int st = 0; st < NSTEP; ++st) {
+      const int ks = st / NT, tap = st % NT;
+      if (st + 1 < NSTEP) {
+        const int ks1 = (st + 1) / NT, tap1 = (st + 1) % NT;
+        if (tap1 == 0) {
+#pragma unroll
+          for (int c = 0; c < FCO; ++c) fz[ks1 & 1][c] = read_frag(sZ, za, ks1 * 32 * RSZ + z_ch + c * 16 * ES);
+        }
+#pragma unroll
+        for (int a = 0; a < FCI; ++a)
+          fx[(st + 1) & 1][a] = read_frag(sP, pa[ks1], rs_off + ((tap1 / KW) * PW + tap1 % KW) * RSP + a_ch + a * 16 * ES);
+      }
+      if (!B2 && tap == 0) {
+#pragma unroll
+        for (int c = 0; c < FCO; ++c) mma32(accb1[c], ones, fz[ks & 1][c]);
       }
 #pragma unroll
-      for (int u = 0; u < NU; ++u)
+      for (int a = 0; a < FCI; ++a) {
 #pragma unroll
-        for (int v = 0; v < KW; ++v)
-#pragma unroll
-          for (int a = 0; a < FCI; ++a) {
-            Frag<T> fx = read_frag(sP, pa[ks], ((u0 + u) * PW + v) * RSP + a_ch + a * 16 * ES);
-#pragma unroll
-            for (int c = 0; c < FCO; ++c) mma32(acc[u * KW + v][a][c], fx, fz[c]);
-            if (bias2) mma32(accb2[a], fx, ones);
-          }
+        for (int c = 0; c < FCO; ++c) mma32(acc[tap][a][c], fx[st & 1][a], fz[ks & 1][c]);
+        if (B2) mma32(accb2[a], fx[st & 1][a], ones);
+      }
     }
   }
 
@@ -358,8 +400,9 @@ template <typename T, int TH, int TW, int KH, int KW, int S, int WCI, int WCO, i
 int launch_cfg(const WgK& P0, hipStream_t st) {
   constexpr int BN = 16 * FCO * WCO, ES = sizeof(T);
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
-  constexpr int PATCH_BYTES = ((PH * PW * (32 * ES + 16) + 15) / 16) * 16;
-  constexpr int LDS = PATCH_BYTES + TH * TW * (BN * ES + 16);
+  constexpr int PADB = ES == 2 ? 32 : 16;
+  constexpr int PATCH_BYTES = ((PH * PW * (32 * ES + PADB) + 15) / 16) * 16;
+  constexpr int LDS = PATCH_BYTES + TH * TW * (BN * ES + PADB);
   WgK P = P0;
   P.tiles_x = cdiv(P.d.Wo, TW); P.tiles_y = cdiv(P.d.Ho, TH);
   P.ntiles = P.d.B * P.tiles_x * P.tiles_y;
@@ -421,7 +464,9 @@ int launch_k(const WgK& P, hipStream_t st) {
   const bool small = (long)cdiv(d.Ho, 8) * 8 * cdiv(d.Wo, 8) * 8 < (long)cdiv(d.Ho, 8) * 8 * cdiv(d.Wo, 16) * 16;
   if (cfg == 0) {
     const int bn = (d.dz.c % 128 == 0) ? 128 : (d.dz.c % 64 == 0 ? 64 : 32);
-    cfg = (bn == 128 ? 1 : bn == 64 ? 2 : 3) + (small ? 3 : 0);
+    static const int bnmax = getenv("SEG_WGRAD_BN") ? atoi(getenv("SEG_WGRAD_BN")) : 64;
+    const int bne = bn > bnmax ? bnmax : bn;
+    cfg = (bne == 128 ? 1 : bne == 64 ? 2 : 3) + (small ? 3 : 0);
   }
   switch (cfg) {
     case 1: return launch_cfg<T, 8, 16, KH, KW, S, 1, 4, 2, 2>(P, st);   // 128 px, 32 ci x 128 co
