@@ -200,17 +200,24 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
     commit();
     __syncthreads();
     if (c + 1 < P.nchunks) prefetch(c + 1);
+    // fragments of tap t+1 are read from LDS before the MFMAs of tap t (explicit software pipeline)
+    Frag<T> fa[2][FN], fb[2][FM];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) fa[0][fn] = lds_read_frag_at<T>(sW + a_addr[fn]);
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) fb[0][fm] = lds_read_frag_at<T>(sP + b_addr[0][fm]);
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
-      Frag<T> fa[FN], fb[FM];
+      if (tap + 1 < NT) {
 #pragma unroll
-      for (int fn = 0; fn < FN; ++fn) fa[fn] = lds_read_frag_at<T>(sW + a_addr[fn] + tap * BN * RSTR);
+        for (int fn = 0; fn < FN; ++fn) fa[(tap + 1) & 1][fn] = lds_read_frag_at<T>(sW + a_addr[fn] + (tap + 1) * BN * RSTR);
 #pragma unroll
-      for (int fm = 0; fm < FM; ++fm) fb[fm] = lds_read_frag_at<T>(sP + b_addr[tap][fm]);
+        for (int fm = 0; fm < FM; ++fm) fb[(tap + 1) & 1][fm] = lds_read_frag_at<T>(sP + b_addr[tap + 1 < NT ? tap + 1 : 0][fm]);
+      }
 #pragma unroll
       for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
-        for (int fm = 0; fm < FM; ++fm) mma32(acc[fn][fm], fa[fn], fb[fm]);
+        for (int fm = 0; fm < FM; ++fm) mma32(acc[fn][fm], fa[tap & 1][fn], fb[tap & 1][fm]);
     }
   }
 
@@ -332,17 +339,24 @@ __global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of chunk c has landed
     __syncthreads();                                       // ... everyone's has, and nobody still reads the other buffer
     if (c + 1 < P.nchunks) issue(c + 1, smem + ((c + 1) & 1) * BUF);
+    // fragments of tap t+1 are read from LDS before the MFMAs of tap t (explicit software pipeline)
+    Frag<T> fa[2][FN], fb[2][FM];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) fa[0][fn] = lds_read_frag_at<T>(cur + a_addr[fn]);
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) fb[0][fm] = lds_read_frag_at<T>(cur + b_addr[0][fm]);
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
-      Frag<T> fa[FN], fb[FM];
+      if (tap + 1 < NT) {
 #pragma unroll
-      for (int fn = 0; fn < FN; ++fn) fa[fn] = lds_read_frag_at<T>(cur + a_addr[fn] + tap * BN * RSTR);
+        for (int fn = 0; fn < FN; ++fn) fa[(tap + 1) & 1][fn] = lds_read_frag_at<T>(cur + a_addr[fn] + (tap + 1) * BN * RSTR);
 #pragma unroll
-      for (int fm = 0; fm < FM; ++fm) fb[fm] = lds_read_frag_at<T>(cur + b_addr[tap][fm]);
+        for (int fm = 0; fm < FM; ++fm) fb[(tap + 1) & 1][fm] = lds_read_frag_at<T>(cur + b_addr[tap + 1 < NT ? tap + 1 : 0][fm]);
+      }
 #pragma unroll
       for (int fn = 0; fn < FN; ++fn)
 #pragma unroll
-        for (int fm = 0; fm < FM; ++fm) mma32(acc[fn][fm], fa[fn], fb[fm]);
+        for (int fm = 0; fm < FM; ++fm) mma32(acc[fn][fm], fa[tap & 1][fn], fb[tap & 1][fm]);
     }
   }
   conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN>(d, acc, b, oy0, ox0, n0, wm, wn, lr, g);
@@ -413,16 +427,25 @@ int launch_k(const ConvK& P, hipStream_t st) {
   const seg_conv_desc& d = P.d;
   int cfg = d.cfg;
   if (cfg == 0) {
-    const bool bn64 = (d.n_count % 64 == 0);
-    const long w816 = waste(d.Ho, d.Wo, 8, 16), w88 = waste(d.Ho, d.Wo, 8, 8);
-    const bool small = w88 < w816;
-    cfg = small ? (bn64 ? 3 : 4) : (bn64 ? 1 : 2);
+    // Tile choice by a two-term cost model calibrated on MI355X micro-benchmarks: a workgroup costs its MACs per
+    // K step (BM*BN) plus a fixed part (prologue, first-load latency, epilogue ~ 5000 MAC-equivalents), and the
+    // grid runs in rounds of 768 resident workgroups (3 per CU).  Small / deep layers therefore prefer the 32-channel
+    // tiles that double the workgroup count; big maps prefer 128x64.
+    static const int TH_[4] = {8, 8, 8, 8}, TW_[4] = {16, 16, 8, 8}, BN_[4] = {64, 32, 64, 32};
+    long best = -1; int bi = 1;
+    for (int c = 0; c < 4; ++c) {
+      if (d.n_count % BN_[c]) continue;
+      const long nwg = (long)d.B * cdiv(d.Ho, TH_[c]) * cdiv(d.Wo, TW_[c]) * (d.n_count / BN_[c]);
+      const long cost = ((nwg + 767) / 768) * ((long)TH_[c] * TW_[c] * BN_[c] + 5000);
+      if (best < 0 || cost < best) { best = cost; bi = c; }
+    }
+    cfg = bi + 1;
     if (sizeof(T) == 2) {
-      // bf16: direct-to-LDS double-buffered variants (SEG_CONV_MODE=0 keeps the register-staged ones; 2 also uses
-      // the 256-pixel tile on maps that are at least 32 wide)
-      static const int mode = getenv("SEG_CONV_MODE") ? atoi(getenv("SEG_CONV_MODE")) : 0;
-      if (mode >= 1) cfg += 10;
-      if (mode >= 2 && cfg == 11 && d.Ho >= 32 && d.Wo >= 32) cfg = 15;
+      // bf16: direct-to-LDS double-buffered variants.  SEG_CONV_MODE: 0 = never, 1 = always, 2 = always + 256-pixel
+      // tile on maps >= 32 wide, 3 (default) = only for the 64-pixel tiles (small LDS footprint, measured faster)
+      static const int mode = getenv("SEG_CONV_MODE") ? atoi(getenv("SEG_CONV_MODE")) : 3;
+      if (mode == 1 || mode == 2 || (mode == 3 && cfg >= 3)) cfg += 10;
+      if (mode == 2 && cfg == 11 && d.Ho >= 32 && d.Wo >= 32) cfg = 15;
     }
   }
   switch (cfg) {

@@ -414,7 +414,8 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
   // of the workgroup tile, so never more than needed and never more than there are tiles.
   const bool rs = KH > 1 && P.d.bias_mode != 2 && P.ntiles <= 64 && base < 192;
   const int wg = base * (rs ? KH : 1);
-  int ks = P.d.ksplit > 0 ? P.d.ksplit : cdiv(256, wg);
+  static const int target_wgs = getenv("SEG_WGRAD_WGS") ? atoi(getenv("SEG_WGRAD_WGS")) : 256;
+  int ks = P.d.ksplit > 0 ? P.d.ksplit : cdiv(target_wgs, wg);
   if (ks > P.ntiles) ks = P.ntiles;
   if (ks < 1) ks = 1;
   P.ksplit = ks;
