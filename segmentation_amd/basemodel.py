@@ -179,7 +179,7 @@ class BaseModel(object):
         s = self._stream()
         self.store.g.zero_()
         self.loss_buf.zero_()
-        self.fwd_plan.run(s)
+        self.fwd_plan.run(s, self._side)
         self.bwd_plan.run(s, self._side)
 
     def _run_update(self):
@@ -229,7 +229,7 @@ class BaseModel(object):
 
         def head():
             self.store.g.zero_(); self.loss_buf.zero_()
-            self.fwd_plan.run(self._stream())
+            self.fwd_plan.run(self._stream(), self._side)
             self.bwd_segments[0][0].run(self._stream(), self._side)
         self._replay('dp0', head)
         self.pg.all_reduce_bucket(self.store.g, *self.bwd_segments[0][1])

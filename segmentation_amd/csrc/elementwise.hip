@@ -186,7 +186,7 @@ __global__ void dropout_kernel(seg_view xin, seg_view yout, int B, int H, int W,
 // ------------------------------------------------------------------------------------------
 // softmax cross-entropy (+grad) and sigmoid/argmax
 // ------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NCP>     // NCP = classes rounded up to 4/8/16/32: bounds every unrolled loop
 __global__ void softmax_xent_kernel(seg_view lg, const uint8_t* labels, int LH, int LW, int ly0, int lx0, int B, int H, int W,
                                     int nc, float inv_n, float gscale, float* loss_sum, seg_view dl) {
   const int64_t total = (int64_t)B * H * W;
@@ -197,13 +197,13 @@ __global__ void softmax_xent_kernel(seg_view lg, const uint8_t* labels, int LH, 
     const int y = t % H; const int b = t / H;
     const float* z = reinterpret_cast<const float*>(lg.ptr) + view_off(lg, b, y, x);
     const int lab = labels[((int64_t)b * LH + y + ly0) * LW + x + lx0];
-    float zv[32];
+    float zv[NCP];
     float m = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) { zv[c] = c < nc ? z[c] : -INFINITY; m = fmaxf(m, zv[c]); }
+    for (int c = 0; c < NCP; ++c) { zv[c] = c < nc ? z[c] : -INFINITY; m = fmaxf(m, zv[c]); }
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) { zv[c] = c < nc ? expf(zv[c] - m) : 0.f; s += zv[c]; }
+    for (int c = 0; c < NCP; ++c) { zv[c] = c < nc ? expf(zv[c] - m) : 0.f; s += zv[c]; }
     const bool valid = lab < nc;
     const float logs = logf(s);
     const float zl = valid ? z[lab] : 0.f;
@@ -217,14 +217,19 @@ __global__ void softmax_xent_kernel(seg_view lg, const uint8_t* labels, int LH, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int c = c8 * 8 + e;
-        const float gv = (c < nc && valid) ? (zv[c] * rs - (c == lab ? 1.f : 0.f)) * k : 0.f;
+        float gv = 0.f;
+        if (c < NCP) gv = (c < nc && valid) ? (zv[c < NCP ? c : 0] * rs - (c == lab ? 1.f : 0.f)) * k : 0.f;
         ov.set(e, gv);
       }
       ov.store(o + c8 * 8);
     }
   }
+  // one atomic per block (hundreds of waves adding to one address serialise at the memory side: ~20 us measured)
+  __shared__ float wsum[4];
   local = wave_sum(local);
-  if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, local * inv_n);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss_sum, (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_n);
 }
 
 __global__ void sigmoid_argmax_kernel(seg_view lg, int B, int H, int W, int nc, float* sig, float* out) {
@@ -327,10 +332,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void pack_kernel(const float* arena, T* packed, const seg_pack_entry* tab, int n_entries) {
   __shared__ int s_e;
   __shared__ float tile[32][33];
-  if (threadIdx.x == 0) {
-    int lo = 0;
-    for (int i = 0; i < n_entries; ++i) if ((int64_t)blockIdx.x >= tab[i].blk_start) lo = i;
-    s_e = lo;
+  if (threadIdx.x < 64) {
+    // entries are sorted by blk_start: the owner is (number of entries starting at or before this block) - 1.
+    // One wave tests 64 entries per pass in parallel (a serial scan by one lane cost ~4 us of latency per block).
+    int cnt = 0;
+    for (int base = 0; base < n_entries; base += 64) {
+      const int i = base + threadIdx.x;
+      const bool le = i < n_entries && (int64_t)blockIdx.x >= tab[i].blk_start;
+      cnt += __popcll(__ballot(le));
+    }
+    if (threadIdx.x == 0) s_e = cnt - 1;
   }
   __syncthreads();
   const seg_pack_entry e = tab[s_e];
@@ -367,12 +378,15 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* arena, T* packed
   }
   __syncthreads();
   T* dst = packed + e.dst_off + (((int64_t)tap * nch + chunk) * e.n_total + nb * 32) * 32;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = threadIdx.x + i * 256;
-    const int kk = idx & 31, pos = idx >> 5;                             // packed row position inside the 32-block
+  // 16-byte stores: 8 consecutive k of one packed row per thread (bf16: 128 threads cover the tile; f32: two passes)
+  constexpr int EPT = 8;
+  for (int idx = threadIdx.x; idx < 1024 / EPT; idx += 256) {
+    const int pos = idx >> 2, kk0 = (idx & 3) * EPT;                    // packed row position, first k
     const int nn = (((pos >> 2) & 3) << 3) | (((pos >> 4) & 1) << 2) | (pos & 3);   // -> logical row
-    dst[pos * 32 + kk] = from_f32<T>(tile[nn][kk]);
+    Vec8<T> o;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) o.set(j, tile[nn][kk0 + j]);
+    o.store(dst + pos * 32 + kk0);
   }
 }
 
@@ -515,9 +529,15 @@ extern "C" int seg_softmax_xent(const seg_view* logits, const uint8_t* labels, i
   if (n_classes < 1 || n_classes > 32 || n_classes > dlogits->c || dlogits->c % 8 || dlogits->c > 32) { seg_set_error("softmax_xent: n_classes %d unsupported (1..32)", n_classes); return SEG_ERR_UNSUPPORTED; }
   if (ly0 < 0 || lx0 < 0 || ly0 + H > LH || lx0 + W > LW) { seg_set_error("softmax_xent: label window out of range"); return SEG_ERR_ARG; }
   const int64_t n = (int64_t)B * H * W;
-  DISPATCH(dtype,
-           SEG_LAUNCH(softmax_xent_kernel<float>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, ST(stream), *logits, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, grad_scale, loss_sum, *dlogits),
-           SEG_LAUNCH(softmax_xent_kernel<bf16_t>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, ST(stream), *logits, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, grad_scale, loss_sum, *dlogits));
+  const int g = grid_for(n, 256, 256);
+#define XENT_ARGS dim3(g), dim3(256), 0, ST(stream), *logits, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, grad_scale, loss_sum, *dlogits
+#define XENT_NCP(TT) do { if (n_classes <= 4) SEG_LAUNCH((softmax_xent_kernel<TT, 4>), XENT_ARGS); \
+    else if (n_classes <= 8) SEG_LAUNCH((softmax_xent_kernel<TT, 8>), XENT_ARGS); \
+    else if (n_classes <= 16) SEG_LAUNCH((softmax_xent_kernel<TT, 16>), XENT_ARGS); \
+    else SEG_LAUNCH((softmax_xent_kernel<TT, 32>), XENT_ARGS); } while (0)
+  DISPATCH(dtype, XENT_NCP(float), XENT_NCP(bf16_t));
+#undef XENT_NCP
+#undef XENT_ARGS
   return seg_check_launch("softmax_xent");
 }
 

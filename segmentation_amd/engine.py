@@ -313,9 +313,9 @@ class Net(object):
         self.ws_bytes = getattr(self, 'ws_bytes', 0) + nbytes.value
         plan.keep += [w, ws]
 
-    def first_bwd(self, plan, layer, x_f32, H, W, dz):
-        """First-layer filter/bias gradient: im2col of the raw input (27 -> 32 channels) + the generic 1x1 MFMA wgrad;
-        the [1][9*cin][cout] result is exactly the HWIO filter gradient."""
+    def first_im2col(self, plan, layer, x_f32, H, W):
+        """im2col of the raw input (27 -> 32 channels) for the first layer's filter gradient.  It depends only on the
+        input batch, so the models emit it at the START of the forward plan on a side stream (off the critical path)."""
         Ho, Wo = H + 2 * layer.pad - 2, W + 2 * layer.pad - 2
         if layer.cin > 3:
             raise L.SegError('first-layer gradient supports input_channel <= 3')
@@ -324,6 +324,14 @@ class Net(object):
         plan.keep.append(cv)
         plan.add(layer.name + '/im2col', self.lib.seg_im2col3x3, x_f32.data_ptr(), self.B, H, W, layer.cin, layer.pad, C.byref(cv), Ho, Wo,
                  self.dtype, kernel='im2col3x3_kernel', side=1)
+        return col
+
+    def first_bwd(self, plan, layer, x_f32, H, W, dz, col=None):
+        """First-layer filter/bias gradient = the generic 1x1 MFMA wgrad over the im2col'd input; the [1][9*cin][cout]
+        result is exactly the HWIO filter gradient."""
+        Ho, Wo = H + 2 * layer.pad - 2, W + 2 * layer.pad - 2
+        if col is None:
+            col = self.first_im2col(plan, layer, x_f32, H, W)
         w = L.WgradDesc()
         w.src0 = col.view(); w.src1 = L.null_view(); w.src0_clog = 9 * layer.cin; w.src1_clog = 0
         w.B, w.Hi, w.Wi = self.B, Ho, Wo
@@ -334,7 +342,7 @@ class Net(object):
         w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
-        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=1, follow=1)
+        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=1)
         plan.flops += fl
 
     def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0):

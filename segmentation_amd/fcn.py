@@ -156,6 +156,7 @@ class FCNModel(BaseModel):
         net = self.net = E.Net(self.store, B, self.dtype, self.device)
         Ly, nc = self.store.layers, self.n_classes
         fwd = self.fwd_plan = E.Plan('fwd')
+        col = net.first_im2col(fwd, Ly['conv1'], self.input_x, H, W)         # side stream, overlaps the forward pass
         A, geo = self._emit_forward(net, fwd, self.input_x, H, W)
         self.acts = A
         self.out_hw = (H, W)
@@ -214,7 +215,7 @@ class FCNModel(BaseModel):
             dz = act_like(a, 'dz_' + name)
             net.pool_bwd(seg, a, dP[i], None, (0, 0), (0, 0), dz, a.H, a.W)
             if i == 1:
-                net.first_bwd(seg, Ly[name], self.input_x, H, W, dz)
+                net.first_bwd(seg, Ly[name], self.input_x, H, W, dz, col=col)
                 break
             pin = A['pool%d' % (i - 1)]
             # pool4 / pool3 already hold the score-branch gradient: the encoder path accumulates onto it
