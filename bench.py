@@ -35,6 +35,8 @@ def parse():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--classes', type=int, default=4)
     ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--model', default='unet', choices=['unet', 'fcn8s'], help='fcn8s = BASELINE config 3 (use --size 512 --classes 21 --batch 8)')
+    ap.add_argument('--nk', type=int, default=32, help='n_kernels')
     ap.add_argument('--dense', action='store_true', help='evaluate conv1_2 densely (no crop-aware window)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -112,9 +114,15 @@ def main():
     from segmentation_amd.unet import UNetModel
 
     ds = SyntheticDataSet(args.batch, args.size, args.classes, seed=5555 + rank, n_batches=2)
-    model = UNetModel(sess=None, dataset=ds, n_classes=args.classes, input_dims=args.size, learning_rate=1e-4,
-                      log_dir=None, save_dir=None, load_snapshot=False, n_kernels=32,
-                      dtype=args.dtype, use_graph=not args.no_graph, crop_aware=not args.dense, seed=5555)
+    if args.model == 'unet':
+        model = UNetModel(sess=None, dataset=ds, n_classes=args.classes, input_dims=args.size, learning_rate=1e-4,
+                          log_dir=None, save_dir=None, load_snapshot=False, n_kernels=args.nk,
+                          dtype=args.dtype, use_graph=not args.no_graph, crop_aware=not args.dense, seed=5555)
+    else:
+        from segmentation_amd.fcn import FCNModel
+        model = FCNModel(sess=None, dataset=ds, n_classes=args.classes, input_dims=args.size, learning_rate=1e-4, fcn_type='8s',
+                         log_dir=None, save_dir=None, load_snapshot=False, n_kernels=args.nk, dtype=args.dtype,
+                         use_graph=not args.no_graph, seed=5555)
     if world > 1:
         model.pg.broadcast_(model.store.p)          # identical replicas (same seed anyway)
         model._repack()
@@ -146,10 +154,10 @@ def main():
             'metric': 'train-step images/sec', 'value': round(world * args.batch * args.steps / dt, 2), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'U-Net %dx%dx3 %d-class batch=%d/GPU %s train step (fwd+xent+bwd+Adam+repack), n_kernels=32'
-                                   % (args.size, args.size, args.classes, args.batch, args.dtype),
+            'config': {'workload': '%s %dx%dx3 %d-class batch=%d/GPU %s train step (fwd+xent+bwd+Adam+repack), n_kernels=%d'
+                                   % ('U-Net' if args.model == 'unet' else 'FCN-8s', args.size, args.size, args.classes, args.batch, args.dtype, args.nk),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
-                       'conv1_2': 'dense' if args.dense else 'crop-aware (only the 72x72 window that survives the skip crop)',
+                       'conv1_2': 'dense' if args.dense else 'crop-aware (only the window that survives the last skip crop is computed)',
                        'hip_graph': not args.no_graph,
                        'executed_gflop_per_step_per_gpu': round(flops_step / 1e9, 2),
                        'step_tflops_per_gpu': round(flops_step / (ms * 1e-3) / 1e12, 2),
