@@ -415,7 +415,27 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
   const bool rs = KH > 1 && P.d.bias_mode != 2 && P.ntiles <= 64 && base < 192;
   const int wg = base * (rs ? KH : 1);
   static const int target_wgs = getenv("SEG_WGRAD_WGS") ? atoi(getenv("SEG_WGRAD_WGS")) : 256;
+  auto k0 = conv_wgrad_kernel<T, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, 0>;
+  auto k1 = conv_wgrad_kernel<T, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, (KH > 1 ? 1 : 0)>;
+  static int occ = 0;                      // resident workgroups per CU of this instance
+  if (occ == 0) {
+    if (LDS > 48 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    }
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k0), 256, LDS) != hipSuccess || nb < 1) nb = 1;
+    occ = nb > 4 ? 4 : nb;
+  }
+  // small filters (<= 64 KB of partial sums per workgroup) are cheap to split: fill every resident slot of the chip
+  const int64_t wg_tile_bytes = (int64_t)KH * KW * 32 * BN * 4;
   int ks = P.d.ksplit > 0 ? P.d.ksplit : cdiv(target_wgs, wg);
+  if (P.d.ksplit <= 0 && wg_tile_bytes <= 64 * 1024 && P.ntiles / ks > 8) {
+    // long serial tile walks (first layer: 31 tiles per workgroup): use every resident slot, keep >= 8 tiles each
+    int ks2 = cdiv(target_wgs * occ, wg);
+    if (ks2 > P.ntiles / 8) ks2 = P.ntiles / 8;
+    if (ks2 > ks) ks = ks2;
+  }
   if (ks > P.ntiles) ks = P.ntiles;
   if (ks < 1) ks = 1;
   P.ksplit = ks;
@@ -429,16 +449,6 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
   }
   if (g_plan_ks) { *g_plan_ks = ks; *g_plan_bytes = P.direct ? 0 : P.slab * ks * 4; return SEG_OK; }
   if (!P.direct && (!P.d.ws || P.d.ws_bytes < P.slab * ks * 4)) { seg_set_error("wgrad: workspace too small (%lld < %lld bytes)", (long long)P.d.ws_bytes, (long long)(P.slab * ks * 4)); return SEG_ERR_ARG; }
-  auto k0 = conv_wgrad_kernel<T, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, 0>;
-  auto k1 = conv_wgrad_kernel<T, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, (KH > 1 ? 1 : 0)>;
-  static bool attr_done = false;
-  if (!attr_done && LDS > 48 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-      seg_set_error("wgrad: cannot raise dynamic LDS to %d", LDS); return SEG_ERR_LAUNCH;
-    }
-    attr_done = true;
-  }
   if (rs) SEG_LAUNCH(k1, dim3(base, ks, KH), dim3(256), LDS, st, P);
   else SEG_LAUNCH(k0, dim3(base, ks, 1), dim3(256), LDS, st, P);
   int rc = seg_check_launch("conv_wgrad");

@@ -122,7 +122,7 @@ class UNetModel(BaseModel):
         return self.fwd_plan
 
     # ---- forward graph (shared by training and inference builders) ----
-    def _emit_forward(self, net, plan, x_in, H, W, crop_aware, dropout=None):
+    def _emit_forward(self, net, plan, x_in, H, W, crop_aware, dropout=None, after_first=None):
         nk, Ly = self.n_kernels, self.store.layers
         if H != W:
             sh, sw = unet_sizes(H), unet_sizes(W)
@@ -131,6 +131,8 @@ class UNetModel(BaseModel):
         A = {}
         A['conv1_1'] = net.act(sh['conv1_1'], sw['conv1_1'], nk, name='conv1_1')
         net.first_fwd(plan, Ly['conv1_1'], x_in, H, W, A['conv1_1'])
+        if after_first is not None:
+            after_first()
         # conv1_2: only its centre window survives the crop of the last skip
         t4h, t4w = sh['upconv4'], sw['upconv4']
         o4h, o4w = (sh['conv1_2'] - t4h) // 2, (sw['conv1_2'] - t4w) // 2
@@ -181,8 +183,11 @@ class UNetModel(BaseModel):
         net = self.net = E.Net(self.store, B, self.dtype, self.device)
         Ly = self.store.layers
         fwd = self.fwd_plan = E.Plan('fwd')
-        col = net.first_im2col(fwd, Ly['conv1_1'], self.input_x, H, W)       # side stream, overlaps the forward pass
-        A, sh, sw, skip_off, o4 = self._emit_forward(net, fwd, self.input_x, H, W, self.crop_aware)
+        cols = []       # im2col of the input for conv1_1's filter gradient: side stream, right after conv1_1 (both are
+        #                 bandwidth-bound), overlapping the rest of the forward pass
+        A, sh, sw, skip_off, o4 = self._emit_forward(net, fwd, self.input_x, H, W, self.crop_aware,
+                                                     after_first=lambda: cols.append(net.first_im2col(fwd, Ly['conv1_1'], self.input_x, H, W)))
+        col = cols[0]
         self.acts = A
         oh, ow = sh['output'], sw['output']
         self.out_hw = (oh, ow)
