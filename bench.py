@@ -52,7 +52,7 @@ def kernel_table(model, reps=5):
     agg = {}
     ops = []
     for rep in range(reps + 1):
-        model.store.g.zero_(); model.loss_buf.zero_()
+        model.loss_buf.zero_()
         rows = []
         for plan in (model.fwd_plan, model.bwd_plan, model.upd_plan):
             rows += plan.run_profiled(stream, torch)

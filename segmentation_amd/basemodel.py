@@ -88,7 +88,9 @@ class BaseModel(object):
         self.seed = seed
         self.pg = D.DataParallel(process_group, overlap=overlap_allreduce)
         self._graphs = {}
-        self._side = [torch.cuda.Stream(self.device) for _ in range(wgrad_streams)] if wgrad_streams > 0 else None
+        # side streams: wgrad_streams for the filter gradients + one auxiliary (weight re-pack)
+        self._side = [torch.cuda.Stream(self.device) for _ in range(wgrad_streams + 1)] if wgrad_streams > 0 else None
+        self._packed_dirty = False
         self._infer_cache = {}
         self.sess = sess
         self._gs_host = 0
@@ -177,13 +179,13 @@ class BaseModel(object):
 
     def _run_fwd_bwd(self):
         s = self._stream()
-        self.store.g.zero_()
-        self.loss_buf.zero_()
+        self.loss_buf.zero_()              # gradients need no zeroing: every entry is overwritten by its wgrad launch
         self.fwd_plan.run(s, self._side)
         self.bwd_plan.run(s, self._side)
 
     def _run_update(self):
         self.upd_plan.run(self._stream())
+        self._packed_dirty = True          # the packed copy is refreshed by the next forward (or lazily by infer())
 
     def _replay(self, key, fn):
         """Runs fn eagerly once (warm-up), then captures it into a hipGraph and replays the graph."""
@@ -228,7 +230,7 @@ class BaseModel(object):
         s = self._stream()
 
         def head():
-            self.store.g.zero_(); self.loss_buf.zero_()
+            self.loss_buf.zero_()
             self.fwd_plan.run(self._stream(), self._side)
             self.bwd_segments[0][0].run(self._stream(), self._side)
         self._replay('dp0', head)
@@ -296,6 +298,7 @@ class BaseModel(object):
         self._repack()
 
     def _repack(self):
+        self._packed_dirty = False
         p = E.Plan('pack')
         self.net.pack(p)
         p.run(self._stream())
@@ -331,7 +334,7 @@ class BaseModel(object):
             self.bwd_plan.extend(plan)
         upd = self.upd_plan = E.Plan('update')
         self.net.adam(upd, self.learning_rate, grad_scale=1.0 / self.pg.world)
-        self.net.pack(upd)
+        # the re-pack of the updated weights is the first op of the next forward plan (aux stream)
 
     def set_weights(self, params):
         """Load {scope: {'weights','biases'}} in TF layouts (tests / interchange)."""
@@ -343,6 +346,8 @@ class BaseModel(object):
         """imgs: float32 ndarray [B,H,W,C] -> [sigmoid(logits) [B,h,w,n_classes], float32 argmax [B,h,w,1]]
         (models/basemodel.py:527-531; inference_ops of models/unet.py:75-79)."""
         imgs = np.ascontiguousarray(imgs, np.float32)
+        if self._packed_dirty:
+            self._repack()
         key = tuple(imgs.shape)
         ent = self._infer_cache.get(key)
         if ent is None:

@@ -171,17 +171,31 @@ class Plan(object):
         sp = C.c_void_p(stream)
         if not side:
             for name, fn, args in self.ops:
+                if fn is None:
+                    continue
                 rc = fn(*args, sp)
                 if rc != 0:
                     L.check(rc, '%s/%s' % (self.name, name))
             return
         main = torch.cuda.current_stream()
         used, rr = {}, 0
+        aux = side[-1]                   # dedicated stream for side='aux' ops (weight re-pack), joined by a 'join_aux' marker
+        aux_used = False
         for i, (name, fn, args) in enumerate(self.ops):
-            if self.meta[i].get('side', 0):
+            tag = self.meta[i].get('side', 0)
+            if fn is None:               # marker: make the main stream wait for the aux stream
+                if aux_used:
+                    ev = torch.cuda.Event(); ev.record(aux); main.wait_event(ev)
+                    aux_used = False
+                continue
+            if tag == 'aux':
+                ev = torch.cuda.Event(); ev.record(main); aux.wait_event(ev)
+                aux_used = True
+                rc = fn(*args, C.c_void_p(aux.cuda_stream))
+            elif tag:
                 if not self.meta[i].get('follow', 0):
                     rr += 1
-                st = side[rr % len(side)]
+                st = side[rr % (len(side) - 1)] if len(side) > 1 else side[0]
                 ev = torch.cuda.Event(); ev.record(main); st.wait_event(ev)
                 used[id(st)] = st
                 rc = fn(*args, C.c_void_p(st.cuda_stream))
@@ -189,6 +203,8 @@ class Plan(object):
                 rc = fn(*args, sp)
             if rc != 0:
                 L.check(rc, '%s/%s' % (self.name, name))
+        if aux_used:
+            used[id(aux)] = aux
         for st in used.values():
             ev = torch.cuda.Event(); ev.record(st); main.wait_event(ev)
 
@@ -208,7 +224,7 @@ class Plan(object):
             q = lib.seg_conv2d_kernel_name if isinstance(d, L.ConvDesc) else lib.seg_conv2d_wgrad_kernel_name
             L.check(q(C.byref(d), buf, 160), 'kernel_name')
             return buf.value.decode()
-        return self.meta[i].get('kernel', fn.__name__)
+        return self.meta[i].get('kernel', fn.__name__ if fn is not None else 'marker')
 
     def run_profiled(self, stream, torch_mod):
         """Eager run with a HIP event between consecutive launches on `stream` (the stream the kernels
@@ -217,9 +233,10 @@ class Plan(object):
         evs = [torch_mod.cuda.Event(enable_timing=True) for _ in range(len(self.ops) + 1)]
         evs[0].record()
         for i, (name, fn, args) in enumerate(self.ops):
-            rc = fn(*args, sp)
-            if rc != 0:
-                L.check(rc, '%s/%s' % (self.name, name))
+            if fn is not None:
+                rc = fn(*args, sp)
+                if rc != 0:
+                    L.check(rc, '%s/%s' % (self.name, name))
             evs[i + 1].record()
         torch_mod.cuda.synchronize()
         return [(self.ops[i][0], self.kernel_name(i), evs[i].elapsed_time(evs[i + 1]), self.meta[i].get('flops', 0))
@@ -472,12 +489,21 @@ class Net(object):
         plan.keep.append(lv)
         plan.add('sigmoid_argmax', self.lib.seg_sigmoid_argmax, C.byref(lv), self.B, H, W, n_classes, sig.data_ptr(), out.data_ptr(), kernel='sigmoid_argmax_kernel')
 
-    def pack(self, plan):
+    def pack(self, plan, aux=False):
+        """Re-packs the fp32 master weights into the MFMA operand layout.  aux=True: on the auxiliary stream (the
+        training forward starts with it, overlapped with the first layer, which reads the fp32 arena directly)."""
         s = self.store
         if s.pack_table is None:
             return
+        meta = {'kernel': 'pack_kernel'}
+        if aux:
+            meta['side'] = 'aux'
         plan.add('pack', self.lib.seg_pack_weights, s.p.data_ptr(), s.packed.data_ptr(), s.pack_table.data_ptr(),
-                 s.n_pack_entries, s.pack_blocks, self.dtype, kernel='pack_kernel')
+                 s.n_pack_entries, s.pack_blocks, self.dtype, **meta)
+
+    def join_aux(self, plan):
+        plan.ops.append(('join_aux', None, ()))
+        plan.meta.append({'kernel': 'marker'})
 
     def adam(self, plan, lr, grad_scale=1.0, b1=0.9, b2=0.999, eps=1e-8):
         s = self.store

@@ -109,6 +109,7 @@ class FCNModel(BaseModel):
             A[name] = net.act(h, w, Ly[name].cout, name=name)
             if i == 0:
                 net.first_fwd(plan, Ly[name], x_in, H, W, A[name])
+                net.join_aux(plan)         # packed weights needed from here on
             else:
                 net.conv_fwd(plan, Ly[name], [(prev, 0, 0)], h, w, A[name])
             h, w = h // 2, w // 2
@@ -156,6 +157,7 @@ class FCNModel(BaseModel):
         net = self.net = E.Net(self.store, B, self.dtype, self.device)
         Ly, nc = self.store.layers, self.n_classes
         fwd = self.fwd_plan = E.Plan('fwd')
+        net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1
         col = net.first_im2col(fwd, Ly['conv1'], self.input_x, H, W)         # side stream, overlaps the forward pass
         A, geo = self._emit_forward(net, fwd, self.input_x, H, W)
         self.acts = A

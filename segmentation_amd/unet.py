@@ -133,6 +133,7 @@ class UNetModel(BaseModel):
         net.first_fwd(plan, Ly['conv1_1'], x_in, H, W, A['conv1_1'])
         if after_first is not None:
             after_first()
+        net.join_aux(plan)                 # packed weights (re-packed on the aux stream in training) are needed from here on
         # conv1_2: only its centre window survives the crop of the last skip
         t4h, t4w = sh['upconv4'], sw['upconv4']
         o4h, o4w = (sh['conv1_2'] - t4h) // 2, (sw['conv1_2'] - t4w) // 2
@@ -183,6 +184,7 @@ class UNetModel(BaseModel):
         net = self.net = E.Net(self.store, B, self.dtype, self.device)
         Ly = self.store.layers
         fwd = self.fwd_plan = E.Plan('fwd')
+        net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1_1
         cols = []       # im2col of the input for conv1_1's filter gradient: side stream, right after conv1_1 (both are
         #                 bandwidth-bound), overlapping the rest of the forward pass
         A, sh, sw, skip_off, o4 = self._emit_forward(net, fwd, self.input_x, H, W, self.crop_aware,
@@ -294,6 +296,8 @@ class UNetModel(BaseModel):
         Every pass recomputes the whole graph (layers ahead of the first dropout are not cached)."""
         import ctypes as C
         imgs = np.ascontiguousarray(imgs, np.float32)
+        if self._packed_dirty:
+            self._repack()
         key = ('mc',) + tuple(imgs.shape) + (keep_prob,)
         ent = self._infer_cache.get(key)
         if ent is None:

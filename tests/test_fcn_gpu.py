@@ -31,8 +31,10 @@ def test_fcn_f32_parity(fcn_type):
         p[n]['biases'] = (np.random.default_rng(3).standard_normal(p[n]['biases'].shape) * 0.05 + 0.05).astype(np.float32)
     m.set_weights(p)
     m._load_batch(m.dataset, m.input_x, m.input_y)
+    m.store.g.fill_(float('nan'))
     m._run_fwd_bwd()
     torch.cuda.synchronize()
+    assert bool(torch.isfinite(m.store.g).all())
     loss_ref, g_ref, c = ofcn.loss_and_grads(p, x[0], y[0], fcn_type)
     logits = m.acts['logits'].t[..., :nc].cpu().numpy()
     assert logits.shape == (B, S, S, nc)

@@ -47,8 +47,10 @@ def test_unet_f32_forward_backward_parity(crop_aware):
     p = m.store.get_params()
     assert sum(v['weights'].size + v['biases'].size for v in p.values()) == 7760130
     m._load_batch(m.dataset, m.input_x, m.input_y)
+    m.store.g.fill_(float('nan'))          # every gradient entry must be (over)written by the backward plan
     m._run_fwd_bwd()
     torch.cuda.synchronize()
+    assert bool(torch.isfinite(m.store.g).all())
     loss_ref, g_ref, c = ounet.loss_and_grads(p, x[0], y[0])
     logits = m.acts['logits'].t[..., :nc].cpu().numpy()
     assert logits.shape == (B, 4, 4, nc)
