@@ -46,7 +46,8 @@ def parse():
 
 
 def kernel_table(model, reps=5):
-    """Per-launch durations with HIP events recorded on the stream the kernels run on, aggregated by kernel
+    """Per-launch durations with HIP events recorded on the stream each kernel is launched on (main or the side
+    streams the filter gradients are forked onto -- the same overlap as in the timed region), aggregated by kernel
     template instance (the names rocprofv3 --kernel-trace --stats prints)."""
     stream = torch.cuda.current_stream().cuda_stream
     agg = {}
@@ -55,7 +56,7 @@ def kernel_table(model, reps=5):
         model.loss_buf.zero_()
         rows = []
         for plan in (model.fwd_plan, model.bwd_plan, model.upd_plan):
-            rows += plan.run_profiled(stream, torch)
+            rows += plan.run_profiled(stream, torch, model._side if plan is not model.upd_plan else None)
         if rep == 0:
             continue               # warm-up
         for i, (op, kern, ms, fl) in enumerate(rows):

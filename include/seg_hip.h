@@ -97,6 +97,7 @@ typedef struct seg_wgrad_desc {
   int32_t bias_mode;              /* 0 none, 1 sum dz, 2 sum src            */
   float* db;
   int32_t bias_n;
+  int32_t phase;                  /* 0 = partial sums + reduce (two launches); 1 = partial sums only; 2 = reduce only */
 } seg_wgrad_desc;
 int seg_conv2d_wgrad(const seg_wgrad_desc* d, void* stream);
 int seg_conv2d_wgrad_plan(const seg_wgrad_desc* d, int32_t* ksplit, int64_t* ws_bytes);

@@ -36,7 +36,7 @@ class WgradDesc(C.Structure):
                 ('stride', C.c_int32), ('pad_t', C.c_int32), ('pad_l', C.c_int32), ('Ho', C.c_int32), ('Wo', C.c_int32),
                 ('dz', View), ('n_log', C.c_int32), ('dw', C.c_void_p), ('dtype', C.c_int32), ('cfg', C.c_int32),
                 ('ws', C.c_void_p), ('ws_bytes', C.c_int64), ('ksplit', C.c_int32), ('bias_mode', C.c_int32),
-                ('db', C.c_void_p), ('bias_n', C.c_int32)]
+                ('db', C.c_void_p), ('bias_n', C.c_int32), ('phase', C.c_int32)]
 
 
 class PackEntry(C.Structure):

@@ -43,6 +43,12 @@ template <> struct Tr<float> {
   static SEG_DEV int lds_off(int row, int piece) { return row * 144 + (piece << 4); }
 };
 
+// Kernel templates take the dtype as an INT (SEG_F32 / SEG_BF16) rather than a type: a `__bf16` template argument
+// mangles to DF16b, which GNU/rocprof demanglers garble, and the kernel names must stay readable in rocprofv3 output.
+template <int DT> struct DtSel;
+template <> struct DtSel<SEG_F32> { typedef float type; };
+template <> struct DtSel<SEG_BF16> { typedef bf16_t type; };
+
 // MFMA operand fragment: the 8 K-elements a lane owns.
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { bf16x8 v; };

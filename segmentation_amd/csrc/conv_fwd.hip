@@ -83,8 +83,9 @@ SEG_DEV void conv_epilogue(const seg_conv_desc& d, f32x4 (&acc)[FN][FM], int b, 
   }
 }
 
-template <typename T, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S>
+template <int DT, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
+  using T = typename DtSel<DT>::type;
   using TT = Tr<T>;
   constexpr int BM = TH * TW;
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW, NPIX = PH * PW;
@@ -379,7 +380,7 @@ int launch_cfg(const ConvK& P0, hipStream_t st) {
   P.tiles_x = cdiv(P.d.Wo, TW);
   P.tiles_y = cdiv(P.d.Ho, TH);
   if (P.d.n_count % BN != 0) { seg_set_error("conv: n_count %d not a multiple of BN %d", P.d.n_count, BN); return SEG_ERR_ARG; }
-  auto kern = conv_fwd_kernel<T, TH, TW, BN, WM, WN, KH, KW, S>;
+  auto kern = conv_fwd_kernel<Tr<T>::DT, TH, TW, BN, WM, WN, KH, KW, S>;
   static bool attr_done = false;
   if (!attr_done && LDS > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {

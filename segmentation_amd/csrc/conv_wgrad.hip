@@ -52,8 +52,9 @@ template <> struct TrRead<bf16_t> {
 // RS = 1: "row split" -- blockIdx.z selects one filter row u, the workgroup keeps only KW taps in registers.
 // Used for the deep layers (few pixel tiles, big filters) where splitting K cannot create enough workgroups:
 // it multiplies the workgroup count by KH without any partial-sum traffic.
-template <typename T, int TH, int TW, int KH, int KW, int S, int WCI, int WCO, int FCI, int FCO, int RS>
+template <int DT, int TH, int TW, int KH, int KW, int S, int WCI, int WCO, int FCI, int FCO, int RS>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
+  using T = typename DtSel<DT>::type;
   constexpr int BM = TH * TW;
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW, NPIX = PH * PW;
   constexpr int NU = RS ? 1 : KH;
@@ -415,8 +416,8 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
   const bool rs = KH > 1 && P.d.bias_mode != 2 && P.ntiles <= 64 && base < 192;
   const int wg = base * (rs ? KH : 1);
   static const int target_wgs = getenv("SEG_WGRAD_WGS") ? atoi(getenv("SEG_WGRAD_WGS")) : 256;
-  auto k0 = conv_wgrad_kernel<T, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, 0>;
-  auto k1 = conv_wgrad_kernel<T, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, (KH > 1 ? 1 : 0)>;
+  auto k0 = conv_wgrad_kernel<Tr<T>::DT, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, 0>;
+  auto k1 = conv_wgrad_kernel<Tr<T>::DT, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, (KH > 1 ? 1 : 0)>;
   static int occ = 0;                      // resident workgroups per CU of this instance
   if (occ == 0) {
     if (LDS > 48 * 1024) {
@@ -449,10 +450,13 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
   }
   if (g_plan_ks) { *g_plan_ks = ks; *g_plan_bytes = P.direct ? 0 : P.slab * ks * 4; return SEG_OK; }
   if (!P.direct && (!P.d.ws || P.d.ws_bytes < P.slab * ks * 4)) { seg_set_error("wgrad: workspace too small (%lld < %lld bytes)", (long long)P.d.ws_bytes, (long long)(P.slab * ks * 4)); return SEG_ERR_ARG; }
-  if (rs) SEG_LAUNCH(k1, dim3(base, ks, KH), dim3(256), LDS, st, P);
-  else SEG_LAUNCH(k0, dim3(base, ks, 1), dim3(256), LDS, st, P);
-  int rc = seg_check_launch("conv_wgrad");
-  if (rc || P.direct) return rc;
+  int rc = SEG_OK;
+  if (P.d.phase != 2) {
+    if (rs) SEG_LAUNCH(k1, dim3(base, ks, KH), dim3(256), LDS, st, P);
+    else SEG_LAUNCH(k0, dim3(base, ks, 1), dim3(256), LDS, st, P);
+    rc = seg_check_launch("conv_wgrad");
+  }
+  if (rc || P.direct || P.d.phase == 1) return rc;
   const int taps = KH * KW, k_log = P.d.src0_clog + P.d.src1_clog;
   const bool v4 = (P.d.n_log % 4 == 0) && (P.n_pad % 4 == 0);
   const int V = v4 ? 4 : 1;

@@ -226,21 +226,46 @@ class Plan(object):
             return buf.value.decode()
         return self.meta[i].get('kernel', fn.__name__ if fn is not None else 'marker')
 
-    def run_profiled(self, stream, torch_mod):
-        """Eager run with a HIP event between consecutive launches on `stream` (the stream the kernels
-        are launched on).  Returns [(op name, kernel name, ms, flops)]."""
+    def run_profiled(self, stream, torch_mod, side=None):
+        """Like run(), with a HIP event recorded before and after every launch ON THE STREAM THE KERNEL IS LAUNCHED ON
+        (main or side), so that the per-kernel durations include the same cross-stream overlap as the timed region.
+        Returns [(op name, kernel name, ms, flops)]."""
         sp = C.c_void_p(stream)
-        evs = [torch_mod.cuda.Event(enable_timing=True) for _ in range(len(self.ops) + 1)]
-        evs[0].record()
+        main = torch_mod.cuda.current_stream()
+        E_ = lambda: torch_mod.cuda.Event(enable_timing=True)
+        recs = []
+        used, rr, aux_used = {}, 0, False
+        aux = side[-1] if side else None
         for i, (name, fn, args) in enumerate(self.ops):
-            if fn is not None:
-                rc = fn(*args, sp)
-                if rc != 0:
-                    L.check(rc, '%s/%s' % (self.name, name))
-            evs[i + 1].record()
+            tag = self.meta[i].get('side', 0) if side else 0
+            if fn is None:
+                if side and aux_used:
+                    ev = torch_mod.cuda.Event(); ev.record(aux); main.wait_event(ev); aux_used = False
+                continue
+            if tag == 'aux':
+                st = aux; aux_used = True
+            elif tag:
+                if not self.meta[i].get('follow', 0):
+                    rr += 1
+                st = side[rr % (len(side) - 1)] if len(side) > 1 else side[0]
+                used[id(st)] = st
+            else:
+                st = main
+            if st is not main:
+                ev = torch_mod.cuda.Event(); ev.record(main); st.wait_event(ev)
+            e0, e1 = E_(), E_()
+            e0.record(st)
+            rc = fn(*args, C.c_void_p(st.cuda_stream) if st is not main else sp)
+            if rc != 0:
+                L.check(rc, '%s/%s' % (self.name, name))
+            e1.record(st)
+            recs.append((i, e0, e1))
+        if side and aux_used:
+            used[id(aux)] = aux
+        for st in used.values():
+            ev = torch_mod.cuda.Event(); ev.record(st); main.wait_event(ev)
         torch_mod.cuda.synchronize()
-        return [(self.ops[i][0], self.kernel_name(i), evs[i].elapsed_time(evs[i + 1]), self.meta[i].get('flops', 0))
-                for i in range(len(self.ops))]
+        return [(self.ops[i][0], self.kernel_name(i), e0.elapsed_time(e1), self.meta[i].get('flops', 0)) for i, e0, e1 in recs]
 
 
 class Net(object):
@@ -330,6 +355,21 @@ class Net(object):
         self.ws_bytes = getattr(self, 'ws_bytes', 0) + nbytes.value
         plan.keep += [w, ws]
 
+    def _add_wgrad(self, plan, name, w, fl, follow=False):
+        """One plan op for the partial-sum kernel and, when K is split, a second one for the slab reduction (same side
+        stream): two C-ABI calls so that each kernel is timed on its own."""
+        meta = {'follow': 1} if follow else {}
+        if w.ksplit > 1:
+            w.phase = 1
+            w2 = L.WgradDesc.from_buffer_copy(w)
+            w2.phase = 2
+            plan.keep.append(w2)
+            plan.add(name, self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=1, **meta)
+            plan.add(name + '/reduce', self.lib.seg_conv2d_wgrad, C.byref(w2), kernel='wgrad_reduce_kernel', side=1, follow=1)
+        else:
+            w.phase = 0
+            plan.add(name, self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=1, **meta)
+
     def first_im2col(self, plan, layer, x_f32, H, W):
         """im2col of the raw input (27 -> 32 channels) for the first layer's filter gradient.  It depends only on the
         input batch, so the models emit it at the START of the forward plan on a side stream (off the critical path)."""
@@ -359,7 +399,7 @@ class Net(object):
         w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
-        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=1)
+        self._add_wgrad(plan, layer.name + '/dw', w, fl)
         plan.flops += fl
 
     def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0):
@@ -380,7 +420,7 @@ class Net(object):
         w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
-        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=1)
+        self._add_wgrad(plan, layer.name + '/dw', w, fl)
         plan.flops += fl
         n_off = 0
         for i, ds in enumerate(dsrcs):
@@ -416,7 +456,7 @@ class Net(object):
         w.bias_mode = 2; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
-        plan.add(layer.name + '/dw', self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=1)
+        self._add_wgrad(plan, layer.name + '/dw', w, fl)
         plan.flops += fl
         if dsrc is not None:
             d = L.ConvDesc()
