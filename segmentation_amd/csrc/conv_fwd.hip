@@ -454,6 +454,8 @@ int launch_k(const ConvK& P, hipStream_t st) {
     case 2: return launch_cfg<T, 8, 16, 32, 4, 1, KH, KW, S>(P, st);   // 128 px x 32 ch
     case 3: return launch_cfg<T, 8, 8, 64, 2, 2, KH, KW, S>(P, st);    //  64 px x 64 ch
     case 4: return launch_cfg<T, 8, 8, 32, 4, 1, KH, KW, S>(P, st);    //  64 px x 32 ch
+    case 5: return launch_cfg<T, 16, 16, 64, 4, 1, KH, KW, S>(P, st);  // 256 px x 64 ch
+    case 6: return launch_cfg<T, 16, 16, 32, 4, 1, KH, KW, S>(P, st);  // 256 px x 32 ch
     default: break;
   }
   if (sizeof(T) == 2) {

@@ -256,6 +256,8 @@ class UNetModel(BaseModel):
             pin = A['pool%d' % (i - 1)]
             dP[i - 1] = net.act(pin.H, pin.W, pin.C, name='dpool%d' % (i - 1))
             net.conv_bwd(seg, Ly[c1], [(pin, 0, 0)], pin.H, pin.W, G[c1], [(dP[i - 1], (0, 0), None, (0, 0))])
+            if i == 3:
+                close_segment('conv3_1')      # third bucket = conv2_x + conv1_x only (0.26 MB): the exposed all-reduce is tiny
         # conv1_2 (window of conv1_1 at o4, extent t4+2) then pool1 + skip add -> dZ(conv1_1)
         t4h, t4w = A['upconv4'].H, A['upconv4'].W
         d11s = net.act(t4h + 2, t4w + 2, A['conv1_1'].C, name='d_conv1_1_skip')

@@ -1,0 +1,71 @@
+"""-m gpu: the full data-parallel train step with world_size 2 (two processes sharing the one GPU of the test box, gloo
+backend on device tensors -- RCCL itself needs one GPU per rank): segmented backward, bucketed all-reduce, 1/world Adam
+scaling.  Two ranks with one image each must reproduce the single-process step on the 2-image batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, x, y, out):
+    import torch.distributed as dist
+    from segmentation_amd.datasets import ArrayDataSet
+    from segmentation_amd.dist import shard_batch
+    from segmentation_amd.unet import UNetModel
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        lo, hi = shard_batch(x.shape[1], world, rank)
+        m = UNetModel(sess=None, dataset=ArrayDataSet(x[:, lo:hi], y[:, lo:hi]), n_classes=2, input_dims=188, learning_rate=1e-3,
+                      log_dir=None, save_dir=None, load_snapshot=False, dtype='f32', use_graph=True)
+        assert m.pg.world == world and m.pg.enabled
+        m.pg.broadcast_(m.store.p); m._repack()
+        m.train_step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            out['g1'] = m.store.g.cpu().numpy() / world          # the arena holds the SUM over ranks; Adam scales by 1/world
+        for _ in range(2):
+            m.train_step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            out['p'] = m.store.p.cpu().numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process_global_batch():
+    import torch.multiprocessing as mp
+    from segmentation_amd.datasets import ArrayDataSet
+    from segmentation_amd.unet import UNetModel
+    rng = np.random.default_rng(7)
+    x = rng.uniform(0, 1, (2, 2, 188, 188, 3)).astype(np.float32)
+    y = rng.integers(0, 2, (2, 2, 188, 188, 1)).astype(np.uint8)
+    ref = UNetModel(sess=None, dataset=ArrayDataSet(x, y), n_classes=2, input_dims=188, learning_rate=1e-3, log_dir=None,
+                    save_dir=None, load_snapshot=False, dtype='f32', use_graph=False)
+    ref.train_step()
+    torch.cuda.synchronize()
+    gref = ref.store.g.cpu().numpy()
+    for _ in range(2):
+        ref.train_step()
+    torch.cuda.synchronize()
+    pref = ref.store.p.cpu().numpy()
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), x, y, out), nprocs=2, join=True)
+    # same math up to summation order (mean over 2 images vs mean of two per-image means)
+    for name, l in ref.store.layers.items():
+        for lo, n in ((l.w_off, l.wsize), (l.b_off, l.cout)):
+            a, b = out['g1'][lo:lo + n], gref[lo:lo + n]
+            assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max() + 1e-12, name
+    # after three Adam steps: identical except where a cancellation-dominated gradient flips sign under round-off
+    # (Adam then moves that weight by a full +-lr); such elements must stay a vanishing fraction
+    d = np.abs(out['p'] - pref)
+    assert np.median(d) < 1e-6 and (d > 1e-4).mean() < 1e-3 and d.max() < 3.5e-3
