@@ -238,7 +238,9 @@ SEG_DEV void glds16(const void* gsrc, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S>
+// NBUF = 2: double-buffered (chunk c+1 in flight during chunk c, ~1 workgroup/CU); NBUF = 1: single LDS buffer, loads are
+// not overlapped inside a workgroup but 4-5 small workgroups per CU overlap each other (no staging VGPRs -> 4+ waves/SIMD).
+template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, int NBUF>
 __global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
   using T = bf16_t;
   using TT = Tr<T>;
@@ -334,12 +336,16 @@ __global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = f32x4{0, 0, 0, 0};
 
-  issue(0, smem);
+  if (NBUF == 2) issue(0, smem);
   for (int c = 0; c < P.nchunks; ++c) {
-    char* cur = smem + (c & 1) * BUF;
+    char* cur = smem + (NBUF == 2 ? (c & 1) * BUF : 0);
+    if (NBUF == 1) {
+      if (c > 0) __syncthreads();                          // everyone finished reading the previous chunk
+      issue(c, smem);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of chunk c has landed
     __syncthreads();                                       // ... everyone's has, and nobody still reads the other buffer
-    if (c + 1 < P.nchunks) issue(c + 1, smem + ((c + 1) & 1) * BUF);
+    if (NBUF == 2 && c + 1 < P.nchunks) issue(c + 1, smem + ((c + 1) & 1) * BUF);
     // fragments of tap t+1 are read from LDS before the MFMAs of tap t (explicit software pipeline)
     Frag<T> fa[2][FN], fb[2][FM];
 #pragma unroll
@@ -393,21 +399,21 @@ int launch_cfg(const ConvK& P0, hipStream_t st) {
   return seg_check_launch("conv_fwd");
 }
 
-template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S>
+template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, int NBUF = 2>
 int launch_glds(const ConvK& P0, hipStream_t st) {
   if (g_name_out) {
-    snprintf(g_name_out, g_name_cap, "conv_fwd_glds_kernel<%d,%d,%d,%d,%d,%d,%d,%d>", TH, TW, BN, WM, WN, KH, KW, S);
+    snprintf(g_name_out, g_name_cap, "conv_fwd_glds_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d>", TH, TW, BN, WM, WN, KH, KW, S, NBUF);
     return SEG_OK;
   }
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
   constexpr int PINST = (PH * PW * 4 + 63) / 64, WINST = KH * KW * BN * 4 / 64;
-  constexpr int LDS = 2 * (PINST + WINST) * 1024;
+  constexpr int LDS = NBUF * (PINST + WINST) * 1024;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   ConvK P = P0;
   P.tiles_x = cdiv(P.d.Wo, TW);
   P.tiles_y = cdiv(P.d.Ho, TH);
   if (P.d.n_count % BN != 0) { seg_set_error("conv: n_count %d not a multiple of BN %d", P.d.n_count, BN); return SEG_ERR_ARG; }
-  auto kern = conv_fwd_glds_kernel<TH, TW, BN, WM, WN, KH, KW, S>;
+  auto kern = conv_fwd_glds_kernel<TH, TW, BN, WM, WN, KH, KW, S, NBUF>;
   static bool attr_done = false;
   if (!attr_done && LDS > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -427,7 +433,8 @@ template <typename T, int KH, int KW, int S>
 int launch_k(const ConvK& P, hipStream_t st) {
   const seg_conv_desc& d = P.d;
   int cfg = d.cfg;
-  if (cfg == 0) {
+  const int mode_hint = cfg < 0 ? -cfg : 0;      // cfg < 0: automatic tile choice with staging mode |cfg| (see below)
+  if (cfg <= 0) {
     // Tile choice by a two-term cost model calibrated on MI355X micro-benchmarks: a workgroup costs its MACs per
     // K step (BM*BN) plus a fixed part (prologue, first-load latency, epilogue ~ 5000 MAC-equivalents), and the
     // grid runs in rounds of 768 resident workgroups (3 per CU).  Small / deep layers therefore prefer the 32-channel
@@ -443,9 +450,13 @@ int launch_k(const ConvK& P, hipStream_t st) {
     cfg = bi + 1;
     if (sizeof(T) == 2) {
       // bf16: direct-to-LDS double-buffered variants.  SEG_CONV_MODE: 0 = never, 1 = always, 2 = always + 256-pixel
-      // tile on maps >= 32 wide, 3 (default) = only for the 64-pixel tiles (small LDS footprint, measured faster)
-      static const int mode = getenv("SEG_CONV_MODE") ? atoi(getenv("SEG_CONV_MODE")) : 3;
+      // tile on maps >= 32 wide, 3 (default) = only for the 64-pixel tiles, 4 = single-buffered direct-to-LDS everywhere (fastest stand-alone:
+      // the host asks for it on the forward pass; in backward the dgrads share the chip with the filter gradients and 3 wins)
+      static const int env_mode = getenv("SEG_CONV_MODE") ? atoi(getenv("SEG_CONV_MODE")) : -1;
+      const int mode = env_mode >= 0 ? env_mode : (mode_hint ? mode_hint : 3);
       if (mode == 1 || mode == 2 || (mode == 3 && cfg >= 3)) cfg += 10;
+      if (mode == 4) cfg += 20;          // single-buffered direct-to-LDS (default: fastest on every measured layer)
+      if (mode == 5) cfg = (cfg == 1 || cfg == 2) ? 22 : 24;   // ... and always 32-channel tiles
       if (mode == 2 && cfg == 11 && d.Ho >= 32 && d.Wo >= 32) cfg = 15;
     }
   }
@@ -465,6 +476,10 @@ int launch_k(const ConvK& P, hipStream_t st) {
       case 13: return launch_glds<8, 8, 64, 2, 2, KH, KW, S>(P, st);
       case 14: return launch_glds<8, 8, 32, 4, 1, KH, KW, S>(P, st);
       case 15: return launch_glds<16, 16, 64, 4, 1, KH, KW, S>(P, st);  // 256 px x 64 ch
+      case 21: return launch_glds<8, 16, 64, 4, 1, KH, KW, S, 1>(P, st);  // single-buffered variants
+      case 22: return launch_glds<8, 16, 32, 4, 1, KH, KW, S, 1>(P, st);
+      case 23: return launch_glds<8, 8, 64, 2, 2, KH, KW, S, 1>(P, st);
+      case 24: return launch_glds<8, 8, 32, 4, 1, KH, KW, S, 1>(P, st);
       default: break;
     }
   }
