@@ -26,48 +26,89 @@ struct ConvK {          // kernel-side copy of the descriptor (trivially copyabl
 };
 
 // ---- epilogue: bias, ReLU, ReLU-grad mask, store 8 channels per lane ----
-template <typename T, int TH, int TW, int BN, int WM, int WN, int FM, int FN>
-SEG_DEV void conv_epilogue(const seg_conv_desc& d, f32x4 (&acc)[FN][FM], int b, int oy0, int ox0, int n0, int wm, int wn, int lr, int g) {
-  constexpr int BM = TH * TW;
+// Stamps (s_memtime) showed the naive epilogue at ~5000 of a wave's ~23000 cycles: the bias and mask loads sat on the
+// critical path one after the other and every store recomputed 64-bit view offsets.  So: (1) all bias loads are issued
+// together (EpiCtx; holding them across the K loop cost 26 VGPRs = one wave per SIMD of occupancy, measured slower),
+// (2) all mask / accumulate loads are issued back to back before the first use, (3) addresses are one 64-bit image base +
+// 32-bit in-image offsets.
+template <int NJ>
+struct EpiCtx {
+  int co[NJ], ua[NJ], uc[NJ];      // first of the lane's 8 channels (dst-relative), transposed-conv tap
+  bool on[NJ];
+  float bv[NJ][8];
+};
+
+template <int BN, int WN, int NJ>
+SEG_DEV void epi_setup(const seg_conv_desc& d, int n0, int wn, int g, EpiCtx<NJ>& E) {
 #pragma unroll
-  for (int j = 0; j < FN / 2; ++j) {
-    const int nl = n0 + wn * (BN / WN) + j * 32 + 8 * g;     // first of this lane's 8 channels (launch-local)
-    if (nl >= d.n_count) continue;
-    const int np = d.n_off + nl;                               // packed row index
-    int co = nl, ua = 0, uc = 0;
-    if (d.up2) { const int tp = np / d.up_cout; co = np - tp * d.up_cout; ua = tp >> 1; uc = tp & 1; }
-    float bv[8];
+  for (int j = 0; j < NJ; ++j) {
+    const int nl = n0 + wn * (BN / WN) + j * 32 + 8 * g;       // launch-local channel
+    const int np = d.n_off + nl;                                 // packed row index
+    E.on[j] = nl < d.n_count;
+    E.co[j] = nl; E.ua[j] = 0; E.uc[j] = 0;
+    if (d.up2) { const int tp = np / d.up_cout; E.co[j] = np - tp * d.up_cout; E.ua[j] = tp >> 1; E.uc[j] = tp & 1; }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int bi = d.up2 ? co + e : np + e;
-      bv[e] = (d.bias != nullptr && bi < d.bias_n) ? d.bias[bi] : 0.f;
+      const int bi = d.up2 ? E.co[j] + e : np + e;
+      E.bv[j][e] = (d.bias != nullptr && bi < d.bias_n) ? d.bias[bi] : 0.f;
     }
+  }
+}
+
+template <typename T, int TH, int TW, int BN, int WM, int WN, int FM, int FN>
+SEG_DEV void conv_epilogue(const seg_conv_desc& d, f32x4 (&acc)[FN][FM], const EpiCtx<FN / 2>& E, int b, int oy0, int ox0, int wm, int lr) {
+  constexpr int BM = TH * TW, NJ = FN / 2;
+  const int sc = d.up2 ? 2 : 1;
+  const T* mbase = reinterpret_cast<const T*>(d.mask.ptr) + ((int64_t)(b * d.mask.H + d.mask.oy) * d.mask.W + d.mask.ox) * d.mask.cs + d.mask.coff;
+  const int64_t dbase = ((int64_t)(b * d.dst.H + d.dst.oy) * d.dst.W + d.dst.ox) * d.dst.cs + d.dst.coff;
+  int poff_d[FM], poff_m[FM];          // in-window pixel offsets (elements) for tap (0,0); -1 = outside the output
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm) {
+    const int m = wm * (BM / WM) + fm * 16 + lr;
+    const int oy = oy0 + m / TW, ox = ox0 + m % TW;
+    const bool ok = oy < d.Ho && ox < d.Wo;
+    poff_d[fm] = ok ? (sc * oy * d.dst.W + sc * ox) * d.dst.cs : -1;
+    poff_m[fm] = (sc * oy * d.mask.W + sc * ox) * d.mask.cs;
+  }
+  const bool has_mask = d.mask.ptr != nullptr, has_acc = d.accum != 0;
+  Vec8<T> mk[NJ][FM], old[NJ][FM];
+  if (has_mask) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm)
+        if (E.on[j] && poff_d[fm] >= 0) mk[j][fm].load(mbase + poff_m[fm] + (E.ua[j] * d.mask.W + E.uc[j]) * d.mask.cs + E.co[j]);
+  }
+  if (has_acc) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm)
+        if (E.on[j] && poff_d[fm] >= 0)
+          old[j][fm].load(reinterpret_cast<const T*>(d.dst.ptr) + dbase + poff_d[fm] + (E.ua[j] * d.dst.W + E.uc[j]) * d.dst.cs + E.co[j]);
+  }
+  const float lo = d.relu ? 0.f : -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    if (!E.on[j]) continue;
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
-      const int m = wm * (BM / WM) + fm * 16 + lr;
-      const int oy = oy0 + m / TW, ox = ox0 + m % TW;
-      if (oy >= d.Ho || ox >= d.Wo) continue;
+      if (poff_d[fm] < 0) continue;
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = acc[2 * j][fm][e] + bv[e]; v[4 + e] = acc[2 * j + 1][fm][e] + bv[4 + e]; }
-      if (d.relu) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      for (int e = 0; e < 4; ++e) {
+        v[e] = fmaxf(acc[2 * j][fm][e] + E.bv[j][e], lo);
+        v[4 + e] = fmaxf(acc[2 * j + 1][fm][e] + E.bv[j][4 + e], lo);
       }
-      const int dy = d.up2 ? 2 * oy + ua : oy, dx = d.up2 ? 2 * ox + uc : ox;
-      if (d.accum) {
-        Vec8<T> old;
-        old.load(reinterpret_cast<const T*>(d.dst.ptr) + view_off(d.dst, b, dy, dx) + co);
+      if (has_acc) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += old.get(e);
+        for (int e = 0; e < 8; ++e) v[e] += old[j][fm].get(e);
       }
-      if (d.mask.ptr != nullptr) {
-        Vec8<T> mk;
-        mk.load(reinterpret_cast<const T*>(d.mask.ptr) + view_off(d.mask, b, dy, dx) + co);
+      if (has_mask) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = mk.get(e) > 0.f ? v[e] : 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = mk[j][fm].get(e) > 0.f ? v[e] : 0.f;
       }
-      const int64_t doff = view_off(d.dst, b, dy, dx) + co;
+      const int64_t doff = dbase + poff_d[fm] + (E.ua[j] * d.dst.W + E.uc[j]) * d.dst.cs + E.co[j];
       if (d.out_f32) {
         Vec8<float> o;
 #pragma unroll
@@ -222,7 +263,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
     }
   }
 
-  conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN>(d, acc, b, oy0, ox0, n0, wm, wn, lr, g);
+  EpiCtx<FN / 2> epi;                              // all bias loads issued together (one latency), then the mask loads
+  epi_setup<BN, WN, FN / 2>(d, n0, wn, g, epi);
+  conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN>(d, acc, epi, b, oy0, ox0, wm, lr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -366,7 +409,9 @@ __global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
         for (int fm = 0; fm < FM; ++fm) mma32(acc[fn][fm], fa[tap & 1][fn], fb[tap & 1][fm]);
     }
   }
-  conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN>(d, acc, b, oy0, ox0, n0, wm, wn, lr, g);
+  EpiCtx<FN / 2> epi;                              // all bias loads issued together (one latency), then the mask loads
+  epi_setup<BN, WN, FN / 2>(d, n0, wn, g, epi);
+  conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN>(d, acc, epi, b, oy0, ox0, wm, lr);
 }
 
 thread_local char* g_name_out = nullptr;   // when set, launches are dry: only the kernel name is reported
