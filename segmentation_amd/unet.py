@@ -125,9 +125,10 @@ class UNetModel(BaseModel):
     def _emit_forward(self, net, plan, x_in, H, W, crop_aware, dropout=None, after_first=None):
         nk, Ly = self.n_kernels, self.store.layers
         if H != W:
-            sh, sw = unet_sizes(H), unet_sizes(W)
-        else:
-            sh = sw = unet_sizes(H)
+            # the reference crops every skip with a SQUARE target taken from the height (models/unet.py:139-140,146-147):
+            # a non-square input makes its tf.concat fail, so it is rejected here too
+            raise Exception('UNetModel needs square inputs (got %dx%d): skips are cropped with a square target' % (H, W))
+        sh = sw = unet_sizes(H)
         A = {}
         A['conv1_1'] = net.act(sh['conv1_1'], sw['conv1_1'], nk, name='conv1_1')
         net.first_fwd(plan, Ly['conv1_1'], x_in, H, W, A['conv1_1'])

@@ -163,3 +163,48 @@ def test_unet_256_shapes_and_loss_decreases():
     assert l1 < l0                               # memorising one batch
     with pytest.raises(Exception):
         UNetModel(sess=None, dataset=SyntheticDataSet(1, 128, 2), n_classes=2, input_dims=128, save_dir=None)
+
+
+@pytest.mark.parametrize('B,H,W,cin,nk,nc', [(1, 188, 188, 2, 32, 2), (3, 188, 188, 1, 16, 21), (2, 204, 204, 3, 8, 5)])
+def test_unet_ragged_shapes_f32(B, H, W, cin, nk, nc):
+    """1/2-channel images, channel counts that are not multiples of 32, odd batch sizes, 21 classes"""
+    rng = np.random.default_rng(H + W + nk)
+    x = rng.uniform(0, 1, (1, B, H, W, cin)).astype(np.float32)
+    y = rng.integers(0, nc, (1, B, H, W, 1)).astype(np.uint8)
+    m = UNetModel(sess=None, dataset=ArrayDataSet(x, y), n_classes=nc, input_dims=[H, W], input_channel=cin, n_kernels=nk,
+                  learning_rate=1e-4, log_dir=None, save_dir=None, load_snapshot=False, dtype='f32', use_graph=False)
+    p = m.store.get_params()
+    for n in p:
+        p[n]['biases'] = (rng.standard_normal(p[n]['biases'].shape) * 0.05).astype(np.float32)
+    m.set_weights(p)
+    m._load_batch(m.dataset, m.input_x, m.input_y)
+    m.store.g.fill_(float('nan'))
+    m._run_fwd_bwd()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(m.store.g).all())
+    import oracle.unet as ou
+    logits_ref, c = ou.forward(p, x[0])
+    oh, ow = logits_ref.shape[1:3]
+    assert m.out_hw == (oh, ow)
+    yc = y[0][:, (H - oh) // 2:(H - oh) // 2 + oh, (W - ow) // 2:(W - ow) // 2 + ow]
+    loss_ref, _, _ = ops.softmax_xent(logits_ref, yc)
+    logits = m.acts['logits'].t[..., :nc].cpu().numpy()
+    assert np.abs(logits - logits_ref).max() < 1e-4
+    assert abs(m.last_loss() - loss_ref) < 1e-5
+    # gradients: the oracle's backward crops labels with a square target, so compare against torch autograd instead
+    from oracle import torch_ref
+    tp = torch_ref.to_torch_params(p, torch.float64)
+    lg = torch_ref.unet_forward(tp, torch.as_tensor(x[0], dtype=torch.float64))
+    loss_t = torch_ref.xent_mean(lg, torch.as_tensor(yc[..., 0].astype(np.int64)))
+    loss_t.backward()
+    g = m.store.get_grads()
+    for n in tp:
+        for k in ('weights', 'biases'):
+            ref = tp[n][k].grad.numpy()
+            err = np.abs(g[n][k] - ref).max() / (np.abs(ref).max() + 1e-20)
+            assert err < 3e-4, (n, k, err)
+
+
+def test_unet_rejects_non_square_like_the_reference():
+    with pytest.raises(Exception):
+        UNetModel(sess=None, dataset=SyntheticDataSet(1, 188, 2), n_classes=2, input_dims=[188, 220], save_dir=None, load_snapshot=False)
