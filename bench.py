@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--per-op', action='store_true', help='also print the per-op table to stderr')
+    ap.add_argument('--host-data', action='store_true', help='feed from host memory through the pinned-buffer prefetcher (PCIe-inclusive rate; not the headline value)')
     return ap.parse_args()
 
 
@@ -115,6 +116,9 @@ def main():
     from segmentation_amd.unet import UNetModel
 
     ds = SyntheticDataSet(args.batch, args.size, args.classes, seed=5555 + rank, n_batches=2)
+    if args.host_data:
+        from segmentation_amd.datasets import ArrayDataSet, DevicePrefetcher
+        ds = DevicePrefetcher(ArrayDataSet(ds.images, ds.masks), depth=6, threads=4)
     if args.model == 'unet':
         model = UNetModel(sess=None, dataset=ds, n_classes=args.classes, input_dims=args.size, learning_rate=1e-4,
                           log_dir=None, save_dir=None, load_snapshot=False, n_kernels=args.nk,
@@ -154,7 +158,7 @@ def main():
         out = {
             'metric': 'train-step images/sec', 'value': round(world * args.batch * args.steps / dt, 2), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic' if not args.host_data else 'synthetic, fed from host memory over PCIe (pinned ring + async H2D)',
             'config': {'workload': '%s %dx%dx3 %d-class batch=%d/GPU %s train step (fwd+xent+bwd+Adam+repack), n_kernels=%d'
                                    % ('U-Net' if args.model == 'unet' else 'FCN-8s', args.size, args.size, args.classes, args.batch, args.dtype, args.nk),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,

@@ -167,3 +167,103 @@ class ThreadedImageMaskDataSet(object):
         self.start()
         img, msk = self.q.get()
         return img.numpy(), msk.numpy()
+
+
+class DevicePrefetcher(object):
+    """Host dataset -> HBM pipeline (the north-star's "pinned host buffers drained by hipMemcpyAsync"):
+    a producer thread pulls batches from any host dataset (get_batch -> ndarray), writes them into a ring of pinned
+    staging buffers and enqueues the H2D copies on a dedicated copy stream into a ring of device slots, recording an
+    event per slot.  get_device_batch() makes the *compute* stream wait for the slot's event and hands out the device
+    tensors, so the copy of batch k+1 overlaps the train step of batch k.  Slot reuse is safe as long as the consumer
+    has copied the tensors out (BaseModel does a D2D copy into its static graph inputs) before `depth` more batches are
+    requested; a per-slot "consumed" event enforces it."""
+
+    def __init__(self, dataset, depth=3, device=None, threads=1):
+        self.ds = dataset
+        self.threads = threads
+        self._lock = threading.Lock()
+        self.batch_size = dataset.batch_size
+        self.has_masks, self.use_feed = True, False
+        self.device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self.depth = depth
+        self._copy = torch.cuda.Stream(self.device)
+        self._free = queue.Queue()
+        self._ready = queue.Queue()
+        self._slots = None
+        self._stop = threading.Event()
+        self._thr = None
+        self._last = None
+        self._alloc_lock = threading.Lock()
+
+    def set_tf_sess(self, sess):
+        if hasattr(self.ds, 'set_tf_sess'):
+            self.ds.set_tf_sess(sess)
+
+    def _alloc(self, img, msk):
+        self._slots = []
+        for i in range(self.depth):
+            px = torch.empty(img.shape, dtype=torch.float32).pin_memory()
+            py = torch.empty(msk.shape, dtype=torch.uint8).pin_memory()
+            dx = torch.empty(img.shape, dtype=torch.float32, device=self.device)
+            dy = torch.empty(msk.shape, dtype=torch.uint8, device=self.device)
+            self._slots.append({'px': px, 'py': py, 'dx': dx, 'dy': dy, 'ready': None, 'consumed': None})
+            self._free.put(i)
+
+    def _produce(self):
+        torch.cuda.set_device(self.device)
+        while not self._stop.is_set():
+            with self._lock:
+                img, msk = self.ds.get_batch()
+            img = img.numpy() if isinstance(img, torch.Tensor) else np.asarray(img, np.float32)
+            msk = msk.numpy() if isinstance(msk, torch.Tensor) else np.asarray(msk, np.uint8)
+            with self._alloc_lock:
+                if self._slots is None:
+                    self._alloc(img, msk)
+            while not self._stop.is_set():
+                try:
+                    i = self._free.get(timeout=0.1)
+                    break
+                except queue.Empty:
+                    continue
+            else:
+                return
+            s = self._slots[i]
+            if s['consumed'] is not None:
+                s['consumed'].synchronize()          # the consumer's D2D copy out of this slot has finished
+            s['px'].copy_(torch.from_numpy(np.ascontiguousarray(img)))
+            s['py'].copy_(torch.from_numpy(np.ascontiguousarray(msk)))
+            with torch.cuda.stream(self._copy):
+                s['dx'].copy_(s['px'], non_blocking=True)
+                s['dy'].copy_(s['py'], non_blocking=True)
+                ev = torch.cuda.Event(); ev.record(self._copy)
+            s['ready'] = ev
+            self._ready.put(i)
+
+    def start(self):
+        if self._thr is None:
+            if hasattr(self.ds, 'start'):
+                self.ds.start()
+            self._thr = [threading.Thread(target=self._produce, daemon=True) for _ in range(self.threads)]
+            for t in self._thr:
+                t.start()
+
+    def stop(self):
+        self._stop.set()
+        if hasattr(self.ds, 'stop'):
+            self.ds.stop()
+
+    def get_device_batch(self):
+        self.start()
+        if self._last is not None:                   # the previous slot has been copied out by now: hand it back
+            ev = torch.cuda.Event(); ev.record()
+            self._slots[self._last]['consumed'] = ev
+            self._free.put(self._last)
+        i = self._ready.get()
+        s = self._slots[i]
+        torch.cuda.current_stream().wait_event(s['ready'])
+        self._last = i
+        return s['dx'], s['dy']
+
+    def get_batch(self):
+        x, y = self.get_device_batch()
+        return x.cpu().numpy(), y.cpu().numpy()

@@ -89,3 +89,20 @@ def test_snapshot_restore_roundtrip(tmp_path):
     assert torch.equal(m.store.p, m2.store.p)                    # resume continues the same trajectory
     names = set(np.load(m2._latest_checkpoint()).files)
     assert {'conv1_1/weights', 'conv1_1/biases', 'output/weights', 'global_step'} <= names
+
+
+def test_device_prefetcher_feeds_identical_batches():
+    """host dataset -> pinned ring -> async H2D on a copy stream -> train_step: same trajectory as the direct feed"""
+    from segmentation_amd.datasets import DevicePrefetcher
+    x, y = _data(2, 188, 2, seed=8, n=3)
+    kw = dict(sess=None, n_classes=2, input_dims=188, learning_rate=1e-3, log_dir=None, save_dir=None, load_snapshot=False, dtype='f32')
+    a = UNetModel(dataset=ArrayDataSet(x, y), **kw)
+    pf = DevicePrefetcher(ArrayDataSet(x, y), depth=2)
+    b = UNetModel(dataset=pf, **kw)
+    try:
+        for _ in range(7):
+            a.train_step(); b.train_step()
+        torch.cuda.synchronize()
+        assert torch.equal(a.store.p, b.store.p)
+    finally:
+        pf.stop()
