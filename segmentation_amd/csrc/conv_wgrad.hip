@@ -479,7 +479,7 @@ int launch_k(const WgK& P, hipStream_t st) {
   const bool small = (long)cdiv(d.Ho, 8) * 8 * cdiv(d.Wo, 8) * 8 < (long)cdiv(d.Ho, 8) * 8 * cdiv(d.Wo, 16) * 16;
   if (cfg == 0) {
     const int bn = (d.dz.c % 128 == 0) ? 128 : (d.dz.c % 64 == 0 ? 64 : 32);
-    static const int bnmax = getenv("SEG_WGRAD_BN") ? atoi(getenv("SEG_WGRAD_BN")) : 64;
+    static const int bnmax = getenv("SEG_WGRAD_BN") ? atoi(getenv("SEG_WGRAD_BN")) : 32;   // 32-channel tiles: fewest registers -> most co-residency with the dgrads (measured best)
     const int bne = bn > bnmax ? bnmax : bn;
     cfg = (bne == 128 ? 1 : bne == 64 ? 2 : 3) + (small ? 3 : 0);
     // large maps: 256-pixel tiles halve the barriers / staging rounds per MFMA (measured +5-8 % at >= 59x59)
