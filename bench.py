@@ -57,7 +57,8 @@ def kernel_table(model, reps=5):
         model.loss_buf.zero_()
         rows = []
         for plan in (model.fwd_plan, model.bwd_plan, model.upd_plan):
-            rows += plan.run_profiled(stream, torch, model._side if plan is not model.upd_plan else None)
+            side = model._side if plan is not model.upd_plan and not os.environ.get('SEG_BENCH_SERIAL') else None
+            rows += plan.run_profiled(stream, torch, side)
         if rep == 0:
             continue               # warm-up
         for i, (op, kern, ms, fl) in enumerate(rows):

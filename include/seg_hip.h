@@ -102,6 +102,15 @@ typedef struct seg_wgrad_desc {
 int seg_conv2d_wgrad(const seg_wgrad_desc* d, void* stream);
 int seg_conv2d_wgrad_plan(const seg_wgrad_desc* d, int32_t* ksplit, int64_t* ws_bytes);
 int seg_conv2d_wgrad_kernel_name(const seg_wgrad_desc* d, char* buf, int32_t cap);
+/* Batched slab reduction for a whole backward segment (one launch instead of one per layer): run the layers'
+ * wgrads with phase = 1, then reduce all of their slabs at once.  _plan writes one opaque 96-byte job record per
+ * descriptor with ksplit > 1 into host memory (jobs_host, cap_bytes) and reports the job count and grid size; the
+ * caller copies the records to device memory once and replays seg_wgrad_reduce_batch.  Same fixed summation order
+ * as the per-layer reduction (bitwise identical results). */
+#define SEG_REDUCE_JOB_BYTES 96
+int seg_wgrad_reduce_batch_plan(const seg_wgrad_desc* const* descs, int32_t n, void* jobs_host, int64_t cap_bytes,
+                                int32_t* njobs, int32_t* total_blocks);
+int seg_wgrad_reduce_batch(const void* jobs_dev, int32_t njobs, int32_t total_blocks, void* stream);
 
 /* First layer (Cin = input_channel <= 4, never padded to 32): models/unet.py:111-116 conv1_1,
  * models/fcn.py:110-115 conv1.  x is float32 NHWC [B,H,W,cin] dense. */

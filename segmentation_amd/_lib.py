@@ -56,6 +56,8 @@ SIGNATURES = {
     'seg_conv2d_kernel_name': [C.POINTER(ConvDesc), C.c_char_p, i32],
     'seg_conv2d_wgrad_kernel_name': [C.POINTER(WgradDesc), C.c_char_p, i32],
     'seg_conv2d_wgrad_plan': [C.POINTER(WgradDesc), C.POINTER(i32), C.POINTER(i64)],
+    'seg_wgrad_reduce_batch_plan': [C.POINTER(C.POINTER(WgradDesc)), i32, vp, i64, C.POINTER(i32), C.POINTER(i32)],
+    'seg_wgrad_reduce_batch': [vp, i32, i32, vp],
     'seg_conv_first_fwd': [vp, i32, i32, i32, i32, vp, vp, i32, i32, PV, i32, i32, i32, i32, vp],
     'seg_im2col3x3': [vp, i32, i32, i32, i32, i32, PV, i32, i32, i32, vp],
     'seg_maxpool2x2_fwd': [PV, PV, vp, i32, i32, i32, i32, i32, vp],

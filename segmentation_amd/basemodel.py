@@ -324,6 +324,7 @@ class BaseModel(object):
 
     def _finish_training_plans(self, segs):
         """segs: [(plan, arena_end_offset)] in backward order -> bwd_segments / bwd_plan / upd_plan."""
+        assert not self.net._pending_reduce, 'a backward segment was closed without flush_reduce()'
         self.bwd_segments, lo = [], 0
         for plan, hi in segs:
             self.bwd_segments.append((plan, (lo, hi)))

@@ -310,19 +310,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
 // One thread owns V consecutive n (V = 4: 16-byte coalesced loads, needs n_log % 4 == 0).  SG = 16: a block =
 // 16 outputs x 16 split groups, group g sums splits g, g+16, ... (8 loads in flight), partials meet in LDS and
 // are added in group order; SG = 1 (few splits): one thread per output.
-template <int V, int SG>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int ksplit, int64_t slab, int taps, int k_pad, int n_pad,
-                                                           int seg0_c, int seg0_cp, int seg1_c, int n_log, float* dw, int bias_mode,
-                                                           int bias_n, float* db) {
-  __shared__ float red[SG][16 * V + 1];
+struct RedArgs {
+  const float* ws; float* dw; float* db;
+  int64_t slab;
+  int ksplit, taps, k_pad, n_pad, seg0_c, seg0_cp, seg1_c, n_log, bias_mode, bias_n;
+};
+// One job of the batched reduction (seg_wgrad_reduce_batch): RedArgs + the job's block range and kernel form.
+struct RedJob { RedArgs a; int first_block, nblocks, flags, pad_; int64_t pad2_; };
+static_assert(sizeof(RedJob) == 96, "RedJob is an opaque 96-byte record in the C-ABI");
+
+template <int V>
+SEG_DEV void reduce_body(const RedArgs& A, const int sg_log, const int blk, const int nblk, float* red) {
+  const float* ws = A.ws; float* dw = A.dw; float* db = A.db;
+  const int ksplit = A.ksplit, taps = A.taps, k_pad = A.k_pad, n_pad = A.n_pad, seg0_c = A.seg0_c, seg0_cp = A.seg0_cp, seg1_c = A.seg1_c,
+            n_log = A.n_log, bias_mode = A.bias_mode, bias_n = A.bias_n;
+  const int64_t slab = A.slab;
   const int k_log = seg0_c + seg1_c;
   const int nq = n_log / V;
   const int64_t nw = (int64_t)taps * k_log * nq;
   const int64_t nb = bias_mode ? (bias_n + V - 1) / V : 0;          // bias handled in units of V as well
   const int64_t total = nw + nb;
-  constexpr int OPB = 256 / SG;                                     // outputs (units of V) per block
-  const int ol = threadIdx.x % OPB, g = threadIdx.x / OPB;
-  for (int64_t i0 = (int64_t)blockIdx.x * OPB; i0 < total; i0 += (int64_t)gridDim.x * OPB) {
+  const int SG = 1 << sg_log, OPB = 256 >> sg_log;                  // split groups; outputs (units of V) per block
+  const int ol = threadIdx.x & (OPB - 1), g = threadIdx.x >> (8 - sg_log);
+  const int rstride = OPB * V + 1;
+  for (int64_t i0 = (int64_t)blk * OPB; i0 < total; i0 += (int64_t)nblk * OPB) {
     const int64_t i = i0 + ol;
     const float* src = ws;
     float* dst = nullptr;
@@ -343,41 +354,39 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int 
     float a[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) a[e] = 0.f;
-    if (valid > 0) {
-      int s = g;
-      for (; s + 7 * SG < ksplit; s += 8 * SG) {
-        float v[8][V];
+    // group g sums splits g, g+SG, ...: 8 predicated loads are issued before any is consumed, so a thread pays one
+    // memory latency per 8 splits (SG is chosen so that this is a single batch whenever ksplit <= 256)
+    for (int s = g; s < ksplit && valid > 0; s += 8 * SG) {
+      float v[8][V];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float* p = src + (int64_t)(s + j * SG) * slab;
-          if (V == 4 && valid == 4) { const f32x4 x = *reinterpret_cast<const f32x4*>(p); v[j][0] = x[0]; v[j][1 % V] = x[1]; v[j][2 % V] = x[2]; v[j][3 % V] = x[3]; }
-          else {
+      for (int j = 0; j < 8; ++j) {
+        const int sj = s + j * SG;
+        const bool on = sj < ksplit;
+        const float* p = src + (int64_t)(on ? sj : s) * slab;
+        if (V == 4 && valid == 4) {
+          f32x4 x = *reinterpret_cast<const f32x4*>(p);
+          if (!on) x = f32x4{0.f, 0.f, 0.f, 0.f};
+          v[j][0] = x[0]; v[j][1 % V] = x[1]; v[j][2 % V] = x[2]; v[j][3 % V] = x[3];
+        } else {
 #pragma unroll
-            for (int e = 0; e < V; ++e) v[j][e] = e < valid ? p[e] : 0.f;
-          }
+          for (int e = 0; e < V; ++e) v[j][e] = (on && e < valid) ? p[e] : 0.f;
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-          for (int e = 0; e < V; ++e) a[e] += v[j][e];
       }
-      for (; s < ksplit; s += SG) {
-        const float* p = src + (int64_t)s * slab;
 #pragma unroll
-        for (int e = 0; e < V; ++e) a[e] += e < valid ? p[e] : 0.f;
-      }
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] += v[j][e];
     }
-    if (SG > 1) {
+    if (sg_log > 0) {
       __syncthreads();
 #pragma unroll
-      for (int e = 0; e < V; ++e) red[g][ol * V + e] = a[e];
+      for (int e = 0; e < V; ++e) red[g * rstride + ol * V + e] = a[e];
       __syncthreads();
       if (g == 0) {
 #pragma unroll
         for (int e = 0; e < V; ++e) {
           float r = 0.f;
-#pragma unroll
-          for (int q = 0; q < SG; ++q) r += red[q][ol * V + e];
+          for (int q = 0; q < SG; ++q) r += red[q * rstride + ol * V + e];
           a[e] = r;
         }
       }
@@ -392,10 +401,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, int 
   }
 }
 
+constexpr int RED_LDS = 256 * 4 + 64;       // floats: SG rows of (OPB*V + 1)
+
+template <int V>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs A, const int sg_log) {
+  __shared__ float red[RED_LDS];
+  reduce_body<V>(A, sg_log, blockIdx.x, gridDim.x, red);
+}
+
+// Every pending slab reduction of a backward segment in one launch.  block -> job: the first_block column is
+// staged in LDS with one load per thread (njobs <= 256 per launch), then scanned.
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const RedJob* __restrict__ jobs, const int njobs) {
+  __shared__ float red[RED_LDS];
+  __shared__ int first[256];
+  if ((int)threadIdx.x < njobs) first[threadIdx.x] = jobs[threadIdx.x].first_block;
+  __syncthreads();
+  int lo = 0;
+  for (int j = 1; j < njobs; ++j) if (first[j] <= (int)blockIdx.x) lo = j;
+  lo = __builtin_amdgcn_readfirstlane(lo);
+  const RedJob& J = jobs[lo];
+  const int blk = blockIdx.x - J.first_block, nblk = J.nblocks;
+  if (J.flags & 1) reduce_body<4>(J.a, J.flags >> 4, blk, nblk, red);
+  else reduce_body<1>(J.a, J.flags >> 4, blk, nblk, red);
+}
+
 thread_local char* g_wname_out = nullptr;      // name-query mode: report the kernel instance, launch nothing
 thread_local int g_wname_cap = 0;
 thread_local int32_t* g_plan_ks = nullptr;     // planning mode: report ksplit / workspace bytes, launch nothing
 thread_local int64_t* g_plan_bytes = nullptr;
+thread_local RedJob* g_job_out = nullptr;      // job-capture mode: describe the slab reduction, launch nothing
 
 template <typename T, int TH, int TW, int KH, int KW, int S, int WCI, int WCO, int FCI, int FCO>
 int launch_cfg(const WgK& P0, hipStream_t st) {
@@ -449,26 +483,30 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
     return SEG_OK;
   }
   if (g_plan_ks) { *g_plan_ks = ks; *g_plan_bytes = P.direct ? 0 : P.slab * ks * 4; return SEG_OK; }
+  if (g_job_out && P.direct) { g_job_out->nblocks = 0; return SEG_OK; }
   if (!P.direct && (!P.d.ws || P.d.ws_bytes < P.slab * ks * 4)) { seg_set_error("wgrad: workspace too small (%lld < %lld bytes)", (long long)P.d.ws_bytes, (long long)(P.slab * ks * 4)); return SEG_ERR_ARG; }
   int rc = SEG_OK;
-  if (P.d.phase != 2) {
+  if (P.d.phase != 2 && !g_job_out) {
     if (rs) SEG_LAUNCH(k1, dim3(base, ks, KH), dim3(256), LDS, st, P);
     else SEG_LAUNCH(k0, dim3(base, ks, 1), dim3(256), LDS, st, P);
     rc = seg_check_launch("conv_wgrad");
   }
-  if (rc || P.direct || P.d.phase == 1) return rc;
+  if (rc || P.direct || (P.d.phase == 1 && !g_job_out)) return rc;
   const int taps = KH * KW, k_log = P.d.src0_clog + P.d.src1_clog;
   const bool v4 = (P.d.n_log % 4 == 0) && (P.n_pad % 4 == 0);
   const int V = v4 ? 4 : 1;
   const int64_t units = (int64_t)taps * k_log * (P.d.n_log / V) + (P.d.bias_mode ? (P.d.bias_n + V - 1) / V : 0);
-  const bool par = ks > 8;
-  int rg = (int)((units + (par ? 15 : 255)) / (par ? 16 : 256)); if (rg > 8192) rg = 8192;
-#define RED_ARGS P.d.ws, ks, P.slab, taps, P.k_pad, P.n_pad, P.d.src0_clog, P.d.src0.c, P.d.src1_clog, P.d.n_log, P.d.dw, P.d.bias_mode, P.d.bias_n, P.d.db
-  if (v4 && par) SEG_LAUNCH((wgrad_reduce_kernel<4, 16>), dim3(rg), dim3(256), 0, st, RED_ARGS);
-  else if (v4) SEG_LAUNCH((wgrad_reduce_kernel<4, 1>), dim3(rg), dim3(256), 0, st, RED_ARGS);
-  else if (par) SEG_LAUNCH((wgrad_reduce_kernel<1, 16>), dim3(rg), dim3(256), 0, st, RED_ARGS);
-  else SEG_LAUNCH((wgrad_reduce_kernel<1, 1>), dim3(rg), dim3(256), 0, st, RED_ARGS);
-#undef RED_ARGS
+  // split groups: one 8-deep load batch per thread whenever ksplit <= 256 (sg = ceil(ks/8) rounded up to a power of two)
+  int sg_log = 0;
+  while ((8 << sg_log) < ks && sg_log < 5) ++sg_log;
+  const int opb = 256 >> sg_log;
+  int rg = (int)((units + opb - 1) / opb); if (rg > 16384) rg = 16384;
+  RedArgs RA;
+  RA.ws = P.d.ws; RA.dw = P.d.dw; RA.db = P.d.db; RA.slab = P.slab; RA.ksplit = ks; RA.taps = taps; RA.k_pad = P.k_pad; RA.n_pad = P.n_pad;
+  RA.seg0_c = P.d.src0_clog; RA.seg0_cp = P.d.src0.c; RA.seg1_c = P.d.src1_clog; RA.n_log = P.d.n_log; RA.bias_mode = P.d.bias_mode; RA.bias_n = P.d.bias_n;
+  if (g_job_out) { g_job_out->a = RA; g_job_out->nblocks = rg; g_job_out->flags = (v4 ? 1 : 0) | (sg_log << 4); g_job_out->first_block = 0; g_job_out->pad_ = 0; return SEG_OK; }
+  if (v4) SEG_LAUNCH((wgrad_reduce_kernel<4>), dim3(rg), dim3(256), 0, st, RA, sg_log);
+  else SEG_LAUNCH((wgrad_reduce_kernel<1>), dim3(rg), dim3(256), 0, st, RA, sg_log);
   return seg_check_launch("wgrad_reduce");
 }
 
@@ -556,4 +594,34 @@ extern "C" int seg_conv2d_wgrad(const seg_wgrad_desc* dp, void* stream) {
   if (d.dtype == SEG_BF16) return launch_t<bf16_t>(P, st);
   seg_set_error("wgrad: bad dtype %d", d.dtype);
   return SEG_ERR_ARG;
+}
+
+/* Batched slab reduction: describe the reductions of n wgrad descriptors (already planned: ws / ksplit set) as
+ * 96-byte job records in host memory; the caller copies them to the device once and replays the launch. */
+extern "C" int seg_wgrad_reduce_batch_plan(const seg_wgrad_desc* const* descs, int32_t n, void* jobs_host, int64_t cap_bytes,
+                                           int32_t* njobs, int32_t* total_blocks) {
+  if (!descs || !jobs_host || !njobs || !total_blocks || n < 0) { seg_set_error("reduce_batch_plan: bad arguments"); return SEG_ERR_ARG; }
+  RedJob* out = reinterpret_cast<RedJob*>(jobs_host);
+  int nj = 0, blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (nj >= 256) { seg_set_error("reduce_batch_plan: more than 256 jobs in one batch"); return SEG_ERR_ARG; }
+    if ((int64_t)(nj + 1) * (int64_t)sizeof(RedJob) > cap_bytes) { seg_set_error("reduce_batch_plan: job buffer too small"); return SEG_ERR_ARG; }
+    RedJob j = RedJob();
+    g_job_out = &j;
+    const int rc = seg_conv2d_wgrad(descs[i], nullptr);
+    g_job_out = nullptr;
+    if (rc) return rc;
+    if (j.nblocks <= 0) continue;                 // ksplit == 1: the wgrad stored its result directly
+    j.first_block = blocks; blocks += j.nblocks;
+    out[nj++] = j;
+  }
+  *njobs = nj; *total_blocks = blocks;
+  return SEG_OK;
+}
+
+extern "C" int seg_wgrad_reduce_batch(const void* jobs_dev, int32_t njobs, int32_t total_blocks, void* stream) {
+  if (njobs <= 0 || total_blocks <= 0) return SEG_OK;
+  if (!jobs_dev) { seg_set_error("reduce_batch: null job table"); return SEG_ERR_ARG; }
+  SEG_LAUNCH(wgrad_reduce_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const RedJob*>(jobs_dev), njobs);
+  return seg_check_launch("wgrad_reduce_batch");
 }

@@ -6,6 +6,7 @@ provides device memory, streams and torch.distributed here -- every arithmetic o
 of libseg_hip.so.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -178,9 +179,20 @@ class Plan(object):
                     L.check(rc, '%s/%s' % (self.name, name))
             return
         main = torch.cuda.current_stream()
-        used, rr = {}, 0
+        used = {}
         aux = side[-1]                   # dedicated stream for side='aux' ops (weight re-pack), joined by a 'join_aux' marker
         aux_used = False
+        defer = os.environ.get('SEG_DEFER_SIDE', '0') != '0'
+        pending = []
+
+        def flush():
+            for ev_, st_, fn_, args_, name_ in pending:
+                st_.wait_event(ev_)
+                rc_ = fn_(*args_, C.c_void_p(st_.cuda_stream))
+                if rc_ != 0:
+                    L.check(rc_, '%s/%s' % (self.name, name_))
+            del pending[:]
+
         for i, (name, fn, args) in enumerate(self.ops):
             tag = self.meta[i].get('side', 0)
             if fn is None:               # marker: make the main stream wait for the aux stream
@@ -193,16 +205,25 @@ class Plan(object):
                 aux_used = True
                 rc = fn(*args, C.c_void_p(aux.cuda_stream))
             elif tag:
-                if not self.meta[i].get('follow', 0):
-                    rr += 1
-                st = side[rr % (len(side) - 1)] if len(side) > 1 else side[0]
-                ev = torch.cuda.Event(); ev.record(main); st.wait_event(ev)
+                # side stream ids are assigned when the plan is built (Net._add_wgrad alternates 1, 2): a filter
+                # gradient and the batched reduction of its slabs are then in order on ONE stream
+                st = side[(tag - 1) % (len(side) - 1)] if len(side) > 1 else side[0]
+                ev = torch.cuda.Event(); ev.record(main)
                 used[id(st)] = st
+                if defer:
+                    # same dependencies, but the side launch is ISSUED after the next main-stream launch: under capture
+                    # the main-stream successor then is the first child of its predecessor (graph order)
+                    pending.append((ev, st, fn, args, name))
+                    continue
+                st.wait_event(ev)
                 rc = fn(*args, C.c_void_p(st.cuda_stream))
             else:
                 rc = fn(*args, sp)
+                if rc == 0 and pending:
+                    flush()
             if rc != 0:
                 L.check(rc, '%s/%s' % (self.name, name))
+        flush()
         if aux_used:
             used[id(aux)] = aux
         for st in used.values():
@@ -234,7 +255,7 @@ class Plan(object):
         main = torch_mod.cuda.current_stream()
         E_ = lambda: torch_mod.cuda.Event(enable_timing=True)
         recs = []
-        used, rr, aux_used = {}, 0, False
+        used, aux_used = {}, False
         aux = side[-1] if side else None
         for i, (name, fn, args) in enumerate(self.ops):
             tag = self.meta[i].get('side', 0) if side else 0
@@ -245,9 +266,7 @@ class Plan(object):
             if tag == 'aux':
                 st = aux; aux_used = True
             elif tag:
-                if not self.meta[i].get('follow', 0):
-                    rr += 1
-                st = side[rr % (len(side) - 1)] if len(side) > 1 else side[0]
+                st = side[(tag - 1) % (len(side) - 1)] if len(side) > 1 else side[0]
                 used[id(st)] = st
             else:
                 st = main
@@ -275,6 +294,13 @@ class Net(object):
         self.lib = L.load()
         self.store, self.B, self.dtype, self.device = store, B, dtype, device
         self.acts = []
+        # slab reductions of the filter gradients: one launch per layer right behind its wgrad (default: best under
+        # hipGraph replay), or batched into one launch per side stream and backward segment (models turn this on for
+        # eager execution, where it saves a quarter of the launches; SEG_BATCH_REDUCE=0/1 overrides)
+        self.batch_reduce = os.environ.get('SEG_BATCH_REDUCE', '0') != '0'
+        self._pending_reduce = {}
+        self.n_wgrad_streams = 2
+        self._wg_rr = 0
 
     def act(self, H, W, C, f32=False, name=''):
         a = Act(self.B, H, W, C, self.dtype, self.device, f32=f32, name=name)
@@ -355,20 +381,44 @@ class Net(object):
         self.ws_bytes = getattr(self, 'ws_bytes', 0) + nbytes.value
         plan.keep += [w, ws]
 
-    def _add_wgrad(self, plan, name, w, fl, follow=False):
+    def _add_wgrad(self, plan, name, w, fl):
         """One plan op for the partial-sum kernel and, when K is split, a second one for the slab reduction (same side
         stream): two C-ABI calls so that each kernel is timed on its own."""
-        meta = {'follow': 1} if follow else {}
-        if w.ksplit > 1:
+        sid = 1 + self._wg_rr % self.n_wgrad_streams        # side stream of this layer's filter gradient
+        self._wg_rr += 1
+        if w.ksplit > 1 and self.batch_reduce:
+            w.phase = 1
+            self._pending_reduce.setdefault(sid, []).append(w)
+            plan.add(name, self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=sid)
+        elif w.ksplit > 1:
             w.phase = 1
             w2 = L.WgradDesc.from_buffer_copy(w)
             w2.phase = 2
             plan.keep.append(w2)
-            plan.add(name, self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=1, **meta)
-            plan.add(name + '/reduce', self.lib.seg_conv2d_wgrad, C.byref(w2), kernel='wgrad_reduce_kernel', side=1, follow=1)
+            plan.add(name, self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=sid)
+            plan.add(name + '/reduce', self.lib.seg_conv2d_wgrad, C.byref(w2), kernel='wgrad_reduce_kernel', side=sid)
         else:
             w.phase = 0
-            plan.add(name, self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=1, **meta)
+            plan.add(name, self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=sid)
+
+    def flush_reduce(self, plan):
+        """Reduces the slabs of every filter gradient emitted since the last flush: one launch per side stream (each
+        stream reduces its own layers, so the launch is simply in order behind them).  Call it where the gradients are
+        first needed -- the end of a backward segment (all-reduce / Adam)."""
+        pending, self._pending_reduce = self._pending_reduce, {}
+        for sid in sorted(pending):
+            ws = pending[sid]
+            n = len(ws)
+            arr = (C.POINTER(L.WgradDesc) * n)(*[C.pointer(w) for w in ws])
+            host = (C.c_uint8 * (96 * n))()
+            nj, nb = C.c_int32(0), C.c_int32(0)
+            L.check(self.lib.seg_wgrad_reduce_batch_plan(arr, n, C.cast(host, C.c_void_p), 96 * n, C.byref(nj), C.byref(nb)), 'reduce_batch_plan')
+            if nj.value == 0:
+                continue
+            jobs = torch.frombuffer(bytearray(host), dtype=torch.uint8)[:96 * nj.value].clone().to(self.device)
+            plan.keep += [jobs, arr]
+            plan.add('dw/reduce[%d]' % nj.value, self.lib.seg_wgrad_reduce_batch, jobs.data_ptr(), nj.value, nb.value,
+                     kernel='wgrad_reduce_batch_kernel', side=sid)
 
     def first_im2col(self, plan, layer, x_f32, H, W):
         """im2col of the raw input (27 -> 32 channels) for the first layer's filter gradient.  It depends only on the

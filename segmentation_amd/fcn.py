@@ -10,6 +10,8 @@ final map is crop-or-padded to the input size.  `fcn16s` crops with (pool4_h, po
 MI355X design: the [k,k,C,C] bilinear bank is channel-diagonal, so the transposed conv runs as a depthwise
 kernel (21x fewer MACs than the dense form TF executes) fused with the crop/pad and the skip addition.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -155,6 +157,9 @@ class FCNModel(BaseModel):
     def _build_training(self):
         B, (H, W) = self.batch_size, self.input_dims
         net = self.net = E.Net(self.store, B, self.dtype, self.device)
+        net.n_wgrad_streams = max(1, len(self._side) - 1) if self._side else 1
+        if 'SEG_BATCH_REDUCE' not in os.environ:
+            net.batch_reduce = not self.use_graph
         Ly, nc = self.store.layers, self.n_classes
         fwd = self.fwd_plan = E.Plan('fwd')
         net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1
@@ -209,6 +214,7 @@ class FCNModel(BaseModel):
         dP = {5: act_like(A['pool5'], 'dpool5')}
         net.conv_bwd(seg, Ly['conv6'], [(A['pool5'], 0, 0)], fr.H, fr.W, dz6, [(dP[5], (0, 0), None, (0, 0))])
         l = Ly['conv6']
+        net.flush_reduce(seg)
         segs.append((seg, l.b_off + l.cout))
         seg = E.Plan('bwd1')
         for i in (5, 4, 3, 2, 1):
@@ -225,6 +231,7 @@ class FCNModel(BaseModel):
             dP[i - 1] = shared if shared is not None else act_like(pin, 'dpool%d' % (i - 1))
             net.conv_bwd(seg, Ly[name], [(pin, 0, 0)], pin.H, pin.W, dz, [(dP[i - 1], (0, 0), None, (0, 0), shared is not None)])
         l = Ly['conv1']
+        net.flush_reduce(seg)
         segs.append((seg, l.b_off + l.cout))
         self._finish_training_plans(segs)
         self.y_hat = A['logits']

@@ -11,6 +11,8 @@ offsets); conv1_2 is evaluated only on the window that survives the crop when cr
 (bit-identical results, fewer MACs -- bench.py reports MACs actually executed); ReLU-grad masks are
 fused into the producing dgrad epilogues and the crop-grad zero-pad + add into the max-pool backward.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -183,6 +185,9 @@ class UNetModel(BaseModel):
     def _build_training(self):
         B, (H, W) = self.batch_size, self.input_dims
         net = self.net = E.Net(self.store, B, self.dtype, self.device)
+        net.n_wgrad_streams = max(1, len(self._side) - 1) if self._side else 1
+        if 'SEG_BATCH_REDUCE' not in os.environ:
+            net.batch_reduce = not self.use_graph
         Ly = self.store.layers
         fwd = self.fwd_plan = E.Plan('fwd')
         net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1_1
@@ -214,6 +219,7 @@ class UNetModel(BaseModel):
         def close_segment(last_layer):
             nonlocal seg
             l = Ly[last_layer]
+            net.flush_reduce(seg)             # one slab-reduction launch per segment
             segs.append((seg, l.b_off + l.cout))
             seg = E.Plan('bwd%d' % len(segs))
 

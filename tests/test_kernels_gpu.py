@@ -92,6 +92,7 @@ def test_conv_fwd_bwd(dtype, case):
     store.g.zero_()
     bplan = E.Plan('b')
     net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs)
+    net.flush_reduce(bplan)
     bplan.run(U.stream()); U.sync()
     dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (k, k), padding, 1)
     dx_ref = ops.conv2d_dgrad(dzv, p['c']['weights'], (H, W), padding, 1)
@@ -129,7 +130,7 @@ def test_upconv_fwd_bwd(dtype, case):
     dz = net.act(2 * H, 2 * W, cout); U.fill_act(dz, dzv)
     dx = net.act(H, W, cin)
     store.g.zero_()
-    bplan = E.Plan('b'); net.up_bwd(bplan, layer, xa, H, W, dz, dx, xa); bplan.run(U.stream()); U.sync()
+    bplan = E.Plan('b'); net.up_bwd(bplan, layer, xa, H, W, dz, dx, xa); net.flush_reduce(bplan); bplan.run(U.stream()); U.sync()
     dw_ref, db_ref = ops.conv2d_transpose_wgrad(xv, dzv, (2, 2), 2, 'VALID')
     dx_ref = ops.conv2d_transpose_dgrad(dzv, p['u']['weights'], (H, W), 2, 'VALID') * (xv > 0)
     g = store.get_grads()['u']
@@ -159,7 +160,7 @@ def test_conv_first(dtype, pad, cin, cout, H):
         dzv = U.round_dtype(rng.standard_normal((B, Ho, Wo, cout)), dtype)
         dz = net.act(Ho, Wo, cout); U.fill_act(dz, dzv)
         store.g.zero_()
-        bp = E.Plan('b'); net.first_bwd(bp, layer, xt, H, W, dz); bp.run(U.stream()); U.sync()
+        bp = E.Plan('b'); net.first_bwd(bp, layer, xt, H, W, dz); net.flush_reduce(bp); bp.run(U.stream()); U.sync()
         dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (3, 3), layer.padding, 1)
         g = store.get_grads()['f']
         # bf16 mode rounds the im2col'd input to bf16 (the MFMA operand type)
@@ -229,6 +230,36 @@ def test_softmax_xent_and_sigmoid_argmax(dtype, nc):
     assert np.array_equal(sig.cpu().numpy(), sref)          # bit-exact float32 sigmoid
     assert np.array_equal(out.cpu().numpy(), oref)          # bit-exact argmax incl. saturated ties
     assert out[0, 0, 0, 0].item() == 0.0
+
+
+def test_batched_slab_reduction_is_bitwise_the_per_layer_one():
+    """seg_wgrad_reduce_batch (one launch for several layers) vs phase-2 launches per layer: identical bits,
+    including layers whose wgrad stores directly (ksplit 1) and ragged channel counts (scalar form)."""
+    dtype = L.SEG_BF16
+    rng = np.random.default_rng(99)
+    specs = [('a', 3, [32], 64, 40), ('b', 3, [64], 64, 38), ('c', 3, [24], 10, 21), ('d', 3, [512], 512, 6), ('e', 1, [64], 4, 30)]
+    layers = [E.Layer(n, 'conv', k, segs, cout, 'VALID', True) for n, k, segs, cout, H in specs]
+    p = {l.name: _rand_params(l, rng, dtype) for l in layers}
+    store = U.make_store(layers, dtype, p)
+    B = 3
+    got = []
+    for batched in (True, False):
+        net = E.Net(store, B, dtype, U.dev())
+        net.batch_reduce = batched
+        rs = np.random.default_rng(5)
+        plan = E.Plan('b')
+        for l, (n, k, segs, cout, H) in zip(layers, specs):
+            x = net.act(H, H, segs[0]); U.fill_act(x, rs.standard_normal((B, H, H, segs[0])))
+            dz = net.act(H - k + 1, H - k + 1, cout); U.fill_act(dz, rs.standard_normal((B, H - k + 1, H - k + 1, cout)))
+            net.conv_bwd(plan, l, [(x, 0, 0)], H, H, dz, [None])
+        net.flush_reduce(plan)
+        names = [o[0] for o in plan.ops]
+        assert any(n.startswith('dw/reduce[') for n in names) == batched
+        store.g.fill_(float('nan'))
+        plan.run(U.stream()); U.sync()
+        assert bool(torch.isfinite(store.g).all())
+        got.append(store.g.clone())
+    assert torch.equal(got[0], got[1])
 
 
 def test_adam_matches_tf_variant():

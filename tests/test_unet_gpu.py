@@ -96,8 +96,9 @@ def test_unet_graph_replay_equals_eager():
     torch.cuda.synchronize()
     assert m2.global_step == 4 and int(m2.store.step.item()) == 4
     assert abs(m1.last_loss() - m2.last_loss()) < 1e-4
-    # wgrad uses f32 atomics -> summation order differs run to run; compare to round-off
-    assert torch.allclose(m1.store.p, m2.store.p, atol=2e-4)
+    # slab reductions have a fixed summation order (no atomics): eager (batched reductions) and graph replay
+    # (per-layer reductions) produce the same bits
+    assert torch.equal(m1.store.p, m2.store.p)
 
 
 def test_unet_infer_matches_oracle_and_argmax_rule():
