@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--per-op', action='store_true', help='also print the per-op table to stderr')
+    ap.add_argument('--streams', type=int, default=2, help='side streams for the filter gradients (0 = everything on one stream)')
     ap.add_argument('--host-data', action='store_true', help='feed from host memory through the pinned-buffer prefetcher (PCIe-inclusive rate; not the headline value)')
     return ap.parse_args()
 
@@ -123,7 +124,7 @@ def main():
     if args.model == 'unet':
         model = UNetModel(sess=None, dataset=ds, n_classes=args.classes, input_dims=args.size, learning_rate=1e-4,
                           log_dir=None, save_dir=None, load_snapshot=False, n_kernels=args.nk,
-                          dtype=args.dtype, use_graph=not args.no_graph, crop_aware=not args.dense, seed=5555)
+                          dtype=args.dtype, use_graph=not args.no_graph, crop_aware=not args.dense, seed=5555, wgrad_streams=args.streams)
     else:
         from segmentation_amd.fcn import FCNModel
         model = FCNModel(sess=None, dataset=ds, n_classes=args.classes, input_dims=args.size, learning_rate=1e-4, fcn_type='8s',

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['conv_fwd.hip', 'conv_wgrad.hip', 'conv_first.hip', 'elementwise.hip']
 LIB = os.path.join(HERE, 'libseg_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result'] + os.environ.get('SEG_EXTRA_FLAGS', '').split()
 
 
 def _stale():

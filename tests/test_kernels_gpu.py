@@ -36,6 +36,18 @@ def _rand_params(layer, rng, dtype):
     (3, 'VALID', [64], 32, 10, 10, 2, False, 14),
     (3, 'VALID', [64, 32], 64, 35, 37, 2, True, 15),
     (3, 'SAME', [64], 64, 19, 33, 1, True, 15),
+    (3, 'VALID', [64], 64, 21, 19, 2, True, 51),          # weight-stationary persistent kernel (fwd + dgrad)
+    (3, 'SAME', [32], 64, 13, 35, 3, True, 51),
+    (3, 'VALID', [32, 32], 32, 20, 20, 2, True, 52),
+    (3, 'SAME', [64, 64], 32, 9, 40, 1, False, 52),
+    (3, 'VALID', [32], 32, 130, 130, 8, True, 52),        # > 768 tiles: every workgroup walks several tiles
+    (3, 'VALID', [160], 32, 21, 19, 1, True, 32),         # N-stage direct-to-LDS rings: 5 K chunks, 3 / 4 stages
+    (3, 'VALID', [96, 64], 64, 13, 15, 2, True, 33),
+    (3, 'SAME', [192], 32, 10, 10, 2, False, 34),
+    (3, 'VALID', [64], 32, 10, 10, 2, False, 34),         # fewer chunks than stages
+    (3, 'VALID', [160], 32, 21, 19, 1, True, 42),
+    (3, 'VALID', [96, 64], 32, 9, 12, 2, True, 44),
+    (1, 'SAME', [256], 32, 9, 9, 2, True, 44),
     (3, 'SAME', [64], 96, 9, 11, 2, True, 0),
     (3, 'VALID', [64, 32], 64, 12, 12, 2, True, 0),
     (3, 'VALID', [16], 24, 11, 11, 1, True, 0),          # unpadded channel counts (n_kernels=16 style)
@@ -91,7 +103,8 @@ def test_conv_fwd_bwd(dtype, case):
         dsrc_acts.append(da)
     store.g.zero_()
     bplan = E.Plan('b')
-    net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs)
+    dcfg = 0 if cfg < 50 else (cfg if all(c % 64 == 0 for c in layer.cin_p) or cfg == 52 else 52)
+    net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs, cfg=dcfg)
     net.flush_reduce(bplan)
     bplan.run(U.stream()); U.sync()
     dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (k, k), padding, 1)
