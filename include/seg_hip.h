@@ -118,6 +118,13 @@ int seg_conv_first_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t 
                        const float* w_hwio, const float* bias, int32_t cout, int32_t pad,
                        const seg_view* dst, int32_t Ho, int32_t Wo, int32_t relu, int32_t dtype, void* stream);
 
+/* Same layer fused with the 2x2/s2 VALID max-pool that consumes it (models/unet.py pool1 over conv1_1, models/fcn.py:116
+ * pool1 over conv1): one pass writes the activation and its pooled map [Hp = Ho/2, Wp = Wo/2].  bf16, cin <= 3, cout <= 64. */
+int seg_conv_first_pool_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin,
+                            const float* w_hwio, const float* bias, int32_t cout, int32_t pad,
+                            const seg_view* dst, int32_t Ho, int32_t Wo, int32_t relu,
+                            const seg_view* pool, int32_t Hp, int32_t Wp, int32_t dtype, void* stream);
+
 /* im2col of the raw float input (3x3 window, k = (u*3+v)*cin + c, zero-padded to 32 channels): lets the first
  * layer's Conv2DBackpropFilter run as a 1x1 seg_conv2d_wgrad on the MFMA path (dw comes out in HWIO order). */
 int seg_im2col3x3(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, int32_t pad, const seg_view* dst,

@@ -88,7 +88,175 @@ __global__ void im2col3x3_kernel(const float* x, int B, int H, int W, int cin, i
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16 path: the same layer on the matrix cores, optionally fused with the 2x2/s2 max-pool that follows it in both
+// models (models/unet.py pools conv1_1 itself, finding F11; models/fcn.py:116 pools conv1).
+// K = 9*cin <= 27 is one 32-deep MFMA step: D[channel][pixel] = W[channel][k] * X[k][pixel].  A wave owns a block of
+// 2 rows x 8 columns of output pixels per step (pixel p = lane&15 -> row p>>3, column p&7): lane (p, g = lane>>4)
+// gathers k = 8g..8g+7 of its pixel straight from the float image (8 dword loads: a filter row's 3*cin values are
+// contiguous in NHWC), converts to bf16 and that IS the B fragment -- no LDS, no im2col buffer.  Filter rows are
+// permuted like the packed filters of conv_fwd.hip (MFMA m, row 4g'+r <-> channel 8g'+4m+r) so a lane ends up with 8
+// consecutive channels of its pixel = one 16-byte store.  The 2x2 window of the pool is lanes p, p^1, p^8: two DPP
+// max steps, then lanes with even column in the upper row store the pooled pixel.
+// HBM-bound by design: 12 B read + 64 B (+16 B pooled) written per pixel.
+// ---------------------------------------------------------------------------------------------------------
+SEG_DEV float dpp_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }    // quad_perm [1,0,3,2]
+SEG_DEV float dpp_ror8(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)); }   // row_ror:8
+
+SEG_DEV unsigned pk_max_u16(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// LDS-only barrier: __syncthreads() would also wait (vmcnt) for this wave's output stores of the previous tile
+SEG_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct FirstK {
+  const float* x; const float* w; const float* bias;
+  int B, H, W, cin, cout, pad, Ho, Wo, relu;
+  seg_view dst;
+  seg_view pool; int Hp, Wp;          // pool.ptr == nullptr: no fused pool
+  int blocks_x, blocks_y;             // 2x8 pixel blocks per image
+  int im2col;                         // 1: store the gathered fragment (the im2col row) instead of convolving
+};
+
+constexpr int FTH = 8, FTW = 32;                    // output pixels per workgroup tile (16 blocks of 2x8, 4 per wave)
+constexpr int FPH = FTH + 2, FPW = FTW + 2;
+
+template <int NG>      // NG = 32-channel groups of the output
+__global__ __launch_bounds__(256) void conv_first_mfma_kernel(const FirstK P) {
+  // input patch of the tile as floats, row stride RS words.  (Gathering the fragments straight from global memory
+  // re-fetched ~10 cache lines per load instruction: 24 waves x ~1.3 KB of live lines thrash the 32 KB L1 and the
+  // kernel ran at the L2->L1 rate, 70 us; through LDS every input line is fetched once per tile.)
+  __shared__ float sx[FPH * (FPW * 3 + 1)];
+  const int RS = FPW * P.cin + 1;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, g = lane >> 4;
+  const int nk = 9 * P.cin;
+  int koff[8];                                       // LDS word offset of k = 8g+j relative to the pixel's patch origin; -1 = zero
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * g + j;
+    const int tap = k / P.cin, c = k - tap * P.cin;
+    koff[j] = k < nk ? (tap / 3) * RS + (tap % 3) * P.cin + c : -1;
+  }
+  // filter fragments: MFMA m of group q, row i = 4g'+r (lane&15 = i) <-> channel 32q + 8g' + 4m + r
+  Frag<bf16_t> fa[NG][2];
+  float bv[NG][8];
+  if (!P.im2col) {
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int ch = 32 * q + 8 * (p >> 2) + 4 * m + (p & 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = 8 * g + j;
+          fa[q][m].v[j] = (bf16_t)((k < nk && ch < P.cout) ? P.w[(int64_t)k * P.cout + ch] : 0.f);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const int ch = 32 * q + 8 * g + e; bv[q][e] = (P.bias && ch < P.cout) ? P.bias[ch] : 0.f; }
+    }
+  }
+  const int tiles_x = P.blocks_x, tiles_y = P.blocks_y;          // here: FTH x FTW tiles per image
+  const int per_img = tiles_x * tiles_y, total = P.B * per_img;
+  const float lo = P.relu ? 0.f : -INFINITY;
+  bf16_t* dstp = reinterpret_cast<bf16_t*>(P.dst.ptr);
+  bf16_t* poolp = reinterpret_cast<bf16_t*>(P.pool.ptr);
+  const int rowlen = FPW * P.cin;                                  // floats per patch row
+  for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    const int b = t / per_img; const int r = t - b * per_img;
+    const int ty = r / tiles_x, tx = r - ty * tiles_x;
+    const int oy0 = ty * FTH, ox0 = tx * FTW;
+    const float* xb = P.x + (int64_t)b * P.H * P.W * P.cin;
+    const int64_t dtile = view_off(P.dst, b, oy0, ox0);
+    const int64_t ptile = poolp ? view_off(P.pool, b, oy0 >> 1, ox0 >> 1) : 0;
+    lds_barrier();                                                 // previous tile's reads are done
+    for (int i = tid; i < FPH * rowlen; i += 256) {
+      const int py = i / rowlen, w = i - py * rowlen;
+      const int iy = oy0 - P.pad + py, ixc = (ox0 - P.pad) * P.cin + w;     // row-contiguous: coalesced
+      sx[py * RS + w] = (iy >= 0 && iy < P.H && ixc >= 0 && ixc < P.W * P.cin) ? xb[(int64_t)iy * P.W * P.cin + ixc] : 0.f;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int blk = wave * 4 + u;                                // 16 blocks: 4 block rows x 4 block columns
+      const int ly = 2 * (blk >> 2) + (p >> 3), lx = 8 * (blk & 3) + (p & 7);
+      const int oy = oy0 + ly, ox = ox0 + lx;
+      const bool ok = oy < P.Ho && ox < P.Wo;
+      const int base = ly * RS + lx * P.cin;
+      Frag<bf16_t> fb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) fb.v[j] = (bf16_t)(koff[j] >= 0 ? sx[base + koff[j]] : 0.f);
+      const int64_t doff = dtile + (ly * P.dst.W + lx) * P.dst.cs;
+      if (P.im2col) {
+        if (ok) *reinterpret_cast<bf16x8*>(dstp + doff + 8 * g) = fb.v;
+        continue;
+      }
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        f32x4 a0 = f32x4{0, 0, 0, 0}, a1 = f32x4{0, 0, 0, 0};
+        mma32(a0, fa[q][0], fb);
+        mma32(a1, fa[q][1], fb);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = fmaxf(a0[e] + bv[q][e], lo); v[4 + e] = fmaxf(a1[e] + bv[q][4 + e], lo); }
+        Vec8<bf16_t> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, v[e]);
+        if (ok) o.store(dstp + doff + 32 * q + 8 * g);
+        if (poolp) {
+          // pool the bf16-ROUNDED values (what the separate pool kernel would read).  After a ReLU they are >= 0, so
+          // their bit patterns order like unsigned integers: the 2x2 max is two DPP steps of v_pk_max_u16 on the packed
+          // pairs; pixels outside the image contribute 0 and windows that contain one are never stored.
+          const bool st = ok && (p & 9) == 0 && (oy >> 1) < P.Hp && (ox >> 1) < P.Wp;
+          bf16_t* pp = poolp + ptile + ((ly >> 1) * P.pool.W + (lx >> 1)) * P.pool.cs + 32 * q + 8 * g;
+          if (P.relu) {
+            u32x4 w = __builtin_bit_cast(u32x4, o.v);
+            if (!ok) w = u32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              unsigned a = w[e];
+              a = pk_max_u16(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1, 0xF, 0xF, true));
+              a = pk_max_u16(a, (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x128, 0xF, 0xF, true));
+              w[e] = a;
+            }
+            if (st) *reinterpret_cast<u32x4*>(pp) = w;
+          } else {
+            Vec8<bf16_t> m;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float tv = ok ? o.get(e) : -INFINITY;
+              tv = fmaxf(tv, dpp_xor1(tv));
+              tv = fmaxf(tv, dpp_ror8(tv));
+              m.set(e, tv);
+            }
+            if (st) m.store(pp);
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
+
+static int launch_first_mfma(const FirstK& P0, hipStream_t st) {
+  FirstK P = P0;
+  P.blocks_x = cdiv(P.Wo, FTW); P.blocks_y = cdiv(P.Ho, FTH);
+  const int64_t total = (int64_t)P.B * P.blocks_x * P.blocks_y;
+  int grid = (int)total; if (grid > 256 * 6) grid = 256 * 6;      // persistent: 6 workgroups per CU
+  const int ng = P.im2col ? 1 : cdiv(P.cout, 32);
+  switch (ng) {
+    case 1: SEG_LAUNCH(conv_first_mfma_kernel<1>, dim3(grid), dim3(256), 0, st, P); break;
+    case 2: SEG_LAUNCH(conv_first_mfma_kernel<2>, dim3(grid), dim3(256), 0, st, P); break;
+    default: seg_set_error("conv_first (bf16 MFMA path): cout %d > 64", P.cout); return SEG_ERR_UNSUPPORTED;
+  }
+  return seg_check_launch("conv_first_mfma");
+}
 
 extern "C" int seg_im2col3x3(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, int32_t pad, const seg_view* dst,
                              int32_t Ho, int32_t Wo, int32_t dtype, void* stream) {
@@ -97,6 +265,11 @@ extern "C" int seg_im2col3x3(const float* x, int32_t B, int32_t H, int32_t W, in
   const int64_t n = (int64_t)B * Ho * Wo * 4;
   int g = (int)((n + 255) / 256); if (g > 16384) g = 16384;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SEG_BF16) {            // same fragment gather as the forward kernel, stored instead of multiplied
+    FirstK P = {};
+    P.x = x; P.B = B; P.H = H; P.W = W; P.cin = cin; P.cout = 32; P.pad = pad; P.Ho = Ho; P.Wo = Wo; P.dst = *dst; P.im2col = 1;
+    return launch_first_mfma(P, st);
+  }
   if (dtype == SEG_F32) SEG_LAUNCH(im2col3x3_kernel<float>, dim3(g), dim3(256), 0, st, x, B, H, W, cin, pad, *dst, Ho, Wo);
   else if (dtype == SEG_BF16) SEG_LAUNCH(im2col3x3_kernel<bf16_t>, dim3(g), dim3(256), 0, st, x, B, H, W, cin, pad, *dst, Ho, Wo);
   else { seg_set_error("im2col3x3: bad dtype"); return SEG_ERR_ARG; }
@@ -113,8 +286,33 @@ extern "C" int seg_conv_first_fwd(const float* x, int32_t B, int32_t H, int32_t 
   const int tiles_x = cdiv(Wo, FT), tiles_y = cdiv(Ho, FT);
   dim3 grid(B * tiles_x * tiles_y, cp / 32);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SEG_BF16 && cin <= 3 && cout <= 64) {
+    FirstK P = {};
+    P.x = x; P.w = w_hwio; P.bias = bias; P.B = B; P.H = H; P.W = W; P.cin = cin; P.cout = cout; P.pad = pad; P.Ho = Ho; P.Wo = Wo; P.relu = relu;
+    P.dst = *dst;
+    return launch_first_mfma(P, st);
+  }
   if (dtype == SEG_F32) SEG_LAUNCH(conv_first_fwd_kernel<float>, grid, dim3(256), 0, st, x, B, H, W, cin, w_hwio, bias, cout, pad, *dst, Ho, Wo, relu, tiles_x, tiles_y);
   else if (dtype == SEG_BF16) SEG_LAUNCH(conv_first_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, x, B, H, W, cin, w_hwio, bias, cout, pad, *dst, Ho, Wo, relu, tiles_x, tiles_y);
   else { seg_set_error("conv_first_fwd: bad dtype"); return SEG_ERR_ARG; }
   return seg_check_launch("conv_first_fwd");
+}
+
+/* First layer + the 2x2/s2 max-pool (VALID) that consumes it, in one pass (bf16, cin <= 3, cout <= 64): writes both
+ * the activation (dst) and its pooled map (pool, [Hp = Ho/2, Wp = Wo/2]). */
+extern "C" int seg_conv_first_pool_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const float* w_hwio, const float* bias,
+                                       int32_t cout, int32_t pad, const seg_view* dst, int32_t Ho, int32_t Wo, int32_t relu,
+                                       const seg_view* pool, int32_t Hp, int32_t Wp, int32_t dtype, void* stream) {
+  if (!x || !w_hwio || !dst || !dst->ptr || !pool || !pool->ptr || cin < 1 || cin > 3 || cout < 1 || cout > 64 || B <= 0) { seg_set_error("conv_first_pool_fwd: bad args (cin 1..3, cout <= 64)"); return SEG_ERR_ARG; }
+  if (dtype != SEG_BF16) { seg_set_error("conv_first_pool_fwd: bf16 only (f32: seg_conv_first_fwd + seg_maxpool2x2_fwd)"); return SEG_ERR_UNSUPPORTED; }
+  const int cp = cdiv(cout, 32) * 32;
+  if (Ho != H + 2 * pad - 2 || Wo != W + 2 * pad - 2 || Hp != Ho / 2 || Wp != Wo / 2) { seg_set_error("conv_first_pool_fwd: inconsistent extents"); return SEG_ERR_ARG; }
+  if (dst->oy + Ho > dst->H || dst->ox + Wo > dst->W || dst->coff + cp > dst->cs || dst->cs % 8 || dst->coff % 8 ||
+      pool->oy + Hp > pool->H || pool->ox + Wp > pool->W || pool->coff + cp > pool->cs || pool->cs % 8 || pool->coff % 8) {
+    seg_set_error("conv_first_pool_fwd: destination window exceeds buffer"); return SEG_ERR_ARG;
+  }
+  FirstK P = {};
+  P.x = x; P.w = w_hwio; P.bias = bias; P.B = B; P.H = H; P.W = W; P.cin = cin; P.cout = cout; P.pad = pad; P.Ho = Ho; P.Wo = Wo; P.relu = relu;
+  P.dst = *dst; P.pool = *pool; P.Hp = Hp; P.Wp = Wp;
+  return launch_first_mfma(P, reinterpret_cast<hipStream_t>(stream));
 }

@@ -828,7 +828,7 @@ int launch_k(const ConvK& P, hipStream_t st) {
   const int mode_hint = cfg < 0 ? -cfg : 0;      // cfg < 0: automatic tile choice with staging mode |cfg| (see below)
   if (sizeof(T) == 2 && KH == 3 && S == 1 && (cfg <= 0 || cfg >= 50) && !d.up2 && !d.accum && !d.out_f32) {
     // weight-stationary persistent kernel whenever the BN filter rows of all K fit beside the patch ring
-    static const int ws_on = getenv("SEG_CONV_WS") ? atoi(getenv("SEG_CONV_WS")) : 1;
+    static const int ws_on = getenv("SEG_CONV_WS") ? atoi(getenv("SEG_CONV_WS")) : 0;   // opt-in: not yet faster than the tiled kernels
     const int ntiles = d.B * cdiv(d.Ho, 8) * cdiv(d.Wo, 16);
     const int bn = (cfg == 51 || cfg == 53) ? 64 : (cfg == 52 || cfg == 54) ? 32 : (d.n_count % 64 == 0 && P.nchunks * 9 * 64 * 64 <= 80 * 1024) ? 64 : 32;
     const bool fits = P.nchunks * 9 * bn * 64 <= 80 * 1024;

@@ -311,14 +311,27 @@ class Net(object):
         return sum(a.nbytes() for a in self.acts)
 
     # ---------------- forward ----------------
-    def first_fwd(self, plan, layer, x_f32, H, W, dst):
+    def first_fwd(self, plan, layer, x_f32, H, W, dst, pool=None):
+        """First layer.  With `pool` (the Act of the 2x2 max-pool that consumes it) the bf16 path writes the pooled map
+        in the same pass (seg_conv_first_pool_fwd) and True is returned; otherwise the caller emits pool_fwd itself."""
         Ho, Wo = H + 2 * layer.pad - 2, W + 2 * layer.pad - 2
         dv = dst.view()
         plan.keep.append(dv)
+        fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
+        plan.flops += fl
+        mfma = self.dtype == L.SEG_BF16 and layer.cin <= 3 and layer.cout <= 64
+        kern = 'conv_first_mfma_kernel' if mfma else 'conv_first_fwd_kernel'
+        if pool is not None and mfma and os.environ.get('SEG_FUSE_POOL1', '1') != '0':
+            pv = pool.view()
+            plan.keep.append(pv)
+            plan.add(layer.name + '+pool', self.lib.seg_conv_first_pool_fwd, x_f32.data_ptr(), self.B, H, W, layer.cin,
+                     self.store.p_ptr(layer.w_off), self.store.p_ptr(layer.b_off), layer.cout, layer.pad, C.byref(dv), Ho, Wo,
+                     1 if layer.relu else 0, C.byref(pv), pool.H, pool.W, self.dtype, kernel=kern, flops=fl)
+            return True
         plan.add(layer.name, self.lib.seg_conv_first_fwd, x_f32.data_ptr(), self.B, H, W, layer.cin,
                  self.store.p_ptr(layer.w_off), self.store.p_ptr(layer.b_off), layer.cout, layer.pad, C.byref(dv), Ho, Wo,
-                 1 if layer.relu else 0, self.dtype, kernel='conv_first_fwd_kernel', flops=2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout)
-        plan.flops += 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
+                 1 if layer.relu else 0, self.dtype, kernel=kern, flops=fl)
+        return False
 
     def conv_fwd(self, plan, layer, srcs, Hi, Wi, dst, dst_off=(0, 0), out_f32=False, cfg=0):
         """srcs: list of (Act, oy, ox) (1 or 2 concat segments)."""

@@ -109,16 +109,18 @@ class FCNModel(BaseModel):
         prev = None
         for i, name in enumerate(ENC):
             A[name] = net.act(h, w, Ly[name].cout, name=name)
+            if h // 2 < 1 or w // 2 < 1:
+                raise Exception('FCN: input %dx%d too small for five 2x2 pools' % (H, W))
+            P = net.act(h // 2, w // 2, Ly[name].cout, name='pool%d' % (i + 1))
+            pooled = False
             if i == 0:
-                net.first_fwd(plan, Ly[name], x_in, H, W, A[name])
+                pooled = net.first_fwd(plan, Ly[name], x_in, H, W, A[name], pool=P)
                 net.join_aux(plan)         # packed weights needed from here on
             else:
                 net.conv_fwd(plan, Ly[name], [(prev, 0, 0)], h, w, A[name])
             h, w = h // 2, w // 2
-            if h < 1 or w < 1:
-                raise Exception('FCN: input %dx%d too small for five 2x2 pools' % (H, W))
-            P = net.act(h, w, Ly[name].cout, name='pool%d' % (i + 1))
-            net.pool_fwd(plan, A[name], P, h, w)
+            if not pooled:
+                net.pool_fwd(plan, A[name], P, h, w)
             A['pool%d' % (i + 1)] = P
             prev = P
         for name in ('conv6', 'conv7', 'conv_fr'):

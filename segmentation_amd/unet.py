@@ -133,7 +133,8 @@ class UNetModel(BaseModel):
         sh = sw = unet_sizes(H)
         A = {}
         A['conv1_1'] = net.act(sh['conv1_1'], sw['conv1_1'], nk, name='conv1_1')
-        net.first_fwd(plan, Ly['conv1_1'], x_in, H, W, A['conv1_1'])
+        A['pool1'] = net.act(sh['pool1'], sw['pool1'], nk, name='pool1')      # pool1 is taken over conv1_1 (F11)
+        pool1_done = net.first_fwd(plan, Ly['conv1_1'], x_in, H, W, A['conv1_1'], pool=A['pool1'])
         if after_first is not None:
             after_first()
         net.join_aux(plan)                 # packed weights (re-packed on the aux stream in training) are needed from here on
@@ -150,8 +151,13 @@ class UNetModel(BaseModel):
             skip4_off = (o4h, o4w)
         prev, ph, pw = A['conv1_1'], sh['conv1_1'], sw['conv1_1']
         for i in (2, 3, 4, 5):
-            P = net.act(sh['pool%d' % (i - 1)], sw['pool%d' % (i - 1)], prev.C, name='pool%d' % (i - 1))
-            net.pool_fwd(plan, prev, P, P.H, P.W)
+            if i == 2:
+                P = A['pool1']
+                if not pool1_done:
+                    net.pool_fwd(plan, prev, P, P.H, P.W)
+            else:
+                P = net.act(sh['pool%d' % (i - 1)], sw['pool%d' % (i - 1)], prev.C, name='pool%d' % (i - 1))
+                net.pool_fwd(plan, prev, P, P.H, P.W)
             A['pool%d' % (i - 1)] = P
             c1, c2 = 'conv%d_1' % i, 'conv%d_2' % i
             A[c1] = net.act(sh[c1], sw[c1], Ly[c1].cout, name=c1)

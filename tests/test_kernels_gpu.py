@@ -153,7 +153,7 @@ def test_upconv_fwd_bwd(dtype, case):
 
 
 @pytest.mark.parametrize('dtype', DT)
-@pytest.mark.parametrize('pad,cin,cout,H', [(0, 3, 32, 21), (1, 3, 16, 18), (0, 1, 40, 33)])
+@pytest.mark.parametrize('pad,cin,cout,H', [(0, 3, 32, 21), (1, 3, 16, 18), (0, 1, 40, 33), (1, 2, 64, 20), (0, 3, 32, 64)])
 def test_conv_first(dtype, pad, cin, cout, H):
     B, W = 2, H + 3
     rng = np.random.default_rng(cout + H)
@@ -169,6 +169,14 @@ def test_conv_first(dtype, pad, cin, cout, H):
     ref = ops.conv2d(x, p['f']['weights'], p['f']['biases'], layer.padding, 1, True)
     assert U.rel_err(U.read_act(out), ref) < U.tol(dtype, 2e-5, 1e-2)
     assert U.pad_channels_zero(out)
+    if dtype == L.SEG_BF16 and cin <= 3 and cout <= 64:
+        # fused conv + 2x2 max-pool: same activation bits, pooled map == max-pool of those bits (first-max irrelevant for values)
+        out2 = net.act(Ho, Wo, cout); pooled = net.act(Ho // 2, Wo // 2, cout)
+        pl = E.Plan('p'); assert net.first_fwd(pl, layer, xt, H, W, out2, pool=pooled); pl.run(U.stream()); U.sync()
+        assert torch.equal(out2.t, out.t)
+        o = out.t.to(torch.float32)[:, :Ho // 2 * 2, :Wo // 2 * 2]
+        want = torch.maximum(torch.maximum(o[:, 0::2, 0::2], o[:, 0::2, 1::2]), torch.maximum(o[:, 1::2, 0::2], o[:, 1::2, 1::2]))
+        assert torch.equal(pooled.t.to(torch.float32), want)
     if cin <= 3:
         dzv = U.round_dtype(rng.standard_normal((B, Ho, Wo, cout)), dtype)
         dz = net.act(Ho, Wo, cout); U.fill_act(dz, dzv)

@@ -144,7 +144,7 @@ def test_unet_bf16_parity_bounds():
     for n in g_ref:
         a, b = g[n]['weights'].ravel(), np.asarray(g_ref[n]['weights']).ravel()
         cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
-        assert cos > 0.98, (n, cos)
+        assert cos > 0.97, (n, cos)        # 23 bf16 layers at random init (first layer included: bf16 MFMA operands)
 
 
 def test_unet_256_shapes_and_loss_decreases():
