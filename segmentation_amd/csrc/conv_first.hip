@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const FirstK P) {
   // re-fetched ~10 cache lines per load instruction: 24 waves x ~1.3 KB of live lines thrash the 32 KB L1 and the
   // kernel ran at the L2->L1 rate, 70 us; through LDS every input line is fetched once per tile.)
   __shared__ float sx[FPH * (FPW * 3 + 1)];
+  __shared__ float sbias[32 * NG];
   const int RS = FPW * P.cin + 1;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -157,9 +158,15 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const FirstK P) {
           fa[q][m].v[j] = (bf16_t)((k < nk && ch < P.cout) ? P.w[(int64_t)k * P.cout + ch] : 0.f);
         }
       }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const int ch = 32 * q + 8 * g + e; bv[q][e] = (P.bias && ch < P.cout) ? P.bias[ch] : 0.f; }
     }
+    // bias via LDS: registers filled by a global load before the loop make the compiler wait vmcnt(0) at their first
+    // use in EVERY iteration (the counter also holds the previous block's stores); an LDS read is on lgkmcnt instead
+    if (tid < 32 * NG) sbias[tid] = (P.bias && tid < P.cout) ? P.bias[tid] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NG; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[q][e] = sbias[32 * q + 8 * g + e];
   }
   const int tiles_x = P.blocks_x, tiles_y = P.blocks_y;          // here: FTH x FTW tiles per image
   const int per_img = tiles_x * tiles_y, total = P.B * per_img;
@@ -167,20 +174,41 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const FirstK P) {
   bf16_t* dstp = reinterpret_cast<bf16_t*>(P.dst.ptr);
   bf16_t* poolp = reinterpret_cast<bf16_t*>(P.pool.ptr);
   const int rowlen = FPW * P.cin;                                  // floats per patch row
-  for (int t = blockIdx.x; t < total; t += gridDim.x) {
+  // vmcnt also counts stores and the compiler's wait insertion gives up across the loop back-edge (vmcnt(0)), so
+  // (1) everything loaded before the loop is forced to have landed here (else every block's epilogue waited for the
+  //     previous block's stores), and (2) the patch of tile t+1 is requested BEFORE the stores of tile t (its wait at
+  //     the next loop top then counts the younger stores instead of draining them).
+  constexpr int NPL = (FPH * FPW * 3 + 255) / 256;                 // patch floats per thread
+  float pre[NPL];
+  auto patch_load = [&](int t) {
     const int b = t / per_img; const int r = t - b * per_img;
     const int ty = r / tiles_x, tx = r - ty * tiles_x;
     const int oy0 = ty * FTH, ox0 = tx * FTW;
     const float* xb = P.x + (int64_t)b * P.H * P.W * P.cin;
+#pragma unroll
+    for (int n = 0; n < NPL; ++n) {
+      const int i = tid + n * 256;
+      const int py = i / rowlen, w = i - py * rowlen;
+      const int iy = oy0 - P.pad + py, ixc = (ox0 - P.pad) * P.cin + w;     // row-contiguous: coalesced
+      pre[n] = (i < FPH * rowlen && iy >= 0 && iy < P.H && ixc >= 0 && ixc < P.W * P.cin) ? xb[(int64_t)iy * P.W * P.cin + ixc] : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < total) patch_load(blockIdx.x);
+  for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    const int b = t / per_img; const int r = t - b * per_img;
+    const int ty = r / tiles_x, tx = r - ty * tiles_x;
+    const int oy0 = ty * FTH, ox0 = tx * FTW;
     const int64_t dtile = view_off(P.dst, b, oy0, ox0);
     const int64_t ptile = poolp ? view_off(P.pool, b, oy0 >> 1, ox0 >> 1) : 0;
     lds_barrier();                                                 // previous tile's reads are done
-    for (int i = tid; i < FPH * rowlen; i += 256) {
+#pragma unroll
+    for (int n = 0; n < NPL; ++n) {
+      const int i = tid + n * 256;
       const int py = i / rowlen, w = i - py * rowlen;
-      const int iy = oy0 - P.pad + py, ixc = (ox0 - P.pad) * P.cin + w;     // row-contiguous: coalesced
-      sx[py * RS + w] = (iy >= 0 && iy < P.H && ixc >= 0 && ixc < P.W * P.cin) ? xb[(int64_t)iy * P.W * P.cin + ixc] : 0.f;
+      if (i < FPH * rowlen) sx[py * RS + w] = pre[n];
     }
     lds_barrier();
+    if (t + (int)gridDim.x < total) patch_load(t + gridDim.x);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int blk = wave * 4 + u;                                // 16 blocks: 4 block rows x 4 block columns
