@@ -482,13 +482,6 @@ __device__ long long* g_stamps = nullptr;      // debug builds only: [workgroup]
 #define SEG_STAMP(row, idx) do { } while (0)
 #endif
 
-#ifdef SEG_STAMPS
-__device__ long long* g_stamps = nullptr;      // debug builds only: [workgroup][wave 0..4][3][32] s_memtime stamps
-#define SEG_STAMP(row, idx) do { if (stp && lane == 0 && (idx) < 32) stp[(row) * 32 + (idx)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define SEG_STAMP(row, idx) do { } while (0)
-#endif
-
 
 template <int TH, int TW, int BN, int WM, int WN, int NLOAD>
 __global__ __launch_bounds__(256 + 64 * NLOAD) void conv_ws_kernel(const ConvK P) {

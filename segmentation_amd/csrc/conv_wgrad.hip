@@ -25,6 +25,13 @@ struct WgK {
   int direct;                    // ksplit == 1: store straight into dw/db, no reduce pass
 };
 
+#ifdef SEG_STAMPS
+__device__ long long* g_wstamps = nullptr;     // debug builds only: [workgroup][4 rows][32] s_memtime stamps of wave 0
+#define WSTAMP(row, idx) do { if (wstp && (idx) < 32) wstp[(row) * 32 + (idx)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WSTAMP(row, idx) do { } while (0)
+#endif
+
 template <typename T> SEG_DEV Frag<T> ones_frag();
 template <> SEG_DEV Frag<bf16_t> ones_frag<bf16_t>() {
   Frag<bf16_t> f;
@@ -134,50 +141,88 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
     sz_off[i] = ((m / TW) * d.dz.W + (m % TW)) * d.dz.cs + h * EPP;
     sz_lds[i] = (BM * ZPIECES % 256 == 0 || idx < BM * ZPIECES) ? m * RSZ + h * 16 : -1;
   }
-  u32x4 rp[NPP], rz[NZP];
-  auto prefetch = [&](int tile) {
-    int t = tile;
-    const int tx = t % P.tiles_x; t /= P.tiles_x;
-    const int ty = t % P.tiles_y; const int b = t / P.tiles_y;
+  // Two staging sets = two tiles of global loads in flight.  The loads are inline asm and the waits are explicit
+  // (s_waitcnt vmcnt(N) with the set's registers tied to it): the compiler's own wait insertion cannot count across
+  // the loop back-edge and falls back to vmcnt(0), which would drain the other set's prefetch at every commit.
+  // Every load is issued unconditionally (clamped address; a bit mask remembers which pieces to zero), so each
+  // prefetch is exactly NLD wave-instructions and "the other set is younger" is vmcnt(NLD).
+  constexpr int NLD = NPP + NZP;
+  static_assert(NLD <= 60, "vmcnt range / mask bits");
+  constexpr bool DUAL = sizeof(T) == 2;              // f32 (parity mode) keeps one set: twice the registers per piece
+  u32x4 rpA[NPP], rzA[NZP], rpB[DUAL ? NPP : 1], rzB[DUAL ? NZP : 1];
+  uint64_t okA = 0, okB = 0;
+  auto gload = [&](u32x4& r, const T* ptr) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory"); };
+  // interior tiles: wave-uniform 64-bit base in SGPRs + the thread's constant 32-bit byte offset (no per-load 64-bit VALU)
+  auto gload_s = [&](u32x4& r, unsigned voff, uint64_t sbase) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory"); };
+  auto uniform64 = [&](const void* p) -> uint64_t {      // the pointer IS wave-uniform; make it so for the register allocator
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return ((uint64_t)hi << 32) | lo;
+  };
+  unsigned sp_boff[NPP], sz_boff[NZP];
+  uint64_t full = 0;                                    // pieces this thread owns at all (interior tiles: all valid)
+#pragma unroll
+  for (int i = 0; i < NPP; ++i) { sp_boff[i] = sp_lds[i] >= 0 ? (unsigned)sp_off[i] * ES : 0u; full |= (uint64_t)(sp_lds[i] >= 0 ? 1 : 0) << i; }
+#pragma unroll
+  for (int i = 0; i < NZP; ++i) { sz_boff[i] = sz_lds[i] >= 0 ? (unsigned)sz_off[i] * ES : 0u; full |= (uint64_t)(sz_lds[i] >= 0 ? 1 : 0) << (NPP + i); }
+  // tile coordinates advance incrementally (no divisions in the walk): a stride of `step` tiles = (sb_, sy_, sx_)
+  struct TileIt { int b, ty, tx; };
+  auto tile_decode = [&](int t) { TileIt it; it.tx = t % P.tiles_x; t /= P.tiles_x; it.ty = t % P.tiles_y; it.b = t / P.tiles_y; return it; };
+  auto tile_advance = [&](TileIt& it, const TileIt& st) {
+    it.tx += st.tx; if (it.tx >= P.tiles_x) { it.tx -= P.tiles_x; ++it.ty; }
+    it.ty += st.ty; if (it.ty >= P.tiles_y) { it.ty -= P.tiles_y; ++it.b; }
+    it.b += st.b;
+  };
+  auto prefetch = [&](const TileIt& it, u32x4 (&rp)[NPP], u32x4 (&rz)[NZP], uint64_t& okm) {
+    const int b = __builtin_amdgcn_readfirstlane(it.b), ty = __builtin_amdgcn_readfirstlane(it.ty), tx = __builtin_amdgcn_readfirstlane(it.tx);
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * S - d.pad_t, ix0 = ox0 * S - d.pad_l;
     const T* sb = srcp + (int64_t)b * sv.H * sv.W * sv.cs + sv.coff + cbase + ((int64_t)(iy0 + sv.oy) * sv.W + ix0 + sv.ox) * sv.cs;
     const T* zb = dzp + (int64_t)b * d.dz.H * d.dz.W * d.dz.cs + d.dz.coff + n0 + ((int64_t)(oy0 + d.dz.oy) * d.dz.W + ox0 + d.dz.ox) * d.dz.cs;
     const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + PH <= d.Hi && ix0 + PW <= d.Wi && oy0 + TH <= d.Ho && ox0 + TW <= d.Wo;
     if (interior) {
+      const uint64_t sbu = uniform64(sb), zbu = uniform64(zb);
 #pragma unroll
-      for (int i = 0; i < NPP; ++i) {
-        rp[i] = u32x4{0, 0, 0, 0};
-        if (sp_lds[i] >= 0) rp[i] = *reinterpret_cast<const u32x4*>(sb + sp_off[i]);
-      }
+      for (int i = 0; i < NPP; ++i) gload_s(rp[i], sp_boff[i], sbu);
 #pragma unroll
-      for (int i = 0; i < NZP; ++i) {
-        rz[i] = u32x4{0, 0, 0, 0};
-        if (sz_lds[i] >= 0) rz[i] = *reinterpret_cast<const u32x4*>(zb + sz_off[i]);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NPP; ++i) {
-        const int q = (tid + i * 256) / PPIECES;
-        const int iy = iy0 + q / PW, ix = ix0 + q % PW;
-        rp[i] = u32x4{0, 0, 0, 0};
-        if (sp_lds[i] >= 0 && iy >= 0 && iy < d.Hi && ix >= 0 && ix < d.Wi) rp[i] = *reinterpret_cast<const u32x4*>(sb + sp_off[i]);
-      }
-#pragma unroll
-      for (int i = 0; i < NZP; ++i) {
-        const int m = (tid + i * 256) / ZPIECES;
-        rz[i] = u32x4{0, 0, 0, 0};
-        if (sz_lds[i] >= 0 && oy0 + m / TW < d.Ho && ox0 + m % TW < d.Wo) rz[i] = *reinterpret_cast<const u32x4*>(zb + sz_off[i]);
-      }
+      for (int i = 0; i < NZP; ++i) gload_s(rz[i], sz_boff[i], zbu);
+      okm = full;
+      return;
     }
+    uint64_t m = 0;
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+      const int q = (tid + i * 256) / PPIECES;
+      const int iy = iy0 + q / PW, ix = ix0 + q % PW;
+      const bool ok = sp_lds[i] >= 0 && iy >= 0 && iy < d.Hi && ix >= 0 && ix < d.Wi;
+      m |= (uint64_t)(ok ? 1 : 0) << i;
+      gload(rp[i], ok ? sb + sp_off[i] : srcp);
+    }
+#pragma unroll
+    for (int i = 0; i < NZP; ++i) {
+      const int mm = (tid + i * 256) / ZPIECES;
+      const bool ok = sz_lds[i] >= 0 && oy0 + mm / TW < d.Ho && ox0 + mm % TW < d.Wo;
+      m |= (uint64_t)(ok ? 1 : 0) << (NPP + i);
+      gload(rz[i], ok ? zb + sz_off[i] : dzp);
+    }
+    okm = m;
   };
-  auto commit = [&]() {
+  // waits until this set's loads have landed; `younger` = the other set's prefetch was issued after them
+  auto wait_set = [&](u32x4 (&rp)[NPP], u32x4 (&rz)[NZP], bool younger) {
+    if (younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) asm volatile("" : "+v"(rp[i]));      // the registers are defined "here" for the compiler
+#pragma unroll
+    for (int i = 0; i < NZP; ++i) asm volatile("" : "+v"(rz[i]));
+  };
+  auto commit = [&](const u32x4 (&rp)[NPP], const u32x4 (&rz)[NZP], uint64_t okm) {
 #pragma unroll
     for (int i = 0; i < NPP; ++i)
-      if (sp_lds[i] >= 0) *reinterpret_cast<u32x4*>(sP + sp_lds[i]) = rp[i];
+      if (sp_lds[i] >= 0) *reinterpret_cast<u32x4*>(sP + sp_lds[i]) = ((okm >> i) & 1) ? rp[i] : u32x4{0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < NZP; ++i)
-      if (sz_lds[i] >= 0) *reinterpret_cast<u32x4*>(sZ + sz_lds[i]) = rz[i];
+      if (sz_lds[i] >= 0) *reinterpret_cast<u32x4*>(sZ + sz_lds[i]) = ((okm >> (NPP + i)) & 1) ? rz[i] : u32x4{0, 0, 0, 0};
   };
 
   // ---- per-lane fragment addresses ----
@@ -216,48 +261,109 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
     }
   };
 
-  int tile = blockIdx.y;
-  if (tile < P.ntiles) prefetch(tile);
-  for (; tile < P.ntiles; tile += P.ksplit) {
-    __syncthreads();
-    commit();
-    __syncthreads();
-    if (tile + P.ksplit < P.ntiles) prefetch(tile + P.ksplit);
-    // Software-pipelined over the flattened (K step, tap) sequence: the transposed LDS reads of step s+1 are issued
-    // before the MFMAs of step s (with one wave per SIMD nothing else hides the ~100-cycle LDS latency; measured:
-    // un-pipelined, the waves sat in s_waitcnt for >50 % of their lifetime).
+  // The tile walk is a serial chain (load -> LDS -> MFMA) and a workgroup is often alone on its CU (ksplit targets ~256
+  // workgroups), so TWO tiles of global loads are kept in flight in two register sets; the barriers are LDS-only
+  // (lgkmcnt + s_barrier): __syncthreads() would also drain vmcnt, i.e. wait for the prefetch just issued.
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto compute = [&]() {
+    // Software-pipelined over the flattened (K step, tap) sequence with the ORDER PINNED (sched_barrier per step):
+    // the transposed reads of step s+LA are issued before the MFMA(s) of step s.  Left to itself the scheduler
+    // batches reads far ahead (204 VGPRs -> 2 waves/SIMD) and still waits on LDS before most MFMAs.
     constexpr int NSTEP = KS * NT;
-    Frag<T> fx[2][FCI], fz[2][FCO];
+    constexpr int LA = 3;                                  // X fragments in flight (steps ahead)
+    constexpr int ZLA = NT >= LA ? 1 : LA;                 // dZ fragments in flight (K steps ahead)
+    Frag<T> fx[LA + 1][FCI], fz[ZLA + 1][FCO];
     const int rs_off = u0 * PW * RSP;
+    auto issue_x = [&](int st1) {
+      const int ks1 = st1 / NT, tap1 = st1 % NT;
 #pragma unroll
-    for (int c = 0; c < FCO; ++c) fz[0][c] = read_frag(sZ, za, z_ch + c * 16 * ES);
+      for (int a = 0; a < FCI; ++a)
+        fx[st1 % (LA + 1)][a] = read_frag(sP, pa[ks1], rs_off + ((tap1 / KW) * PW + tap1 % KW) * RSP + a_ch + a * 16 * ES);
+    };
+    auto issue_z = [&](int ks1) {
 #pragma unroll
-    for (int a = 0; a < FCI; ++a) fx[0][a] = read_frag(sP, pa[0], rs_off + a_ch + a * 16 * ES);
+      for (int c = 0; c < FCO; ++c) fz[ks1 % (ZLA + 1)][c] = read_frag(sZ, za, ks1 * 32 * RSZ + z_ch + c * 16 * ES);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < ZLA; ++i) if (i < KS) issue_z(i);
+#pragma unroll
+    for (int i = 0; i < LA; ++i) if (i < NSTEP) issue_x(i);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
       const int ks = st / NT, tap = st % NT;
-      if (st + 1 < NSTEP) {
-        const int ks1 = (st + 1) / NT, tap1 = (st + 1) % NT;
-        if (tap1 == 0) {
-#pragma unroll
-          for (int c = 0; c < FCO; ++c) fz[ks1 & 1][c] = read_frag(sZ, za, ks1 * 32 * RSZ + z_ch + c * 16 * ES);
-        }
-#pragma unroll
-        for (int a = 0; a < FCI; ++a)
-          fx[(st + 1) & 1][a] = read_frag(sP, pa[ks1], rs_off + ((tap1 / KW) * PW + tap1 % KW) * RSP + a_ch + a * 16 * ES);
-      }
+      if (st + LA < NSTEP) issue_x(st + LA);
+      if (tap == 0 && ks + ZLA < KS) issue_z(ks + ZLA);
       if (!B2 && tap == 0) {
 #pragma unroll
-        for (int c = 0; c < FCO; ++c) mma32(accb1[c], ones, fz[ks & 1][c]);
+        for (int c = 0; c < FCO; ++c) mma32(accb1[c], ones, fz[ks % (ZLA + 1)][c]);
       }
 #pragma unroll
       for (int a = 0; a < FCI; ++a) {
 #pragma unroll
-        for (int c = 0; c < FCO; ++c) mma32(acc[tap][a][c], fx[st & 1][a], fz[ks & 1][c]);
-        if (B2) mma32(accb2[a], fx[st & 1][a], ones);
+        for (int c = 0; c < FCO; ++c) mma32(acc[tap][a][c], fx[st % (LA + 1)][a], fz[ks % (ZLA + 1)][c]);
+        if (B2) mma32(accb2[a], fx[st % (LA + 1)][a], ones);
       }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  int tile = blockIdx.y;
+  const int ks_ = P.ksplit;
+#ifdef SEG_STAMPS
+  long long* wstp = (g_wstamps && blockIdx.x == 0 && blockIdx.z == 0 && blockIdx.y < 64 && tid == 0) ? g_wstamps + (int64_t)blockIdx.y * 128 : nullptr;
+  int it_ = 0;
+#endif
+  WSTAMP(3, 0);
+  TileIt itA = tile_decode(tile < P.ntiles ? tile : 0);
+  if (tile < P.ntiles) prefetch(itA, rpA, rzA, okA);
+  if constexpr (DUAL) {
+    const TileIt st2 = tile_decode(2 * ks_);            // each set strides by two splits
+    TileIt itB = tile_decode(tile + ks_ < P.ntiles ? tile + ks_ : 0);
+    bool youngerB = tile + ks_ < P.ntiles;              // set B was issued after the pending set A
+    if (youngerB) prefetch(itB, rpB, rzB, okB);
+    for (; tile < P.ntiles; tile += 2 * ks_) {
+      wait_set(rpA, rzA, youngerB);
+      WSTAMP(0, it_);
+      lds_barrier();                                     // previous tile's LDS reads are done
+      commit(rpA, rzA, okA);
+      lds_barrier();
+      WSTAMP(1, it_);
+      const bool moreA = tile + 2 * ks_ < P.ntiles;
+      if (moreA) { tile_advance(itA, st2); prefetch(itA, rpA, rzA, okA); }
+      WSTAMP(2, it_);
+      compute();
+#ifdef SEG_STAMPS
+      ++it_;
+#endif
+      if (tile + ks_ >= P.ntiles) break;
+      wait_set(rpB, rzB, moreA);
+      WSTAMP(0, it_);
+      lds_barrier();
+      commit(rpB, rzB, okB);
+      lds_barrier();
+      WSTAMP(1, it_);
+      youngerB = tile + 3 * ks_ < P.ntiles;
+      if (youngerB) { tile_advance(itB, st2); prefetch(itB, rpB, rzB, okB); }
+      WSTAMP(2, it_);
+      compute();
+#ifdef SEG_STAMPS
+      ++it_;
+#endif
+    }
+  } else {
+    const TileIt st1 = tile_decode(ks_);
+    for (; tile < P.ntiles; tile += ks_) {
+      wait_set(rpA, rzA, false);
+      lds_barrier();
+      commit(rpA, rzA, okA);
+      lds_barrier();
+      if (tile + ks_ < P.ntiles) { tile_advance(itA, st1); prefetch(itA, rpA, rzA, okA); }
+      compute();
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WSTAMP(3, 1);
 
   // ---- flush: D[row = ci][col = co]; lane: co = lr, ci = 4G + r ----
   // ksplit == 1: straight into the TF-layout gradient; else into this split's slab (plain stores).
@@ -625,3 +731,9 @@ extern "C" int seg_wgrad_reduce_batch(const void* jobs_dev, int32_t njobs, int32
   SEG_LAUNCH(wgrad_reduce_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const RedJob*>(jobs_dev), njobs);
   return seg_check_launch("wgrad_reduce_batch");
 }
+
+#ifdef SEG_STAMPS
+extern "C" int seg_dbg_set_wstamps(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_wstamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
