@@ -183,11 +183,16 @@ class Plan(object):
         aux = side[-1]                   # dedicated stream for side='aux' ops (weight re-pack), joined by a 'join_aux' marker
         aux_used = False
         defer = os.environ.get('SEG_DEFER_SIDE', '0') != '0'
+        batch = int(os.environ.get('SEG_SIDE_BATCH', '0'))     # > 0: fork the side streams once per `batch` main launches
         pending = []
+        since = 0
 
         def flush():
+            ev1 = None
+            if batch > 0 and pending:
+                ev1 = torch.cuda.Event(); ev1.record(main)      # one fork point for everything queued (later = still a valid dependency)
             for ev_, st_, fn_, args_, name_ in pending:
-                st_.wait_event(ev_)
+                st_.wait_event(ev1 if ev1 is not None else ev_)
                 rc_ = fn_(*args_, C.c_void_p(st_.cuda_stream))
                 if rc_ != 0:
                     L.check(rc_, '%s/%s' % (self.name, name_))
@@ -208,8 +213,11 @@ class Plan(object):
                 # side stream ids are assigned when the plan is built (Net._add_wgrad alternates 1, 2): a filter
                 # gradient and the batched reduction of its slabs are then in order on ONE stream
                 st = side[(tag - 1) % (len(side) - 1)] if len(side) > 1 else side[0]
-                ev = torch.cuda.Event(); ev.record(main)
                 used[id(st)] = st
+                if batch > 0:
+                    pending.append((None, st, fn, args, name))
+                    continue
+                ev = torch.cuda.Event(); ev.record(main)
                 if defer:
                     # same dependencies, but the side launch is ISSUED after the next main-stream launch: under capture
                     # the main-stream successor then is the first child of its predecessor (graph order)
@@ -220,7 +228,9 @@ class Plan(object):
             else:
                 rc = fn(*args, sp)
                 if rc == 0 and pending:
-                    flush()
+                    since += 1
+                    if batch <= 0 or since >= batch:
+                        flush(); since = 0
             if rc != 0:
                 L.check(rc, '%s/%s' % (self.name, name))
         flush()

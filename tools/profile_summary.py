@@ -18,7 +18,7 @@ def pretty(name):
             m = re.match(r'(.*)', mm.group(1)); args = re.findall(r'Li(\d+)E', mm.group(2)); kname = mm.group(1)
         else:
             k = re.search(r'(\w+_kernel)', name)
-            return k.group(1) if k else name[:48]
+            return re.sub(r'^_ZN\d+_GLOBAL__N_1\d+', '', k.group(1)) if k else name[:48]
     else:
         kname = m.group(1); args = [a.strip() for a in m.group(2).split(',')]
     if kname != 'conv_fwd_glds_kernel':
