@@ -173,6 +173,10 @@ int seg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, 
              float eps, float grad_scale, const int64_t* step_dev, void* stream);
 /* global_step assign_add 1: models/basemodel.py:88-89,368. */
 int seg_step_increment(int64_t* step_dev, void* stream);
+/* The same assign_add folded into the START of a train step, together with zeroing the loss accumulator (one tiny
+ * launch on the auxiliary stream instead of two on the critical path): step2 = {global_step, completed}:
+ * completed := global_step; global_step += 1; *loss_sum = 0.  seg_adam is then given &step2[1] (t = completed + 1). */
+int seg_step_begin(int64_t* step2_dev, float* loss_sum, void* stream);
 
 /* Weight re-layout (+cast) from the fp32 TF-layout master copy into the packed MFMA operand layout
  * [taps][K/32][n_total][32].  One launch handles a whole table of layers. */

@@ -68,6 +68,7 @@ SIGNATURES = {
     'seg_bias_grad': [PV, i32, i32, i32, i32, vp, i32, vp],
     'seg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp],
     'seg_step_increment': [vp, vp],
+    'seg_step_begin': [vp, vp, vp],
     'seg_pack_weights': [vp, vp, vp, i32, i64, i32, vp],
     'seg_bilinear_up_fwd': [PV, i32, i32, i32, vp, PV, PV, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     'seg_bilinear_up_bwd': [PV, i32, i32, i32, i32, i32, vp, PV, i32, i32, i32, i32, i32, i32, vp],

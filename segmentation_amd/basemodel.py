@@ -179,7 +179,8 @@ class BaseModel(object):
 
     def _run_fwd_bwd(self):
         s = self._stream()
-        self.loss_buf.zero_()              # gradients need no zeroing: every entry is overwritten by its wgrad launch
+        # loss accumulator and global_step are handled by the plan's first op (step_begin, aux stream); gradients need no
+        # zeroing: every entry is overwritten by its wgrad launch
         self.fwd_plan.run(s, self._side)
         self.bwd_plan.run(s, self._side)
 
@@ -230,7 +231,6 @@ class BaseModel(object):
         s = self._stream()
 
         def head():
-            self.loss_buf.zero_()
             self.fwd_plan.run(self._stream(), self._side)
             self.bwd_segments[0][0].run(self._stream(), self._side)
         self._replay('dp0', head)
@@ -261,7 +261,7 @@ class BaseModel(object):
         ds = self.test_dataset if self.test_dataset is not None else self.dataset
         self._load_batch(ds, self.input_x, self.input_y)
         self.loss_buf.zero_()
-        self.fwd_plan.run(self._stream())
+        self.fwd_plan.run(self._stream(), skip=('step_begin',))     # a test pass does not advance global_step
         self.last_test_loss = float(self.loss_buf.item())
         print('TEST LOSS', self.last_test_loss, self.global_step)
         self.write_summary({'test_loss': self.last_test_loss})
@@ -294,7 +294,7 @@ class BaseModel(object):
             self.store.m.copy_(torch.from_numpy(z['m']))
             self.store.v.copy_(torch.from_numpy(z['v']))
         self._gs_host = int(z['global_step'])
-        self.store.step.fill_(self._gs_host)
+        self.store.step.fill_(self._gs_host)          # both counters: nothing is in flight here
         self._repack()
 
     def _repack(self):

@@ -316,6 +316,10 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_
   }
 }
 __global__ void step_inc_kernel(int64_t* s) { if (threadIdx.x == 0 && blockIdx.x == 0) *s += 1; }
+// start of a train step: step2[1] = completed steps so far (what seg_adam reads, t = step2[1] + 1), step2[0] = t; loss = 0
+__global__ void step_begin_kernel(int64_t* s, float* loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { const int64_t t0 = s[0]; s[1] = t0; s[0] = t0 + 1; if (loss) *loss = 0.f; }
+}
 
 // ------------------------------------------------------------------------------------------
 // weight packing: fp32 TF layout -> [taps][K/32][n_total][32] (rows permuted inside each
@@ -568,6 +572,12 @@ extern "C" int seg_adam(float* p, const float* g, float* m, float* v, int64_t n,
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) { seg_set_error("adam: arenas must be 16-byte aligned"); return SEG_ERR_ARG; }
   SEG_LAUNCH(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, b1, b2, eps, grad_scale, step_dev);
   return seg_check_launch("adam");
+}
+
+extern "C" int seg_step_begin(int64_t* step2_dev, float* loss_sum, void* stream) {
+  if (!step2_dev) { seg_set_error("step_begin: null"); return SEG_ERR_ARG; }
+  SEG_LAUNCH(step_begin_kernel, dim3(1), dim3(64), 0, ST(stream), step2_dev, loss_sum);
+  return seg_check_launch("step_begin");
 }
 
 extern "C" int seg_step_increment(int64_t* step_dev, void* stream) {

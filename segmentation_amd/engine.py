@@ -79,7 +79,7 @@ class ParamStore(object):
             self.g = torch.zeros(off, dtype=torch.float32, device=device)
             self.m = torch.zeros(off, dtype=torch.float32, device=device)
             self.v = torch.zeros(off, dtype=torch.float32, device=device)
-        self.step = torch.zeros(1, dtype=torch.int64, device=device)
+        self.step = torch.zeros(2, dtype=torch.int64, device=device)     # [global_step, steps completed before the current one]
         # packed arena + table
         entries, poff, blk = [], 0, 0
         for l in layers:
@@ -164,7 +164,7 @@ class Plan(object):
         self.ops.append((name, fn, args))
         self.meta.append(meta)
 
-    def run(self, stream, side=None):
+    def run(self, stream, side=None, skip=()):
         """Launches every op in order.  Ops tagged side=1 (filter gradients: nothing on the backward critical path
         consumes them) go round-robin onto the `side` torch streams; each first waits for an event recorded on the
         main stream at its program position (so everything launched before it is its dependency) and the side
@@ -172,7 +172,7 @@ class Plan(object):
         sp = C.c_void_p(stream)
         if not side:
             for name, fn, args in self.ops:
-                if fn is None:
+                if fn is None or name in skip:
                     continue
                 rc = fn(*args, sp)
                 if rc != 0:
@@ -200,6 +200,8 @@ class Plan(object):
 
         for i, (name, fn, args) in enumerate(self.ops):
             tag = self.meta[i].get('side', 0)
+            if name in skip:
+                continue
             if fn is None:               # marker: make the main stream wait for the aux stream
                 if aux_used:
                     ev = torch.cuda.Event(); ev.record(aux); main.wait_event(ev)
@@ -621,5 +623,12 @@ class Net(object):
     def adam(self, plan, lr, grad_scale=1.0, b1=0.9, b2=0.999, eps=1e-8):
         s = self.store
         plan.add('adam', self.lib.seg_adam, s.p.data_ptr(), s.g.data_ptr(), s.m.data_ptr(), s.v.data_ptr(), s.n, lr, b1, b2, eps,
-                 grad_scale, s.step.data_ptr(), kernel='adam_kernel')
-        plan.add('step++', self.lib.seg_step_increment, s.step.data_ptr(), kernel='step_inc_kernel')
+                 grad_scale, s.step.data_ptr() + 8, kernel='adam_kernel')
+
+    def step_begin(self, plan, loss_buf, aux=True):
+        """global_step += 1 and loss accumulator = 0, first thing of a training forward (auxiliary stream: off the
+        critical path; nothing before the loss kernel / Adam reads either)."""
+        meta = {'kernel': 'step_begin_kernel'}
+        if aux:
+            meta['side'] = 'aux'
+        plan.add('step_begin', self.lib.seg_step_begin, self.store.step.data_ptr(), loss_buf.data_ptr(), **meta)

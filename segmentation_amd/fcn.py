@@ -164,13 +164,14 @@ class FCNModel(BaseModel):
             net.batch_reduce = not self.use_graph
         Ly, nc = self.store.layers, self.n_classes
         fwd = self.fwd_plan = E.Plan('fwd')
+        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+        net.step_begin(fwd, self.loss_buf)     # aux stream: global_step += 1, loss accumulator = 0
         net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1
         col = net.first_im2col(fwd, Ly['conv1'], self.input_x, H, W)         # side stream, overlaps the forward pass
         A, geo = self._emit_forward(net, fwd, self.input_x, H, W)
         self.acts = A
         self.out_hw = (H, W)
         self.label_off = (0, 0)
-        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
         dlog = net.act(H, W, nc, name='dlogits')
         net.softmax_xent(fwd, A['logits'], self.input_y, H, W, (0, 0), H, W, nc, self.loss_buf, dlog)
         self.dlogits = dlog

@@ -196,6 +196,8 @@ class UNetModel(BaseModel):
             net.batch_reduce = not self.use_graph
         Ly = self.store.layers
         fwd = self.fwd_plan = E.Plan('fwd')
+        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+        net.step_begin(fwd, self.loss_buf)     # aux stream: global_step += 1, loss accumulator = 0
         net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1_1
         cols = []       # im2col of the input for conv1_1's filter gradient: side stream, right after conv1_1 (both are
         #                 bandwidth-bound), overlapping the rest of the forward pass
@@ -205,7 +207,6 @@ class UNetModel(BaseModel):
         self.acts = A
         oh, ow = sh['output'], sw['output']
         self.out_hw = (oh, ow)
-        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
         dlog = net.act(oh, ow, self.n_classes, name='dlogits')
         # label crop: resize_image_with_crop_or_pad(input_y, target, target) -> floor offsets (unet.py:171-174)
         self.label_off = ((H - oh) // 2, (W - ow) // 2)

@@ -82,7 +82,7 @@ def test_snapshot_restore_roundtrip(tmp_path):
     m.train_step(); m.train_step(); m.snapshot(); m.test()
     assert m.last_test_loss is not None
     m2 = UNetModel(dataset=ArrayDataSet(x, y), save_dir=str(tmp_path / 'snap'), load_snapshot=True, **kw)
-    assert m2.global_step == 2 and int(m2.store.step.item()) == 2
+    assert m2.global_step == 2 and int(m2.store.step[0].item()) == 2
     assert torch.equal(m.store.p, m2.store.p) and torch.equal(m.store.m, m2.store.m)
     m.train_step(); m2.train_step()
     torch.cuda.synchronize()

@@ -290,14 +290,16 @@ def test_adam_matches_tf_variant():
     p0, g0 = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
     p = torch.from_numpy(p0.copy()).to(U.dev()); g = torch.from_numpy(g0).to(U.dev())
     m = torch.zeros(n, device=U.dev()); v = torch.zeros(n, device=U.dev())
-    step = torch.zeros(1, dtype=torch.int64, device=U.dev())
+    step = torch.zeros(2, dtype=torch.int64, device=U.dev())      # {global_step, completed}; Adam reads &step[1]
+    loss = torch.full((1,), 7.0, device=U.dev())
     pr, mr, vr = p0.astype(np.float64), np.zeros(n), np.zeros(n)
     for t in (1, 2, 3):
-        L.check(lib.seg_adam(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.5, step.data_ptr(), U.stream()))
-        L.check(lib.seg_step_increment(step.data_ptr(), U.stream()))
+        L.check(lib.seg_step_begin(step.data_ptr(), loss.data_ptr(), U.stream()))
+        L.check(lib.seg_adam(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.5, step.data_ptr() + 8, U.stream()))
         pr, mr, vr = ops.adam_tf(pr, g0.astype(np.float64) * 0.5, mr, vr, t, lr=1e-3)
+    L.check(lib.seg_step_increment(step.data_ptr() + 8, U.stream()))      # the stand-alone assign_add still works
     U.sync()
-    assert int(step.item()) == 3
+    assert step.tolist() == [3, 3] and float(loss.item()) == 0.0
     assert np.allclose(p.cpu().numpy(), pr, atol=1e-6)
     assert np.allclose(m.cpu().numpy(), mr, atol=1e-6) and np.allclose(v.cpu().numpy(), vr, atol=1e-7)
 

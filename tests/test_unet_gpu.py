@@ -77,7 +77,7 @@ def test_unet_f32_train_steps_match_oracle_adam():
     for t in (1, 2):
         l, pr, mm, vv = ounet.train_step(pr, mm, vv, t, x[t - 1], y[t - 1], lr=1e-3)
         ref_losses.append(l)
-    assert m.global_step == 2 and int(m.store.step.item()) == 2
+    assert m.global_step == 2 and int(m.store.step[0].item()) == 2
     assert np.allclose(losses, ref_losses, atol=2e-5)
     got = m.store.get_params()
     for n in pr:
@@ -94,7 +94,7 @@ def test_unet_graph_replay_equals_eager():
     for _ in range(4):          # eager warm-up, capture, then two replays
         m1.train_step(); m2.train_step()
     torch.cuda.synchronize()
-    assert m2.global_step == 4 and int(m2.store.step.item()) == 4
+    assert m2.global_step == 4 and int(m2.store.step[0].item()) == 4
     assert abs(m1.last_loss() - m2.last_loss()) < 1e-4
     # slab reductions have a fixed summation order (no atomics): eager (batched reductions) and graph replay
     # (per-layer reductions) produce the same bits

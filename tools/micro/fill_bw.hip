@@ -10,7 +10,7 @@ __device__ __forceinline__ void glds16(const void* g, char* l) {
 }
 // pattern 0: contiguous 1 KiB per instruction; 1: 16 pixels x 64 B at 128-B stride (half lines); 2: 8 pixels x 128 B (full lines, 2 pixel rows apart every 18)
 template <int DEPTH, int MODE>
-__global__ __launch_bounds__(256) void fill(const char* src, size_t bytes_per_wg, int iters, int pattern, unsigned* sink) {
+__global__ __launch_bounds__(1024) void fill(const char* src, size_t bytes_per_wg, int iters, int pattern, unsigned* sink) {
   extern __shared__ char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const char* base = src + (size_t)blockIdx.x * bytes_per_wg;
@@ -55,6 +55,23 @@ int main() {
     const double bytes = (double)ncu * nl * iters * 1024;
     printf("%-6s loaders %d depth %2d pattern %d : %7.1f us  %6.2f TB/s  %5.1f GB/s/CU\n", name, nl, depth, pattern, ms * 1e3, bytes / ms / 1e9, bytes / ms / 1e6 / ncu);
   };
+  // L2-resident working set (the filter rows every workgroup re-reads): 256 KiB window per CU
+  {
+    const size_t small = 256 << 10;
+    auto run2 = [&](auto kern, int nl, int depth, const char* name) {
+      const int iters = 2048;
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(ncu), dim3(64 * nl), nl * depth * 1024, 0, src, small, iters, 0, sink);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+      }
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      const double bytes = (double)ncu * nl * iters * 1024;
+      printf("L2-resident %-5s waves %2d depth %2d : %7.1f us  %6.2f TB/s  %5.1f GB/s/CU\n", name, nl, depth, ms * 1e3, bytes / ms / 1e9, bytes / ms / 1e6 / ncu);
+    };
+    for (int nl : {1, 4, 8, 12, 16}) { run2(fill<8, 0>, nl, 8, "glds"); run2(fill<8, 1>, nl, 8, "vgpr"); }
+  }
   for (int pattern = 0; pattern < 3; ++pattern)
     for (int nl : {1, 4}) {
       run(fill<4, 0>, nl, 4, pattern, "glds");
