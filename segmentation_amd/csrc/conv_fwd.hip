@@ -780,6 +780,7 @@ int launch_ws(const ConvK& P0, hipStream_t st) {
   }
   constexpr int PINST = ((TH + 2) * (TW + 2) * 4 + 63) / 64;
   ConvK P = P0;
+  if (P.d.n_count % BN != 0) { seg_set_error("conv_ws: n_count %d not a multiple of BN %d", P.d.n_count, BN); return SEG_ERR_ARG; }
   P.tiles_x = cdiv(P.d.Wo, TW);
   P.tiles_y = cdiv(P.d.Ho, TH);
   // ring depth: bytes in flight per CU are what buys fill bandwidth (Little's law at ~4 us loaded latency), so one

@@ -629,6 +629,7 @@ int launch_k(const WgK& P, hipStream_t st) {
     // large maps: 256-pixel tiles halve the barriers / staging rounds per MFMA (measured +5-8 % at >= 59x59)
     if (!small && d.Ho >= 48 && d.Wo >= 48 && (cfg == 2 || cfg == 3)) cfg += 6;
   }
+  if (S != 1 && (cfg == 8 || cfg == 9)) { seg_set_error("wgrad: 256-pixel tiles are stride-1 only (cfg %d)", cfg); return SEG_ERR_UNSUPPORTED; }
   switch (cfg) {
     case 1: return launch_cfg<T, 8, 16, KH, KW, S, 1, 4, 2, 2>(P, st);   // 128 px, 32 ci x 128 co
     case 2: return launch_cfg<T, 8, 16, KH, KW, S, 1, 4, 2, 1>(P, st);   // 128 px, 32 ci x 64 co

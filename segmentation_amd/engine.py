@@ -299,6 +299,31 @@ class Plan(object):
         return [(self.ops[i][0], self.kernel_name(i), e0.elapsed_time(e1), self.meta[i].get('flops', 0)) for i, e0, e1 in recs]
 
 
+def tune_key(d):
+    """Shape signature of a conv / wgrad descriptor: the unit the per-shape tile table (tuning/gfx950.json) is keyed by."""
+    if isinstance(d, L.ConvDesc):
+        return 'c:%dx%ds%du%d:B%d:%dx%d:k%d:n%d/%d:m%d:p%d:a%d:f%d' % (d.KH, d.KW, d.stride, d.up2, d.B, d.Hi, d.Wi, d.src0.c + (d.src1.c if d.src1.ptr else 0),
+                                                             d.n_count, d.n_total, 1 if d.mask.ptr else 0, d.pad_t, d.accum, d.out_f32)
+    return 'w:%dx%ds%d:B%d:%dx%d:k%d:n%d:b%d' % (d.KH, d.KW, d.stride, d.B, d.Ho, d.Wo, d.src0.c + (d.src1.c if d.src1.ptr else 0), d.dz.c, d.bias_mode)
+
+
+_TUNE = None
+
+
+def load_tuning():
+    """Per-shape tile choices found by tools/autotune.py IN the overlapped train step (a kernel that is fastest alone is
+    often not the one that co-runs best with the filter gradients).  SEG_TUNE=0 disables, SEG_TUNE_FILE overrides."""
+    global _TUNE
+    if _TUNE is None:
+        _TUNE = {}
+        if os.environ.get('SEG_TUNE', '1') != '0':
+            import json
+            path = os.environ.get('SEG_TUNE_FILE', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuning', 'gfx950.json'))
+            if os.path.exists(path):
+                _TUNE = {k: int(v) for k, v in json.load(open(path)).items() if not k.startswith('_')}
+    return _TUNE
+
+
 class Net(object):
     """Emits launches for one network instance (fixed batch / spatial size / dtype)."""
 
@@ -313,6 +338,11 @@ class Net(object):
         self._pending_reduce = {}
         self.n_wgrad_streams = 2
         self._wg_rr = 0
+        self.tune = load_tuning() if dtype == L.SEG_BF16 else {}
+
+    def _tuned(self, d):
+        if d.cfg == 0 and self.tune:
+            d.cfg = self.tune.get(tune_key(d), 0)
 
     def act(self, H, W, C, f32=False, name=''):
         a = Act(self.B, H, W, C, self.dtype, self.device, f32=f32, name=name)
@@ -363,6 +393,7 @@ class Net(object):
         d.relu = 1 if layer.relu else 0
         d.out_f32 = 1 if out_f32 else 0
         d.dtype = self.dtype; d.cfg = cfg
+        self._tuned(d)
         plan.keep.append(d)
         fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
         plan.add(layer.name, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl)
@@ -380,6 +411,7 @@ class Net(object):
         d.bias = self.store.p_ptr(layer.b_off); d.bias_n = layer.cout
         d.dst = dst.view(); d.up2 = 1; d.up_cout = layer.cout_p; d.mask = L.null_view()
         d.relu = 1 if layer.relu else 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
+        self._tuned(d)
         plan.keep.append(d)
         fl = 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
         plan.add(layer.name, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl)
@@ -472,6 +504,7 @@ class Net(object):
         w.dz = dz.view(); w.n_log = layer.cout
         w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = 0
         w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
+        self._tuned(w)
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
         self._add_wgrad(plan, layer.name + '/dw', w, fl)
@@ -493,6 +526,7 @@ class Net(object):
         w.dz = dz.view(dz_off[0], dz_off[1]); w.n_log = layer.cout
         w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = wcfg
         w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
+        self._tuned(w)
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
         self._add_wgrad(plan, layer.name + '/dw', w, fl)
@@ -513,6 +547,7 @@ class Net(object):
                 d.dst = dst.view(doff[0], doff[1]); d.up2 = 0; d.up_cout = 0
                 d.mask = mask.view(moff[0], moff[1]) if mask is not None else L.null_view()
                 d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
+                self._tuned(d)
                 plan.keep.append(d)
                 fl = 2 * self.B * Ho * Wo * k * k * layer.cin_segs[i] * layer.cout
                 plan.add(layer.name + '/dx%d' % i, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl)
@@ -529,6 +564,7 @@ class Net(object):
         w.dz = src.view(); w.n_log = layer.cin
         w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = wcfg
         w.bias_mode = 2; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
+        self._tuned(w)
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
         self._add_wgrad(plan, layer.name + '/dw', w, fl)
@@ -545,6 +581,7 @@ class Net(object):
             d.dst = dsrc.view(); d.up2 = 0; d.up_cout = 0
             d.mask = mask.view() if mask is not None else L.null_view()
             d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
+            self._tuned(d)
             plan.keep.append(d)
             plan.add(layer.name + '/dx', self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl)
             plan.flops += fl
