@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--per-op', action='store_true', help='also print the per-op table to stderr')
     ap.add_argument('--streams', type=int, default=2, help='side streams for the filter gradients (0 = everything on one stream)')
+    ap.add_argument('--force-dist', action='store_true', help='diagnostic: take the data-parallel code path (RCCL group of size 1) on one GPU')
     ap.add_argument('--host-data', action='store_true', help='feed from host memory through the pinned-buffer prefetcher (PCIe-inclusive rate; not the headline value)')
     return ap.parse_args()
 
@@ -107,8 +108,9 @@ def main():
         # single-process invocation asked for several GPUs: the contract launches us through torch.distributed.run
         raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
 
@@ -206,7 +208,7 @@ def main():
         out['cpu_baseline'] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_dist:
         torch.distributed.destroy_process_group()
 
 

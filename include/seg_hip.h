@@ -62,6 +62,10 @@ typedef struct seg_conv_desc {
   int32_t dtype;
   int32_t cfg;             /* 0 = auto tile choice; else forced config id (tuning/tests) */
   int32_t accum;           /* 1: add to what dst already holds (second consumer of a tensor in backward) */
+  int32_t n_split;         /* > 0: two destinations in one launch (dgrad of a channel-concat input): out channels
+                            * [0, n_split) -> dst / mask, channels [n_split, n_count) -> dst1 / mask1 (as j - n_split).
+                            * n_split must be a multiple of 64 or 32 (the channel tile) */
+  seg_view dst1, mask1;
 } seg_conv_desc;
 
 /* slim.convolution2d / conv2d_transpose fwd, Conv2DBackpropInput: models/unet.py:111-166,

@@ -125,6 +125,14 @@ SEG_DEV void conv_epilogue(const seg_conv_desc& d, f32x4 (&acc)[FN][FM], const E
   }
 }
 
+// dgrad of a channel-concat input: one launch, two destinations; a workgroup's BN block lies entirely in one of them
+SEG_DEV void select_dst(seg_conv_desc& d, int n0) {
+  if (d.n_split > 0 && n0 >= d.n_split) {
+    d.dst = d.dst1; d.dst.coff -= d.n_split;
+    d.mask = d.mask1; d.mask.coff -= d.n_split;
+  }
+}
+
 template <int DT, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
   using T = typename DtSel<DT>::type;
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
   char* sP = smem;
   char* sW = smem + PATCH_BYTES;
 
-  const seg_conv_desc& d = P.d;
+  seg_conv_desc d = P.d;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -156,6 +164,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
   const int ty = t % P.tiles_y; const int b = t / P.tiles_y;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int n0 = blockIdx.y * BN;                 // within this launch's n range
+  select_dst(d, n0);
 
   // ---- per-thread staging descriptors (constant over the K loop) ----
   int p_lds[NPP];
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
   static_assert((NT * BN * 4) % 64 == 0, "filter rows fill whole wave-instructions");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const seg_conv_desc& d = P.d;
+  seg_conv_desc d = P.d;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -343,6 +352,7 @@ __global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
   const int ty = t % P.tiles_y; const int b = t / P.tiles_y;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int n0 = blockIdx.y * BN;
+  select_dst(d, n0);
 
   // ---- per-lane source descriptors: instruction i of this wave covers LDS pieces [(i*4+wave)*64, +64) ----
   int p_off0[PPW], p_off1[PPW];                 // element offsets inside image b; -1 = zero word
@@ -729,7 +739,7 @@ int launch_cfg(const ConvK& P0, hipStream_t st) {
   ConvK P = P0;
   P.tiles_x = cdiv(P.d.Wo, TW);
   P.tiles_y = cdiv(P.d.Ho, TH);
-  if (P.d.n_count % BN != 0) { seg_set_error("conv: n_count %d not a multiple of BN %d", P.d.n_count, BN); return SEG_ERR_ARG; }
+  if (P.d.n_count % BN != 0 || P.d.n_split % BN != 0) { seg_set_error("conv: n_count %d / n_split %d not a multiple of BN %d", P.d.n_count, P.d.n_split, BN); return SEG_ERR_ARG; }
   auto kern = conv_fwd_kernel<Tr<T>::DT, TH, TW, BN, WM, WN, KH, KW, S>;
   static bool attr_done = false;
   if (!attr_done && LDS > 48 * 1024) {
@@ -756,7 +766,7 @@ int launch_glds(const ConvK& P0, hipStream_t st) {
   ConvK P = P0;
   P.tiles_x = cdiv(P.d.Wo, TW);
   P.tiles_y = cdiv(P.d.Ho, TH);
-  if (P.d.n_count % BN != 0) { seg_set_error("conv: n_count %d not a multiple of BN %d", P.d.n_count, BN); return SEG_ERR_ARG; }
+  if (P.d.n_count % BN != 0 || P.d.n_split % BN != 0) { seg_set_error("conv: n_count %d / n_split %d not a multiple of BN %d", P.d.n_count, P.d.n_split, BN); return SEG_ERR_ARG; }
   auto kern = conv_fwd_glds_kernel<TH, TW, BN, WM, WN, KH, KW, S, NBUF>;
   static bool attr_done = false;
   if (!attr_done && LDS > 48 * 1024) {
@@ -820,7 +830,7 @@ int launch_k(const ConvK& P, hipStream_t st) {
   const seg_conv_desc& d = P.d;
   int cfg = d.cfg;
   const int mode_hint = cfg < 0 ? -cfg : 0;      // cfg < 0: automatic tile choice with staging mode |cfg| (see below)
-  if (sizeof(T) == 2 && KH == 3 && S == 1 && (cfg <= 0 || cfg >= 50) && !d.up2 && !d.accum && !d.out_f32) {
+  if (sizeof(T) == 2 && KH == 3 && S == 1 && (cfg <= 0 || cfg >= 50) && !d.up2 && !d.accum && !d.out_f32 && d.n_split == 0) {
     // weight-stationary persistent kernel whenever the BN filter rows of all K fit beside the patch ring
     static const int ws_on = getenv("SEG_CONV_WS") ? atoi(getenv("SEG_CONV_WS")) : 0;   // opt-in: not yet faster than the tiled kernels
     const int ntiles = d.B * cdiv(d.Ho, 8) * cdiv(d.Wo, 16);
@@ -849,7 +859,7 @@ int launch_k(const ConvK& P, hipStream_t st) {
     static const int TH_[4] = {8, 8, 8, 8}, TW_[4] = {16, 16, 8, 8}, BN_[4] = {64, 32, 64, 32};
     long best = -1; int bi = 1;
     for (int c = 0; c < 4; ++c) {
-      if (d.n_count % BN_[c]) continue;
+      if (d.n_count % BN_[c] || d.n_split % BN_[c]) continue;
       const long nwg = (long)d.B * cdiv(d.Ho, TH_[c]) * cdiv(d.Wo, TW_[c]) * (d.n_count / BN_[c]);
       const long cost = ((nwg + 767) / 768) * ((long)TH_[c] * TW_[c] * BN_[c] + 5000);
       if (best < 0 || cost < best) { best = cost; bi = c; }
@@ -939,9 +949,15 @@ extern "C" int seg_conv2d(const seg_conv_desc* dp, void* stream) {
       (d.src1.ptr && (d.src1.oy + d.Hi > d.src1.H || d.src1.ox + d.Wi > d.src1.W || d.src1.coff + d.src1.c > d.src1.cs))) {
     seg_set_error("conv: source window exceeds its buffer"); return SEG_ERR_ARG;
   }
+  if (d.n_split != 0) {
+    if (d.n_split < 0 || d.n_split >= d.n_count || d.n_split % 32 || d.up2 || d.accum || d.out_f32 || !d.dst1.ptr) { seg_set_error("conv: bad n_split %d (needs 0 < n_split < n_count, multiple of 32, no up2/accum/out_f32)", d.n_split); return SEG_ERR_ARG; }
+    const int n1 = d.n_count - d.n_split;
+    if (d.dst1.oy + d.Ho > d.dst1.H || d.dst1.ox + d.Wo > d.dst1.W || d.dst1.coff + n1 > d.dst1.cs || d.dst.coff + d.n_split > d.dst.cs) { seg_set_error("conv: split destination window exceeds its buffer"); return SEG_ERR_ARG; }
+    if (d.mask1.ptr && (d.mask1.oy + d.Ho > d.mask1.H || d.mask1.ox + d.Wo > d.mask1.W || d.mask1.coff + n1 > d.mask1.cs)) { seg_set_error("conv: split mask window exceeds its buffer"); return SEG_ERR_ARG; }
+  }
   {
     const int sc = d.up2 ? 2 : 1;
-    const int nch = d.up2 ? d.up_cout : d.n_count;
+    const int nch = d.up2 ? d.up_cout : (d.n_split > 0 ? d.n_split : d.n_count);
     if (d.dst.oy + sc * d.Ho > d.dst.H || d.dst.ox + sc * d.Wo > d.dst.W || d.dst.coff + nch > d.dst.cs) {
       seg_set_error("conv: destination window exceeds its buffer"); return SEG_ERR_ARG;
     }

@@ -302,8 +302,8 @@ class Plan(object):
 def tune_key(d):
     """Shape signature of a conv / wgrad descriptor: the unit the per-shape tile table (tuning/gfx950.json) is keyed by."""
     if isinstance(d, L.ConvDesc):
-        return 'c:%dx%ds%du%d:B%d:%dx%d:k%d:n%d/%d:m%d:p%d:a%d:f%d' % (d.KH, d.KW, d.stride, d.up2, d.B, d.Hi, d.Wi, d.src0.c + (d.src1.c if d.src1.ptr else 0),
-                                                             d.n_count, d.n_total, 1 if d.mask.ptr else 0, d.pad_t, d.accum, d.out_f32)
+        return 'c:%dx%ds%du%d:B%d:%dx%d:k%d:n%d/%d:m%d:p%d:a%d:f%d:s%d' % (d.KH, d.KW, d.stride, d.up2, d.B, d.Hi, d.Wi, d.src0.c + (d.src1.c if d.src1.ptr else 0),
+                                                                 d.n_count, d.n_total, 1 if d.mask.ptr else 0, d.pad_t, d.accum, d.out_f32, d.n_split)
     return 'w:%dx%ds%d:B%d:%dx%d:k%d:n%d:b%d' % (d.KH, d.KW, d.stride, d.B, d.Ho, d.Wo, d.src0.c + (d.src1.c if d.src1.ptr else 0), d.dz.c, d.bias_mode)
 
 
@@ -532,6 +532,30 @@ class Net(object):
         self._add_wgrad(plan, layer.name + '/dw', w, fl)
         plan.flops += fl
         n_off = 0
+        merged = (len(dsrcs) == 2 and dsrcs[0] is not None and dsrcs[1] is not None and not any(len(x) > 4 and x[4] for x in dsrcs)
+                  and os.environ.get('SEG_MERGE_DGRAD', '1') != '0')
+        if merged:
+            # both halves of a channel-concat input in ONE launch (seg_conv_desc.n_split): one kernel less per decoder level
+            d = L.ConvDesc()
+            d.accum = 0
+            d.src0 = dz.view(dz_off[0], dz_off[1]); d.src1 = L.null_view()
+            d.B, d.Hi, d.Wi = self.B, Ho, Wo
+            d.KH = d.KW = k; d.stride = 1; d.pad_t = d.pad_l = k - 1 - pad
+            d.Ho, d.Wo = Hi, Wi
+            d.w_packed = self.store.packed_ptr(layer.pk_dgrad)
+            d.n_total = sum(layer.cin_p); d.n_off = 0; d.n_count = d.n_total; d.n_split = layer.cin_p[0]
+            d.bias = None; d.bias_n = 0; d.up2 = 0; d.up_cout = 0
+            (dst0, doff0, mask0, moff0), (dst1, doff1, mask1, moff1) = dsrcs[0][:4], dsrcs[1][:4]
+            d.dst = dst0.view(doff0[0], doff0[1]); d.dst1 = dst1.view(doff1[0], doff1[1])
+            d.mask = mask0.view(moff0[0], moff0[1]) if mask0 is not None else L.null_view()
+            d.mask1 = mask1.view(moff1[0], moff1[1]) if mask1 is not None else L.null_view()
+            d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
+            self._tuned(d)
+            plan.keep.append(d)
+            fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
+            plan.add(layer.name + '/dx01', self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl)
+            plan.flops += fl
+            return
         for i, ds in enumerate(dsrcs):
             if ds is not None:
                 dst, doff, mask, moff = ds[:4]

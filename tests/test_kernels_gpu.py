@@ -103,7 +103,8 @@ def test_conv_fwd_bwd(dtype, case):
         dsrc_acts.append(da)
     store.g.zero_()
     bplan = E.Plan('b')
-    dcfg = 0 if cfg < 50 else (cfg if all(c % 64 == 0 for c in layer.cin_p) or cfg == 52 else 52)
+    # two-source layers take the merged two-destination dgrad launch (n_split), which the tiled kernels serve
+    dcfg = 0 if (cfg < 50 or len(segs) > 1) else (cfg if all(c % 64 == 0 for c in layer.cin_p) or cfg == 52 else 52)
     net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs, cfg=dcfg)
     net.flush_reduce(bplan)
     bplan.run(U.stream()); U.sync()
