@@ -58,8 +58,8 @@ def kernel_table(model, reps=5):
     for rep in range(reps + 1):
         model.loss_buf.zero_()
         rows = []
-        for plan in (model.fwd_plan, model.bwd_plan, model.upd_plan):
-            side = model._side if plan is not model.upd_plan and not os.environ.get('SEG_BENCH_SERIAL') else None
+        for plan in (model.fwd_plan, model.bwd_upd_plan):       # the plans the timed step replays
+            side = model._side if not os.environ.get('SEG_BENCH_SERIAL') else None
             rows += plan.run_profiled(stream, torch, side)
         if rep == 0:
             continue               # warm-up
@@ -158,7 +158,7 @@ def main():
     out = None
     if rank == 0:
         ms = dt / args.steps * 1e3
-        flops_step = model.fwd_plan.flops + model.bwd_plan.flops
+        flops_step = model.fwd_plan.flops + model.bwd_plan.flops      # (bwd_upd_plan = bwd_plan + Adam)
         out = {
             'metric': 'train-step images/sec', 'value': round(world * args.batch * args.steps / dt, 2), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),

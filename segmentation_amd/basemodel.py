@@ -184,6 +184,12 @@ class BaseModel(object):
         self.fwd_plan.run(s, self._side)
         self.bwd_plan.run(s, self._side)
 
+    def _run_step(self):
+        s = self._stream()
+        self.fwd_plan.run(s, self._side)
+        self.bwd_upd_plan.run(s, self._side)
+        self._packed_dirty = True
+
     def _run_update(self):
         self.upd_plan.run(self._stream())
         self._packed_dirty = True          # the packed copy is refreshed by the next forward (or lazily by infer())
@@ -218,7 +224,7 @@ class BaseModel(object):
             raise Exception('train_step() with INFERENCE mode invalid')
         self._load_batch(self.dataset, self.input_x, self.input_y)
         if not self.pg.enabled:
-            self._replay('step', lambda: (self._run_fwd_bwd(), self._run_update()))
+            self._replay('step', self._run_step)
         else:
             self._train_step_dp()
         self._gs_host += 1
@@ -336,6 +342,18 @@ class BaseModel(object):
         upd = self.upd_plan = E.Plan('update')
         self.net.adam(upd, self.learning_rate, grad_scale=1.0 / self.pg.world)
         # the re-pack of the updated weights is the first op of the next forward plan (aux stream)
+        # Single-GPU step (SEG_EARLY_ADAM=1, measured 3 % slower under hipGraph, hence off): Adam of the buckets that are complete before the last backward segment runs on the auxiliary
+        # stream BESIDE that segment (nothing in backward reads the fp32 master weights); only the last, small bucket is
+        # updated after it.  The data-parallel path keeps one Adam after the last all-reduce (upd_plan).
+        self.bwd_upd_plan = E.Plan('bwd+update')
+        early = len(self.bwd_segments) >= 2 and self._side is not None and os.environ.get('SEG_EARLY_ADAM', '0') != '0'
+        cut = self.bwd_segments[-2][1][1] if early else 0
+        for i, (plan, _) in enumerate(self.bwd_segments):
+            self.bwd_upd_plan.extend(plan)
+            if early and i == len(self.bwd_segments) - 2:
+                self.net.adam(self.bwd_upd_plan, self.learning_rate, grad_scale=1.0, lo=0, hi=cut, side='aux_join')
+        self.net.join_all(self.bwd_upd_plan)           # the last filter gradients / reductions are on the side streams
+        self.net.adam(self.bwd_upd_plan, self.learning_rate, grad_scale=1.0, lo=cut, hi=self.store.n)
 
     def set_weights(self, params):
         """Load {scope: {'weights','biases'}} in TF layouts (tests / interchange)."""

@@ -202,12 +202,24 @@ class Plan(object):
             tag = self.meta[i].get('side', 0)
             if name in skip:
                 continue
+            if fn is None and name == 'join_all':      # marker: the main stream waits for every side stream used so far
+                flush()
+                for o_ in used.values():
+                    ev = torch.cuda.Event(); ev.record(o_); main.wait_event(ev)
+                if aux_used:
+                    ev = torch.cuda.Event(); ev.record(aux); main.wait_event(ev)
+                continue
             if fn is None:               # marker: make the main stream wait for the aux stream
                 if aux_used:
                     ev = torch.cuda.Event(); ev.record(aux); main.wait_event(ev)
                     aux_used = False
                 continue
-            if tag == 'aux':
+            if tag == 'aux' or tag == 'aux_join':
+                if tag == 'aux_join':
+                    flush()
+                    for o_ in used.values():             # everything the filter-gradient streams hold so far
+                        if o_ is not aux:
+                            ev = torch.cuda.Event(); ev.record(o_); aux.wait_event(ev)
                 ev = torch.cuda.Event(); ev.record(main); aux.wait_event(ev)
                 aux_used = True
                 rc = fn(*args, C.c_void_p(aux.cuda_stream))
@@ -271,12 +283,22 @@ class Plan(object):
         aux = side[-1] if side else None
         for i, (name, fn, args) in enumerate(self.ops):
             tag = self.meta[i].get('side', 0) if side else 0
+            if fn is None and name == 'join_all':
+                for o_ in used.values():
+                    ev = torch_mod.cuda.Event(); ev.record(o_); main.wait_event(ev)
+                if side and aux_used:
+                    ev = torch_mod.cuda.Event(); ev.record(aux); main.wait_event(ev)
+                continue
             if fn is None:
                 if side and aux_used:
                     ev = torch_mod.cuda.Event(); ev.record(aux); main.wait_event(ev); aux_used = False
                 continue
-            if tag == 'aux':
+            if tag == 'aux' or tag == 'aux_join':
                 st = aux; aux_used = True
+                if tag == 'aux_join':
+                    for o_ in used.values():
+                        if o_ is not aux:
+                            ev = torch_mod.cuda.Event(); ev.record(o_); aux.wait_event(ev)
             elif tag:
                 st = side[(tag - 1) % (len(side) - 1)] if len(side) > 1 else side[0]
                 used[id(st)] = st
@@ -677,14 +699,28 @@ class Net(object):
         plan.add('pack', self.lib.seg_pack_weights, s.p.data_ptr(), s.packed.data_ptr(), s.pack_table.data_ptr(),
                  s.n_pack_entries, s.pack_blocks, self.dtype, **meta)
 
+    def join_all(self, plan):
+        """main stream waits for every side stream (the filter gradients) -- e.g. before Adam inside the same plan"""
+        plan.ops.append(('join_all', None, ()))
+        plan.meta.append({'kernel': 'marker'})
+
     def join_aux(self, plan):
         plan.ops.append(('join_aux', None, ()))
         plan.meta.append({'kernel': 'marker'})
 
-    def adam(self, plan, lr, grad_scale=1.0, b1=0.9, b2=0.999, eps=1e-8):
+    def adam(self, plan, lr, grad_scale=1.0, b1=0.9, b2=0.999, eps=1e-8, lo=0, hi=None, side=None):
+        """TF-Adam over the arena slice [lo, hi).  side='aux_join': on the auxiliary stream, after everything launched so
+        far on the main AND the filter-gradient streams (an early update of the buckets whose gradients are complete)."""
         s = self.store
-        plan.add('adam', self.lib.seg_adam, s.p.data_ptr(), s.g.data_ptr(), s.m.data_ptr(), s.v.data_ptr(), s.n, lr, b1, b2, eps,
-                 grad_scale, s.step.data_ptr() + 8, kernel='adam_kernel')
+        hi = s.n if hi is None else hi
+        if hi <= lo:
+            return
+        meta = {'kernel': 'adam_kernel'}
+        if side:
+            meta['side'] = side
+        o = lo * 4
+        plan.add('adam[%d:%d]' % (lo, hi), self.lib.seg_adam, s.p.data_ptr() + o, s.g.data_ptr() + o, s.m.data_ptr() + o, s.v.data_ptr() + o,
+                 hi - lo, lr, b1, b2, eps, grad_scale, s.step.data_ptr() + 8, **meta)
 
     def step_begin(self, plan, loss_buf, aux=True):
         """global_step += 1 and loss accumulator = 0, first thing of a training forward (auxiliary stream: off the
