@@ -253,6 +253,16 @@ class Plan(object):
         for st in used.values():
             ev = torch.cuda.Event(); ev.record(st); main.wait_event(ev)
 
+    def rebind(self, mapping):
+        """Replaces raw device pointers among the launch arguments ({old: new}; the network inputs when a device-resident
+        dataset hands over its own buffers).  Returns the number of arguments changed."""
+        n = 0
+        for i, (name, fn, args) in enumerate(self.ops):
+            if any(isinstance(a, int) and a in mapping for a in args):
+                self.ops[i] = (name, fn, tuple(mapping.get(a, a) if isinstance(a, int) else a for a in args))
+                n += 1
+        return n
+
     def __len__(self):
         return len(self.ops)
 
