@@ -232,6 +232,92 @@ __global__ void softmax_xent_kernel(seg_view lg, const uint8_t* labels, int LH, 
   if (threadIdx.x == 0) atomicAdd(loss_sum, (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_n);
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused segmentation head of the U-Net train step: 1x1 'output' conv (logits) + softmax cross-entropy + the 1x1 conv's
+// input gradient (with the ReLU-grad mask of its input), one thread per pixel -- three launches of ~6 us each on the
+// critical path become one.  w is the fp32 HWIO filter [cin][nc] (models/unet.py:166,171-174, basemodel.py:59-70).
+// ------------------------------------------------------------------------------------------
+template <typename T, int NCP, int CINP>
+__global__ __launch_bounds__(256) void head_xent_kernel(seg_view act, const float* w, const float* bias, int cin, const uint8_t* labels,
+                                                        int LH, int LW, int ly0, int lx0, int B, int H, int W, int nc, float inv_n,
+                                                        float* loss_sum, seg_view lg, seg_view dl, seg_view dact) {
+  __shared__ float sw[CINP * NCP];
+  __shared__ float sb[NCP];
+  for (int i = threadIdx.x; i < CINP * NCP; i += 256) { const int k = i / NCP, c = i % NCP; sw[i] = (k < cin && c < nc) ? w[(int64_t)k * nc + c] : 0.f; }
+  if (threadIdx.x < NCP) sb[threadIdx.x] = (bias && (int)threadIdx.x < nc) ? bias[threadIdx.x] : 0.f;
+  __syncthreads();
+  const int64_t total = (int64_t)B * H * W;
+  float local = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int x = t % W; t /= W;
+    const int y = t % H; const int b = t / H;
+    const T* ap = reinterpret_cast<const T*>(act.ptr) + view_off(act, b, y, x);
+    float a[CINP];
+#pragma unroll
+    for (int k8 = 0; k8 < CINP / 8; ++k8) {
+      Vec8<T> v; v.load(ap + k8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[k8 * 8 + e] = v.get(e);
+    }
+    float zv[NCP];
+#pragma unroll
+    for (int c = 0; c < NCP; ++c) zv[c] = sb[c];
+#pragma unroll
+    for (int k = 0; k < CINP; ++k)
+#pragma unroll
+      for (int c = 0; c < NCP; ++c) zv[c] = fmaf(a[k], sw[k * NCP + c], zv[c]);
+    float* zo = reinterpret_cast<float*>(lg.ptr) + view_off(lg, b, y, x);
+#pragma unroll
+    for (int c = 0; c < NCP; ++c) if (c < nc) zo[c] = zv[c];
+    const int lab = labels[((int64_t)b * LH + y + ly0) * LW + x + lx0];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NCP; ++c) { if (c >= nc) zv[c] = -INFINITY; m = fmaxf(m, zv[c]); }
+    const bool valid = lab < nc;
+    float zl = 0.f, s_ = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCP; ++c) { if (c == lab) zl = zv[c]; zv[c] = c < nc ? expf(zv[c] - m) : 0.f; s_ += zv[c]; }
+    if (valid) local += (logf(s_) - (zl - m));
+    const float rs = 1.f / s_;
+    float g[NCP];
+#pragma unroll
+    for (int c = 0; c < NCP; ++c) g[c] = (c < nc && valid) ? (zv[c] * rs - (c == lab ? 1.f : 0.f)) * inv_n : 0.f;
+    T* o = reinterpret_cast<T*>(dl.ptr) + view_off(dl, b, y, x);
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8) {
+      if (c8 * 8 >= dl.c) break;
+      Vec8<T> ov;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const int c = c8 * 8 + e; ov.set(e, c < NCP ? g[c < NCP ? c : 0] : 0.f); }
+      ov.store(o + c8 * 8);
+    }
+    // gradient of the 1x1 conv's input, masked by that input's ReLU.  dlogits is what the filter gradient reads, so the
+    // same (dtype-rounded) values are used here as the separate dgrad launch would see.
+#pragma unroll
+    for (int c = 0; c < NCP; ++c) { Vec8<T> r; r.set(0, g[c]); g[c] = r.get(0); }
+    T* da = reinterpret_cast<T*>(dact.ptr) + view_off(dact, b, y, x);
+#pragma unroll
+    for (int k8 = 0; k8 < CINP / 8; ++k8) {
+      Vec8<T> ov;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = k8 * 8 + e;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) acc = fmaf(g[c], sw[k * NCP + c], acc);
+        ov.set(e, a[k] > 0.f ? acc : 0.f);
+      }
+      ov.store(da + k8 * 8);
+    }
+  }
+  __shared__ float wsum[4];
+  local = wave_sum(local);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss_sum, (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_n);
+}
+
 __global__ void sigmoid_argmax_kernel(seg_view lg, int B, int H, int W, int nc, float* sig, float* out) {
   const int64_t total = (int64_t)B * H * W;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -543,6 +629,26 @@ extern "C" int seg_softmax_xent(const seg_view* logits, const uint8_t* labels, i
 #undef XENT_NCP
 #undef XENT_ARGS
   return seg_check_launch("softmax_xent");
+}
+
+extern "C" int seg_head_xent(const seg_view* act, const float* w_hwio, const float* bias, int32_t cin, const uint8_t* labels, int32_t LH, int32_t LW,
+                             int32_t ly0, int32_t lx0, int32_t B, int32_t H, int32_t W, int32_t n_classes, float inv_n, float* loss_sum,
+                             const seg_view* logits, const seg_view* dlogits, const seg_view* dact, int32_t dtype, void* stream) {
+  if (!act || !act->ptr || !w_hwio || !labels || !loss_sum || !logits || !logits->ptr || !view_ok(dlogits, H, W, dlogits ? dlogits->c : 0) ||
+      !view_ok(dact, H, W, dact ? dact->c : 0) || !view_ok(act, H, W, act->c)) { seg_set_error("head_xent: bad args"); return SEG_ERR_ARG; }
+  if (n_classes < 1 || n_classes > 32 || n_classes > dlogits->c || dlogits->c % 8 || dlogits->c > 32 || n_classes > logits->cs) { seg_set_error("head_xent: n_classes %d unsupported (1..32)", n_classes); return SEG_ERR_UNSUPPORTED; }
+  if ((act->c != 32 && act->c != 64) || dact->c != act->c || cin < 1 || cin > act->c) { seg_set_error("head_xent: input channels %d unsupported (32 or 64 padded)", act->c); return SEG_ERR_UNSUPPORTED; }
+  if (ly0 < 0 || lx0 < 0 || ly0 + H > LH || lx0 + W > LW) { seg_set_error("head_xent: label window out of range"); return SEG_ERR_ARG; }
+  const int64_t n = (int64_t)B * H * W;
+  const int g = grid_for(n, 256, 512);
+#define HEAD_ARGS dim3(g), dim3(256), 0, ST(stream), *act, w_hwio, bias, cin, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, loss_sum, *logits, *dlogits, *dact
+#define HEAD_C(TT, NCP) do { if (act->c == 32) SEG_LAUNCH((head_xent_kernel<TT, NCP, 32>), HEAD_ARGS); else SEG_LAUNCH((head_xent_kernel<TT, NCP, 64>), HEAD_ARGS); } while (0)
+#define HEAD_NCP(TT) do { if (n_classes <= 4) HEAD_C(TT, 4); else if (n_classes <= 8) HEAD_C(TT, 8); else if (n_classes <= 16) HEAD_C(TT, 16); else HEAD_C(TT, 32); } while (0)
+  DISPATCH(dtype, HEAD_NCP(float), HEAD_NCP(bf16_t));
+#undef HEAD_NCP
+#undef HEAD_C
+#undef HEAD_ARGS
+  return seg_check_launch("head_xent");
 }
 
 extern "C" int seg_sigmoid_argmax(const seg_view* logits, int32_t B, int32_t H, int32_t W, int32_t n_classes, float* sig, float* out,

@@ -692,6 +692,17 @@ class Net(object):
         plan.add('xent', self.lib.seg_softmax_xent, C.byref(lv), labels_u8.data_ptr(), LH, LW, loff[0], loff[1], self.B, H, W,
                  n_classes, inv_n, 1.0, loss_buf.data_ptr(), C.byref(dv), self.dtype, kernel='softmax_xent_kernel')
 
+    def head_xent(self, plan, layer, act, labels_u8, LH, LW, loff, H, W, n_classes, loss_buf, logits, dlogits, dact):
+        """Fused 1x1 output conv + softmax x-entropy + the conv's masked input gradient (seg_head_xent)."""
+        av, lv, dv, gv = act.view(), logits.view(), dlogits.view(), dact.view()
+        plan.keep += [av, lv, dv, gv]
+        inv_n = 1.0 / float(self.B * H * W)
+        fl = 2 * 2 * self.B * H * W * layer.cin * layer.cout          # forward + input gradient
+        plan.add(layer.name + '+xent+dx', self.lib.seg_head_xent, C.byref(av), self.store.p_ptr(layer.w_off), self.store.p_ptr(layer.b_off),
+                 layer.cin, labels_u8.data_ptr(), LH, LW, loff[0], loff[1], self.B, H, W, n_classes, inv_n, loss_buf.data_ptr(),
+                 C.byref(lv), C.byref(dv), C.byref(gv), self.dtype, kernel='head_xent_kernel', flops=fl)
+        plan.flops += fl
+
     def sigmoid_argmax(self, plan, logits, H, W, n_classes, sig, out):
         lv = logits.view()
         plan.keep.append(lv)

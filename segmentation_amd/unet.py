@@ -124,7 +124,7 @@ class UNetModel(BaseModel):
         return self.fwd_plan
 
     # ---- forward graph (shared by training and inference builders) ----
-    def _emit_forward(self, net, plan, x_in, H, W, crop_aware, dropout=None, after_first=None):
+    def _emit_forward(self, net, plan, x_in, H, W, crop_aware, dropout=None, after_first=None, head=True):
         nk, Ly = self.n_kernels, self.store.layers
         if H != W:
             # the reference crops every skip with a SQUARE target taken from the height (models/unet.py:139-140,146-147):
@@ -184,7 +184,8 @@ class UNetModel(BaseModel):
                 net.dropout(plan, A[cb], dropout['keep'], dropout['seed'] + 10 + i, dropout['offset'])
             prev = A[cb]
         A['logits'] = net.act(sh['output'], sw['output'], self.n_classes, f32=True, name='logits')
-        net.conv_fwd(plan, Ly['output'], [(prev, 0, 0)], prev.H, prev.W, A['logits'], out_f32=True)
+        if head:        # (the training plan fuses this 1x1 conv with the loss and its input gradient: Net.head_xent)
+            net.conv_fwd(plan, Ly['output'], [(prev, 0, 0)], prev.H, prev.W, A['logits'], out_f32=True)
         return A, sh, sw, skip_off, (o4h, o4w)
 
     # ---- training plans ----
@@ -201,7 +202,8 @@ class UNetModel(BaseModel):
         net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1_1
         cols = []       # im2col of the input for conv1_1's filter gradient: side stream, right after conv1_1 (both are
         #                 bandwidth-bound), overlapping the rest of the forward pass
-        A, sh, sw, skip_off, o4 = self._emit_forward(net, fwd, self.input_x, H, W, self.crop_aware,
+        fuse_head = (E.rup(Ly['output'].cin) in (32, 64) and self.n_classes <= 32 and os.environ.get('SEG_FUSE_HEAD', '1') != '0')
+        A, sh, sw, skip_off, o4 = self._emit_forward(net, fwd, self.input_x, H, W, self.crop_aware, head=not fuse_head,
                                                      after_first=lambda: cols.append(net.first_im2col(fwd, Ly['conv1_1'], self.input_x, H, W)))
         col = cols[0]
         self.acts = A
@@ -210,10 +212,16 @@ class UNetModel(BaseModel):
         dlog = net.act(oh, ow, self.n_classes, name='dlogits')
         # label crop: resize_image_with_crop_or_pad(input_y, target, target) -> floor offsets (unet.py:171-174)
         self.label_off = ((H - oh) // 2, (W - ow) // 2)
-        net.softmax_xent(fwd, A['logits'], self.input_y, H, W, self.label_off, oh, ow, self.n_classes, self.loss_buf, dlog)
-        self.dlogits = dlog
-
         G = {}                                    # masked gradients dZ (same shape as the activation)
+        if fuse_head:
+            # 1x1 output conv + loss + its input gradient in one launch
+            a92 = A['conv9_2']
+            G['conv9_2'] = net.act(a92.H, a92.W, a92.C, name='dconv9_2')
+            net.head_xent(fwd, Ly['output'], a92, self.input_y, H, W, self.label_off, oh, ow, self.n_classes, self.loss_buf,
+                          A['logits'], dlog, G['conv9_2'])
+        else:
+            net.softmax_xent(fwd, A['logits'], self.input_y, H, W, self.label_off, oh, ow, self.n_classes, self.loss_buf, dlog)
+        self.dlogits = dlog
 
         def gz(name):
             a = A[name]
@@ -232,7 +240,7 @@ class UNetModel(BaseModel):
 
         # output layer
         net.conv_bwd(seg, Ly['output'], [(A['conv9_2'], 0, 0)], A['conv9_2'].H, A['conv9_2'].W, dlog,
-                     [(gz('conv9_2'), (0, 0), A['conv9_2'], (0, 0))])
+                     [None if fuse_head else (gz('conv9_2'), (0, 0), A['conv9_2'], (0, 0))])
         dskip = {}
         prev_of = {'upconv1': 'conv5_2', 'upconv2': 'conv6_2', 'upconv3': 'conv7_2', 'upconv4': 'conv8_2'}
         for lvl in (3, 2, 1, 0):
