@@ -370,6 +370,7 @@ class Net(object):
         self._pending_reduce = {}
         self.n_wgrad_streams = 2
         self._wg_rr = 0
+        self.side_enabled = True
         self.tune = load_tuning() if dtype == L.SEG_BF16 else {}
 
     def _tuned(self, d):
@@ -475,6 +476,8 @@ class Net(object):
         stream): two C-ABI calls so that each kernel is timed on its own."""
         sid = 1 + self._wg_rr % self.n_wgrad_streams        # side stream of this layer's filter gradient
         self._wg_rr += 1
+        if not self.side_enabled:
+            sid = 0                                             # (experiments) keep it on the main stream
         if w.ksplit > 1 and self.batch_reduce:
             w.phase = 1
             self._pending_reduce.setdefault(sid, []).append(w)

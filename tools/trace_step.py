@@ -7,7 +7,7 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 def short(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')
-    for k in ('conv_fwd_glds_kernel', 'conv_fwd_kernel', 'conv_wgrad_kernel', 'wgrad_reduce_batch', 'wgrad_reduce_kernel', 'conv_first_fwd', 'im2col', 'maxpool_fwd', 'maxpool_bwd',
+    for k in ('conv_fwd_glds_kernel', 'conv_fwd_kernel', 'conv_wgrad_kernel', 'wgrad_reduce_batch', 'wgrad_reduce_kernel', 'conv_first_mfma', 'conv_first_fwd', 'im2col', 'head_xent', 'step_begin', 'conv_ws_kernel', 'maxpool_fwd', 'maxpool_bwd',
               'softmax_xent', 'adam_kernel', 'pack_kernel', 'step_inc', 'bias_grad', 'copyBuffer', 'FillFunctor'):
         if k in n: return k
     return n[:40]
