@@ -171,12 +171,18 @@ class Plan(object):
         streams are joined back into the main stream at the end -- under hipGraph capture this becomes a fork/join."""
         sp = C.c_void_p(stream)
         if not side:
+            dbg = os.environ.get('SEG_DEBUG_SYNC')        # name every launch on stderr and synchronise after it (fault hunting)
             for name, fn, args in self.ops:
                 if fn is None or name in skip:
                     continue
+                if dbg:
+                    import sys
+                    sys.stderr.write('[launch] %s/%s\n' % (self.name, name)); sys.stderr.flush()
                 rc = fn(*args, sp)
                 if rc != 0:
                     L.check(rc, '%s/%s' % (self.name, name))
+                if dbg:
+                    torch.cuda.synchronize()
             return
         main = torch.cuda.current_stream()
         used = {}
