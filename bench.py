@@ -181,7 +181,8 @@ def main():
             fa = fam.setdefault(f, {'ms': 0.0, 'flops': 0, 'launches': 0})
             fa['ms'] += a['ms']; fa['flops'] += a['flops']; fa['launches'] += a['launches']
         # dominant kernel = the template instance with the largest total time
-        dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
+        # (among the kernels that do arithmetic: the slab reductions / pools / Adam are HBM movers with no FLOP count)
+        dom = max((kv for kv in agg.items() if kv[1]['flops'] > 0), key=lambda kv: kv[1]['ms'])
         name, a = dom
         avg_ms = a['ms'] / a['launches']
         ach = a['flops'] / a['launches'] / (avg_ms * 1e-3) / 1e12 if a['flops'] else 0.0
