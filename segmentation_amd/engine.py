@@ -499,11 +499,16 @@ class Net(object):
             w.phase = 0
             plan.add(name, self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=sid)
 
-    def flush_reduce(self, plan):
+    def flush_reduce(self, plan, on_main=False):
         """Reduces the slabs of every filter gradient emitted since the last flush: one launch per side stream (each
         stream reduces its own layers, so the launch is simply in order behind them).  Call it where the gradients are
-        first needed -- the end of a backward segment (all-reduce / Adam)."""
+        first needed -- the end of a backward segment (all-reduce / Adam).  on_main: ONE launch on the main stream
+        behind a join of the side streams (everything pending, whatever stream it ran on)."""
         pending, self._pending_reduce = self._pending_reduce, {}
+        if on_main and pending:
+            allw = [w for sid in sorted(pending) for w in pending[sid]]
+            pending = {0: allw}
+            self.join_all(plan)
         for sid in sorted(pending):
             ws = pending[sid]
             n = len(ws)
@@ -516,7 +521,7 @@ class Net(object):
             jobs = torch.frombuffer(bytearray(host), dtype=torch.uint8)[:96 * nj.value].clone().to(self.device)
             plan.keep += [jobs, arr]
             plan.add('dw/reduce[%d]' % nj.value, self.lib.seg_wgrad_reduce_batch, jobs.data_ptr(), nj.value, nb.value,
-                     kernel='wgrad_reduce_batch_kernel', side=sid)
+                     kernel='wgrad_reduce_batch_kernel', side=sid)          # sid 0 = main stream
 
     def first_im2col(self, plan, layer, x_f32, H, W):
         """im2col of the raw input (27 -> 32 channels) for the first layer's filter gradient.  It depends only on the
