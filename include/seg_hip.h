@@ -66,6 +66,10 @@ typedef struct seg_conv_desc {
                             * [0, n_split) -> dst / mask, channels [n_split, n_count) -> dst1 / mask1 (as j - n_split).
                             * n_split must be a multiple of 64 or 32 (the channel tile) */
   seg_view dst1, mask1;
+  seg_view pool;           /* nullable ptr: also write the 2x2/s2 VALID max-pool of the output ([pool_h = Ho/2, pool_w = Wo/2], same
+                            * channels) -- slim.max_pool2d fused into the producing conv; SEG_ERR_UNSUPPORTED when the layer's
+                            * tile cannot carry it (ask seg_conv2d_kernel_name first, or fall back to seg_maxpool2x2_fwd) */
+  int32_t pool_h, pool_w;
 } seg_conv_desc;
 
 /* slim.convolution2d / conv2d_transpose fwd, Conv2DBackpropInput: models/unet.py:111-166,

@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
                 ('n_off', C.c_int32), ('n_count', C.c_int32), ('bias', C.c_void_p), ('bias_n', C.c_int32),
                 ('dst', View), ('up2', C.c_int32), ('up_cout', C.c_int32), ('mask', View), ('relu', C.c_int32),
                 ('out_f32', C.c_int32), ('dtype', C.c_int32), ('cfg', C.c_int32), ('accum', C.c_int32),
-                ('n_split', C.c_int32), ('dst1', View), ('mask1', View)]
+                ('n_split', C.c_int32), ('dst1', View), ('mask1', View), ('pool', View), ('pool_h', C.c_int32), ('pool_w', C.c_int32)]
 
 
 class WgradDesc(C.Structure):

@@ -56,7 +56,7 @@ SEG_DEV void epi_setup(const seg_conv_desc& d, int n0, int wn, int g, EpiCtx<NJ>
   }
 }
 
-template <typename T, int TH, int TW, int BN, int WM, int WN, int FM, int FN>
+template <typename T, int TH, int TW, int BN, int WM, int WN, int FM, int FN, bool POOL = false>
 SEG_DEV void conv_epilogue(const seg_conv_desc& d, f32x4 (&acc)[FN][FM], const EpiCtx<FN / 2>& E, int b, int oy0, int ox0, int wm, int lr) {
   constexpr int BM = TH * TW, NJ = FN / 2;
   const int sc = d.up2 ? 2 : 1;
@@ -89,6 +89,38 @@ SEG_DEV void conv_epilogue(const seg_conv_desc& d, f32x4 (&acc)[FN][FM], const E
           old[j][fm].load(reinterpret_cast<const T*>(d.dst.ptr) + dbase + poff_d[fm] + (E.ua[j] * d.dst.W + E.uc[j]) * d.dst.cs + E.co[j]);
   }
   const float lo = d.relu ? 0.f : -INFINITY;
+  if constexpr (POOL) {
+    // Fused 2x2/s2 VALID max-pool of this layer's output (the slim.max_pool2d that consumes it): with the 8x16 tile a wave
+    // owns two full tile rows, fragment fm = row 2*wm + fm, lane lr = column -- the 2x2 window is (fm 0, fm 1) x (lane,
+    // lane^1).  Pooling the bf16-ROUNDED values gives the bits the separate pool kernel would produce.
+    static_assert(TW == 16 && WM == 4 && FM == 2, "pool fusion needs the 8x16 tile");
+    T* pbase = reinterpret_cast<T*>(d.pool.ptr) + ((int64_t)(b * d.pool.H + d.pool.oy) * d.pool.W + d.pool.ox) * d.pool.cs + d.pool.coff;
+    const int py = (oy0 >> 1) + wm, px = (ox0 + lr) >> 1;
+    const bool pst = (lr & 1) == 0 && py < d.pool_h && px < d.pool_w;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (!E.on[j]) continue;
+      Vec8<T> o[2];
+#pragma unroll
+      for (int fm = 0; fm < 2; ++fm) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[fm].set(e, fmaxf(acc[2 * j][fm][e] + E.bv[j][e], lo));
+          o[fm].set(4 + e, fmaxf(acc[2 * j + 1][fm][e] + E.bv[j][4 + e], lo));
+        }
+        if (poff_d[fm] >= 0) o[fm].store(reinterpret_cast<T*>(d.dst.ptr) + dbase + poff_d[fm] + E.co[j]);
+      }
+      Vec8<T> m;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = fmaxf(o[0].get(e), o[1].get(e));
+        t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true)));   // lane ^ 1
+        m.set(e, t);
+      }
+      if (pst) m.store(pbase + ((int64_t)py * d.pool.W + px) * d.pool.cs + E.co[j]);
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     if (!E.on[j]) continue;
@@ -133,7 +165,7 @@ SEG_DEV void select_dst(seg_conv_desc& d, int n0) {
   }
 }
 
-template <int DT, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S>
+template <int DT, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, bool POOL = false>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
   using T = typename DtSel<DT>::type;
   using TT = Tr<T>;
@@ -275,7 +307,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
 
   EpiCtx<FN / 2> epi;                              // all bias loads issued together (one latency), then the mask loads
   epi_setup<BN, WN, FN / 2>(d, n0, wn, g, epi);
-  conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN>(d, acc, epi, b, oy0, ox0, wm, lr);
+  conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN, POOL>(d, acc, epi, b, oy0, ox0, wm, lr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -726,11 +758,11 @@ __global__ __launch_bounds__(256 + 64 * NLOAD) void conv_ws_kernel(const ConvK P
 thread_local char* g_name_out = nullptr;   // when set, launches are dry: only the kernel name is reported
 thread_local int g_name_cap = 0;
 
-template <typename T, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S>
+template <typename T, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, bool POOL = false>
 int launch_cfg(const ConvK& P0, hipStream_t st) {
   using TT = Tr<T>;
   if (g_name_out) {
-    snprintf(g_name_out, g_name_cap, "conv_fwd_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, WM, WN, KH, KW, S);
+    snprintf(g_name_out, g_name_cap, POOL ? "conv_fwd_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,1>" : "conv_fwd_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, WM, WN, KH, KW, S);
     return SEG_OK;
   }
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
@@ -740,7 +772,7 @@ int launch_cfg(const ConvK& P0, hipStream_t st) {
   P.tiles_x = cdiv(P.d.Wo, TW);
   P.tiles_y = cdiv(P.d.Ho, TH);
   if (P.d.n_count % BN != 0 || P.d.n_split % BN != 0) { seg_set_error("conv: n_count %d / n_split %d not a multiple of BN %d", P.d.n_count, P.d.n_split, BN); return SEG_ERR_ARG; }
-  auto kern = conv_fwd_kernel<Tr<T>::DT, TH, TW, BN, WM, WN, KH, KW, S>;
+  auto kern = conv_fwd_kernel<Tr<T>::DT, TH, TW, BN, WM, WN, KH, KW, S, POOL>;
   static bool attr_done = false;
   if (!attr_done && LDS > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -851,6 +883,18 @@ int launch_k(const ConvK& P, hipStream_t st) {
       seg_set_error("conv: unknown cfg %d", cfg); return SEG_ERR_ARG;
     }
   }
+  if (d.pool.ptr) {
+    // fused max-pool: only the 8x16 register-staged tiles carry it (bf16, 3x3/s1); anything else is refused so that the
+    // caller keeps the separate pool launch (it asks seg_conv2d_kernel_name first)
+    if constexpr (sizeof(T) == 2 && KH == 3 && S == 1) {
+      const long w1 = waste(d.Ho, d.Wo, 8, 16), w3 = waste(d.Ho, d.Wo, 8, 8);
+      if (!d.up2 && !d.accum && !d.out_f32 && d.n_split == 0 && !d.mask.ptr && (cfg == 0 || cfg == 1 || cfg == 2) && 4 * w1 <= 5 * w3) {
+        if ((cfg == 0 || cfg == 1) && d.n_count % 64 == 0) return launch_cfg<T, 8, 16, 64, 4, 1, KH, KW, S, true>(P, st);
+        if (cfg != 1) return launch_cfg<T, 8, 16, 32, 4, 1, KH, KW, S, true>(P, st);
+      }
+    }
+    seg_set_error("conv: fused max-pool is not available for this layer / tile"); return SEG_ERR_UNSUPPORTED;
+  }
   if (cfg <= 0) {
     // Tile choice by a two-term cost model calibrated on MI355X micro-benchmarks: a workgroup costs its MACs per
     // K step (BM*BN) plus a fixed part (prologue, first-load latency, epilogue ~ 5000 MAC-equivalents), and the
@@ -948,6 +992,10 @@ extern "C" int seg_conv2d(const seg_conv_desc* dp, void* stream) {
   if (d.src0.oy + d.Hi > d.src0.H || d.src0.ox + d.Wi > d.src0.W || d.src0.coff + d.src0.c > d.src0.cs ||
       (d.src1.ptr && (d.src1.oy + d.Hi > d.src1.H || d.src1.ox + d.Wi > d.src1.W || d.src1.coff + d.src1.c > d.src1.cs))) {
     seg_set_error("conv: source window exceeds its buffer"); return SEG_ERR_ARG;
+  }
+  if (d.pool.ptr) {
+    if (d.pool_h != d.Ho / 2 || d.pool_w != d.Wo / 2 || d.pool_h < 1 || d.pool_w < 1 || d.pool.oy + d.pool_h > d.pool.H || d.pool.ox + d.pool_w > d.pool.W ||
+        d.pool.coff + d.n_count > d.pool.cs || d.pool.cs % 8 || d.pool.coff % 8) { seg_set_error("conv: bad pooled destination"); return SEG_ERR_ARG; }
   }
   if (d.n_split != 0) {
     if (d.n_split < 0 || d.n_split >= d.n_count || d.n_split % 32 || d.up2 || d.accum || d.out_f32 || !d.dst1.ptr) { seg_set_error("conv: bad n_split %d (needs 0 < n_split < n_count, multiple of 32, no up2/accum/out_f32)", d.n_split); return SEG_ERR_ARG; }

@@ -377,6 +377,7 @@ class Net(object):
         self.n_wgrad_streams = 2
         self._wg_rr = 0
         self.side_enabled = True
+        self.pool_fused = False
         self.tune = load_tuning() if dtype == L.SEG_BF16 else {}
 
     def _tuned(self, d):
@@ -414,8 +415,11 @@ class Net(object):
                  1 if layer.relu else 0, self.dtype, kernel=kern, flops=fl)
         return False
 
-    def conv_fwd(self, plan, layer, srcs, Hi, Wi, dst, dst_off=(0, 0), out_f32=False, cfg=0):
-        """srcs: list of (Act, oy, ox) (1 or 2 concat segments)."""
+    def conv_fwd(self, plan, layer, srcs, Hi, Wi, dst, dst_off=(0, 0), out_f32=False, cfg=0, pool=None):
+        """srcs: list of (Act, oy, ox) (1 or 2 concat segments).  pool: Act of the 2x2 max-pool that consumes dst; when the
+        layer's tile can carry it the pooled map is written by the same launch and `self.pool_fused` is set (else the
+        caller emits pool_fwd)."""
+        self.pool_fused = False
         k, pad = layer.k, layer.pad
         Ho, Wo = Hi + 2 * pad - k + 1, Wi + 2 * pad - k + 1
         d = L.ConvDesc()
@@ -433,9 +437,18 @@ class Net(object):
         d.out_f32 = 1 if out_f32 else 0
         d.dtype = self.dtype; d.cfg = cfg
         self._tuned(d)
+        name = layer.name
+        if pool is not None and self.dtype == L.SEG_BF16 and dst_off == (0, 0) and os.environ.get('SEG_FUSE_POOL', '1') != '0':
+            d.pool = pool.view(); d.pool_h, d.pool_w = pool.H, pool.W
+            buf = C.create_string_buffer(160)
+            if self.lib.seg_conv2d_kernel_name(C.byref(d), buf, 160) == 0:        # the library accepts the fused form for this layer
+                self.pool_fused = True
+                name += '+pool'
+            else:
+                d.pool = L.null_view(); d.pool_h = d.pool_w = 0
         plan.keep.append(d)
         fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
-        plan.add(layer.name, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl)
+        plan.add(name, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl)
         plan.flops += fl
         return Ho, Wo
 

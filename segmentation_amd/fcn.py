@@ -117,7 +117,8 @@ class FCNModel(BaseModel):
                 pooled = net.first_fwd(plan, Ly[name], x_in, H, W, A[name], pool=P)
                 net.join_aux(plan)         # packed weights needed from here on
             else:
-                net.conv_fwd(plan, Ly[name], [(prev, 0, 0)], h, w, A[name])
+                net.conv_fwd(plan, Ly[name], [(prev, 0, 0)], h, w, A[name], pool=P)      # pool fused where the tile allows
+                pooled = net.pool_fused
             h, w = h // 2, w // 2
             if not pooled:
                 net.pool_fwd(plan, A[name], P, h, w)

@@ -150,21 +150,22 @@ class UNetModel(BaseModel):
             net.conv_fwd(plan, Ly['conv1_2'], [(A['conv1_1'], 0, 0)], sh['conv1_1'], sw['conv1_1'], A['conv1_2'])
             skip4_off = (o4h, o4w)
         prev, ph, pw = A['conv1_1'], sh['conv1_1'], sw['conv1_1']
+        pooled = pool1_done                  # the pool of `prev` has already been written by the launch that produced it
         for i in (2, 3, 4, 5):
-            if i == 2:
-                P = A['pool1']
-                if not pool1_done:
-                    net.pool_fwd(plan, prev, P, P.H, P.W)
-            else:
-                P = net.act(sh['pool%d' % (i - 1)], sw['pool%d' % (i - 1)], prev.C, name='pool%d' % (i - 1))
+            P = A['pool%d' % (i - 1)]
+            if not pooled:
                 net.pool_fwd(plan, prev, P, P.H, P.W)
-            A['pool%d' % (i - 1)] = P
             c1, c2 = 'conv%d_1' % i, 'conv%d_2' % i
             A[c1] = net.act(sh[c1], sw[c1], Ly[c1].cout, name=c1)
             net.conv_fwd(plan, Ly[c1], [(P, 0, 0)], P.H, P.W, A[c1])
             A[c2] = net.act(sh[c2], sw[c2], Ly[c2].cout, name=c2)
-            net.conv_fwd(plan, Ly[c2], [(A[c1], 0, 0)], sh[c1], sw[c1], A[c2])
-            if dropout is not None and c2 in dropout['sites']:
+            drop = dropout is not None and c2 in dropout['sites']
+            nxt = None
+            if i < 5:                        # conv i_2 feeds pool i: fuse the pool into its epilogue where the tile allows
+                nxt = A['pool%d' % i] = net.act(sh['pool%d' % i], sw['pool%d' % i], Ly[c2].cout, name='pool%d' % i)
+            net.conv_fwd(plan, Ly[c2], [(A[c1], 0, 0)], sh[c1], sw[c1], A[c2], pool=None if drop else nxt)
+            pooled = net.pool_fused
+            if drop:
                 net.dropout(plan, A[c2], dropout['keep'], dropout['seed'] + i, dropout['offset'])
             prev = A[c2]
         skip_off = {}

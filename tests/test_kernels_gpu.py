@@ -123,6 +123,31 @@ def test_conv_fwd_bwd(dtype, case):
         c0 += c
 
 
+@pytest.mark.parametrize('cin,cout,H,W,padding', [(64, 64, 23, 37, 'VALID'), (32, 32, 34, 34, 'SAME'), (128, 96, 19, 50, 'VALID')])
+def test_conv_with_fused_maxpool(cin, cout, H, W, padding):
+    """seg_conv_desc.pool: same activation bits as the plain launch, pooled map == 2x2 max-pool of those bits."""
+    dtype = L.SEG_BF16
+    rng = np.random.default_rng(cin + H)
+    layer = E.Layer('c', 'conv', 3, [cin], cout, padding, True)
+    p = {'c': _rand_params(layer, rng, dtype)}
+    store = U.make_store([layer], dtype, p)
+    B = 3
+    net = E.Net(store, B, dtype, U.dev())
+    x = net.act(H, W, cin); U.fill_act(x, U.round_dtype(rng.standard_normal((B, H, W, cin)), dtype))
+    pad = layer.pad
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    y0 = net.act(Ho, Wo, cout); y1 = net.act(Ho, Wo, cout); pooled = net.act(Ho // 2, Wo // 2, cout)
+    plan = E.Plan('t')
+    net.conv_fwd(plan, layer, [(x, 0, 0)], H, W, y0)
+    net.conv_fwd(plan, layer, [(x, 0, 0)], H, W, y1, pool=pooled)
+    assert net.pool_fused and plan.ops[-1][0] == 'c+pool'
+    plan.run(U.stream()); U.sync()
+    assert torch.equal(y0.t, y1.t)
+    o = y0.t.to(torch.float32)[:, :Ho // 2 * 2, :Wo // 2 * 2]
+    want = torch.maximum(torch.maximum(o[:, 0::2, 0::2], o[:, 0::2, 1::2]), torch.maximum(o[:, 1::2, 0::2], o[:, 1::2, 1::2]))
+    assert torch.equal(pooled.t.to(torch.float32), want)
+
+
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('case', [(64, 32, 8, 8, 2), (32, 32, 36, 36, 1), (128, 64, 5, 7, 2), (24, 8, 6, 6, 1)])
 def test_upconv_fwd_bwd(dtype, case):
