@@ -762,7 +762,8 @@ template <typename T, int TH, int TW, int BN, int WM, int WN, int KH, int KW, in
 int launch_cfg(const ConvK& P0, hipStream_t st) {
   using TT = Tr<T>;
   if (g_name_out) {
-    snprintf(g_name_out, g_name_cap, POOL ? "conv_fwd_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,1>" : "conv_fwd_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, WM, WN, KH, KW, S);
+    // (the fused-pool instance reports under the same name: same tile, same main loop, one more store per window)
+    snprintf(g_name_out, g_name_cap, "conv_fwd_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, WM, WN, KH, KW, S);
     return SEG_OK;
   }
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;

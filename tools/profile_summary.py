@@ -21,6 +21,8 @@ def pretty(name):
             return re.sub(r'^_ZN\d+_GLOBAL__N_1\d+', '', k.group(1)) if k else name[:48]
     else:
         kname = m.group(1); args = [a.strip() for a in m.group(2).split(',')]
+        if kname == 'conv_fwd_kernel' and len(args) == 10:      # trailing POOL flag: same family as the plain instance
+            args = args[:9]
     if kname != 'conv_fwd_glds_kernel':
         args[0] = {'0': 'f32', '1': 'bf16'}.get(args[0], args[0])
     return '%s<%s>' % (kname, ','.join(args))
@@ -41,10 +43,14 @@ def main():
     os.makedirs(root, exist_ok=True)
     st = glob.glob(os.path.join(stats_dir, '*', '*kernel_stats.csv'))[0]
     rows = list(csv.DictReader(open(st)))
+    merged = collections.OrderedDict()          # template instances that differ only in a dropped flag share a row
+    for r in rows:
+        a = merged.setdefault(pretty(r['Name']), [0, 0.0, 0.0])
+        a[0] += int(r['Calls']); a[1] += float(r['TotalDurationNs']); a[2] += float(r['Percentage'])
     with open(os.path.join(root, tag + '_kernel_stats.csv'), 'w') as f:
         w = csv.writer(f); w.writerow(['kernel', 'calls', 'total_ms', 'avg_us', 'percent'])
-        for r in rows:
-            w.writerow([pretty(r['Name']), r['Calls'], '%.3f' % (float(r['TotalDurationNs']) / 1e6), '%.2f' % (float(r['AverageNs']) / 1e3), r['Percentage']])
+        for k, (calls, tot, pct) in sorted(merged.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([k, calls, '%.3f' % (tot / 1e6), '%.2f' % (tot / calls / 1e3), '%.4g' % pct])
     fetch, write = pmc(fetch_dir, 'FETCH_SIZE'), pmc(write_dir, 'WRITE_SIZE')
     out = {}
     for k in sorted(set(fetch) | set(write)):
