@@ -525,8 +525,11 @@ __device__ long long* g_stamps = nullptr;      // debug builds only: [workgroup]
 #endif
 
 
-template <int TH, int TW, int BN, int WM, int WN, int NLOAD>
-__global__ __launch_bounds__(256 + 64 * NLOAD) void conv_ws_kernel(const ConvK P) {
+// TEAMS = 2: two groups of four consumer waves work on ALTERNATE tiles, the second one shifted by one stage, so that one
+// team's epilogue / tile setup runs in the shadow of the other team's MFMAs (each SIMD then holds one wave of either team).
+// Ring order: stage q = TEAMS*j + t is team t's j-th stage; interval i (one s_barrier each) has team t on its stage i - t.
+template <int TH, int TW, int BN, int WM, int WN, int NLOAD, int TEAMS>
+__global__ __launch_bounds__(256 * TEAMS + 64 * NLOAD) void conv_ws_kernel(const ConvK P) {
   using T = bf16_t;
   using TT = Tr<T>;
   constexpr int KW = 3, NT = 9, BM = TH * TW;
@@ -549,17 +552,21 @@ __global__ __launch_bounds__(256 + 64 * NLOAD) void conv_ws_kernel(const ConvK P
   char* sS = smem + wbytes;
   const int ntiles = d.B * P.tiles_y * P.tiles_x;
   const int nk = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // pixel tiles of this workgroup
-  const int total = nk * P.nchunks;                                                       // stages it consumes
+  const int nkt = (nk + TEAMS - 1) / TEAMS;                                               // tiles per team (the last may be missing)
+  const int S = nkt * P.nchunks;                                                          // stages per team
+  const int Q = TEAMS * S;                                                                // ring sequence length
+  const int J = S + TEAMS - 1;                                                            // intervals = barriers every wave executes
+  constexpr int NCW = 4 * TEAMS;                                                          // consumer waves
   const T* wp = reinterpret_cast<const T*>(d.w_packed);
 #ifdef SEG_STAMPS
-  long long* stp = (g_stamps && blockIdx.y == 0 && blockIdx.x < 64) ? g_stamps + ((int64_t)blockIdx.x * 8 + wave) * 96 : nullptr;
+  long long* stp = (g_stamps && blockIdx.y == 0 && blockIdx.x < 64) ? g_stamps + ((int64_t)blockIdx.x * 12 + (wave >= NCW ? 11 : wave)) * 96 : nullptr;
 #endif
   SEG_STAMP(2, 0);
 
   // ---- filters: LDS rows ((chunk*9 + tap)*BN + row), same piece swizzle as the tiled kernels ----
   {
     const int winst = P.nchunks * NT * BN * 4 / 64;
-    for (int j = wave; j < winst; j += 4 + NLOAD) {
+    for (int j = wave; j < winst; j += NCW + NLOAD) {
       const int piece = j * 64 + lane;
       const int rowg = piece >> 2, h = (piece & 3) ^ ((rowg >> 1) & 2);
       const int c = rowg / (NT * BN), rem = rowg - c * (NT * BN);
@@ -570,9 +577,9 @@ __global__ __launch_bounds__(256 + 64 * NLOAD) void conv_ws_kernel(const ConvK P
   }
   SEG_STAMP(2, 1);
 
-  if (wave >= 4) {
-    // ================= loader waves: wave 4+j fills instructions j, j+NLOAD, ... of every stage =================
-    const int lw = wave - 4;
+  if (wave >= NCW) {
+    // ================= loader waves: wave NCW+j fills instructions j, j+NLOAD, ... of every stage =================
+    const int lw = wave - NCW;
     int spy[LPI], spx[LPI], sh[LPI];
 #pragma unroll
     for (int i = 0; i < LPI; ++i) {
@@ -582,52 +589,67 @@ __global__ __launch_bounds__(256 + 64 * NLOAD) void conv_ws_kernel(const ConvK P
       spy[i] = q < NPIX ? q / PW : -100000;                  // pieces past the patch always read the zero word
       spx[i] = q % PW;
     }
-    int off0[LPI], off1[LPI];
-    const T* src0 = nullptr; const T* src1 = nullptr;
-    int ik = 0, ic = 0;
-    auto set_tile = [&](int k) {
-      int t = blockIdx.x + k * gridDim.x;
+    int off0[TEAMS][LPI], off1[TEAMS][LPI];
+    const T* src0[TEAMS]; const T* src1[TEAMS];
+    auto set_tile = [&](int t_, int k) {            // offsets of team t_'s tile k (k >= nk: a missing tile -> zero fills)
+      const bool real = k < nk;
+      int t = blockIdx.x + (real ? k : 0) * gridDim.x;
       const int tx = t % P.tiles_x; t /= P.tiles_x;
       const int ty = t % P.tiles_y; const int b = t / P.tiles_y;
       const int iy0 = ty * TH - d.pad_t, ix0 = tx * TW - d.pad_l;
-      src0 = reinterpret_cast<const T*>(d.src0.ptr) + (int64_t)b * d.src0.H * d.src0.W * d.src0.cs;
-      src1 = reinterpret_cast<const T*>(d.src1.ptr) + (int64_t)b * d.src1.H * d.src1.W * d.src1.cs;
+      src0[t_] = reinterpret_cast<const T*>(d.src0.ptr) + (int64_t)b * d.src0.H * d.src0.W * d.src0.cs;
+      src1[t_] = reinterpret_cast<const T*>(d.src1.ptr) + (int64_t)b * d.src1.H * d.src1.W * d.src1.cs;
 #pragma unroll
       for (int i = 0; i < LPI; ++i) {
         const int iy = iy0 + spy[i], ix = ix0 + spx[i];
-        const bool in = iy >= 0 && iy < d.Hi && ix >= 0 && ix < d.Wi;
-        off0[i] = in ? ((iy + d.src0.oy) * d.src0.W + ix + d.src0.ox) * d.src0.cs + d.src0.coff + sh[i] : -1;
-        off1[i] = in ? ((iy + d.src1.oy) * d.src1.W + ix + d.src1.ox) * d.src1.cs + d.src1.coff + sh[i] : -1;
+        const bool in = real && iy >= 0 && iy < d.Hi && ix >= 0 && ix < d.Wi;
+        off0[t_][i] = in ? ((iy + d.src0.oy) * d.src0.W + ix + d.src0.ox) * d.src0.cs + d.src0.coff + sh[i] : -1;
+        off1[t_][i] = in ? ((iy + d.src1.oy) * d.src1.W + ix + d.src1.ox) * d.src1.cs + d.src1.coff + sh[i] : -1;
       }
     };
-    auto issue_next = [&](int slot) {
-      const bool first = ic < P.nchunks0;
-      const T* sb = first ? src0 + ic * 32 : src1 + (ic - P.nchunks0) * 32;
-      char* buf = sS + slot * STAGE;
+    int next = 0;                                    // next ring sequence index to issue
+    auto issue_next = [&]() {
+      const int t_ = next % TEAMS, j = next / TEAMS;
+      const int ic = j % P.nchunks;
+      if (ic == 0) {
 #pragma unroll
-      for (int i = 0; i < LPI; ++i) {
-        const int off = first ? off0[i] : off1[i];
-        glds16(off >= 0 ? (const void*)(sb + off) : (const void*)g_zero16, buf + (i * NLOAD + lw) * 1024);
+        for (int tt = 0; tt < TEAMS; ++tt) if (tt == t_) set_tile(tt, TEAMS * (j / P.nchunks) + tt);
       }
-      if (++ic == P.nchunks) { ic = 0; ++ik; if (ik < nk) set_tile(ik); }
+      const bool first = ic < P.nchunks0;
+      char* buf = sS + (next % NST) * STAGE;
+#pragma unroll
+      for (int tt = 0; tt < TEAMS; ++tt) {
+        if (tt != t_) continue;
+        const T* sb = first ? src0[tt] + ic * 32 : src1[tt] + (ic - P.nchunks0) * 32;
+#pragma unroll
+        for (int i = 0; i < LPI; ++i) {
+          const int off = first ? off0[tt][i] : off1[tt][i];
+          glds16(off >= 0 ? (const void*)(sb + off) : (const void*)g_zero16, buf + (i * NLOAD + lw) * 1024);
+        }
+      }
+      ++next;
     };
-    set_tile(0);
-    for (int i = 0; i < PD; ++i) if (i < total) issue_next(i);
-    int slot = 0;
-    for (int s = 0; s < total; ++s) {
-      const int later = total - 1 - s < PD - 1 ? total - 1 - s : PD - 1;       // stage fills younger than stage s
-      wait_vmcnt(later * LPI);
-      SEG_STAMP(0, s);
-      ws_barrier();                        // stage s is handed over; the consumers are done with stage s-1
-      SEG_STAMP(1, s);
-      if (s + PD < total) issue_next(slot == 0 ? NST - 1 : slot - 1);
-      slot = slot + 1 == NST ? 0 : slot + 1;
+    // stage q (team t = q % TEAMS, its j-th) is consumed during interval j + t, i.e. known consumed at barrier j + t + 1
+    while (next < Q && next < NST) issue_next();
+    for (int i = 0; i < J; ++i) {
+      const int need = TEAMS * i < Q - 1 ? TEAMS * i : Q - 1;              // everything up to here must have landed
+      const int later = next - 1 - need;
+      wait_vmcnt(later > 0 ? later * LPI : 0);
+      SEG_STAMP(0, i);
+      ws_barrier();                        // interval i starts; the consumers are done with interval i-1
+      SEG_STAMP(1, i);
+      while (next < Q) {
+        const int qo = next - NST;         // current occupant of the slot
+        if (qo >= 0 && qo / TEAMS + qo % TEAMS + 1 > i) break;
+        issue_next();
+      }
     }
     return;
   }
 
   // ================= consumer waves =================
-  const int wm = wave / WN, wn = wave % WN;
+  const int team = wave >> 2, cw = wave & 3;
+  const int wm = cw / WN, wn = cw % WN;
   const int lr = lane & 15, g = lane >> 4;
   int a_addr[FN];
 #pragma unroll
@@ -652,11 +674,14 @@ __global__ __launch_bounds__(256 + 64 * NLOAD) void conv_ws_kernel(const ConvK P
   Vec8<T> mk[NJ][FM];
   int poff_d[FM];
   int64_t dbase = 0;
-  int cc = 0, ck = 0, slot = 0;
-  for (int s = 0; s < total; ++s) {
-    SEG_STAMP(0, s);
+  int cc = 0, ck = team;                           // chunk within the tile; index of the tile in this workgroup's list
+  for (int iv = 0; iv < J; ++iv) {
+    SEG_STAMP(0, iv);
     ws_barrier();
-    SEG_STAMP(1, s);
+    SEG_STAMP(1, iv);
+    const int js = iv - team;                        // this team's stage in this interval
+    if (js < 0 || js >= S || ck >= nk) continue;     // shifted start / tail, or the missing last tile of this team
+    const int slot = (TEAMS * js + team) % NST;
     if (cc == 0) {
       int t = blockIdx.x + ck * gridDim.x;
       const int tx = t % P.tiles_x; t /= P.tiles_x;
@@ -719,10 +744,9 @@ __global__ __launch_bounds__(256 + 64 * NLOAD) void conv_ws_kernel(const ConvK P
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    slot = slot + 1 == NST ? 0 : slot + 1;
-    SEG_STAMP(2, 2 + s);
+    SEG_STAMP(2, 2 + iv);
     if (++cc == P.nchunks) {
-      cc = 0; ++ck;
+      cc = 0; ck += TEAMS;
       // ---- epilogue of the finished tile: bias, ReLU / ReLU-grad mask, 16-byte stores ----
       // Two passes: all values first (the only wait is for the mask loads requested a whole tile ago), then the
       // stores back to back -- vmcnt also counts stores on gfx9, so a mask wait between two stores would serialise them.
@@ -815,10 +839,10 @@ int launch_glds(const ConvK& P0, hipStream_t st) {
 
 
 // Weight-stationary launch: grid.x persistent workgroups per BN block walk the pixel tiles.
-template <int TH, int TW, int BN, int WM, int WN, int NLOAD>
+template <int TH, int TW, int BN, int WM, int WN, int NLOAD, int TEAMS = 1>
 int launch_ws(const ConvK& P0, hipStream_t st) {
   if (g_name_out) {
-    snprintf(g_name_out, g_name_cap, "conv_ws_kernel<%d,%d,%d,%d,%d,%d>", TH, TW, BN, WM, WN, NLOAD);
+    snprintf(g_name_out, g_name_cap, "conv_ws_kernel<%d,%d,%d,%d,%d,%d,%d>", TH, TW, BN, WM, WN, NLOAD, TEAMS);
     return SEG_OK;
   }
   constexpr int PINST = ((TH + 2) * (TW + 2) * 4 + 63) / 64;
@@ -837,7 +861,7 @@ int launch_ws(const ConvK& P0, hipStream_t st) {
   if (nst < 2) { seg_set_error("conv_ws: filters leave no room for the patch ring"); return SEG_ERR_ARG; }
   P.nst = nst;
   const int lds = wbytes + nst * PINST * 1024;
-  auto kern = conv_ws_kernel<TH, TW, BN, WM, WN, NLOAD>;
+  auto kern = conv_ws_kernel<TH, TW, BN, WM, WN, NLOAD, TEAMS>;
   static int lds_max = 0;
   if (lds > lds_max) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -851,7 +875,7 @@ int launch_ws(const ConvK& P0, hipStream_t st) {
   int maxwg = ncu * occ / nblk; if (maxwg < 1) maxwg = 1;
   const int rounds = cdiv(ntiles, maxwg);
   const int gx = cdiv(ntiles, rounds);               // balanced: every workgroup walks `rounds` (or rounds-1) tiles
-  SEG_LAUNCH(kern, dim3(gx, nblk), dim3(256 + 64 * NLOAD), lds, st, P);
+  SEG_LAUNCH(kern, dim3(gx, nblk), dim3(256 * TEAMS + 64 * NLOAD), lds, st, P);
   return seg_check_launch("conv_ws");
 }
 
@@ -867,7 +891,7 @@ int launch_k(const ConvK& P, hipStream_t st) {
     // weight-stationary persistent kernel whenever the BN filter rows of all K fit beside the patch ring
     static const int ws_on = getenv("SEG_CONV_WS") ? atoi(getenv("SEG_CONV_WS")) : 0;   // opt-in: not yet faster than the tiled kernels
     const int ntiles = d.B * cdiv(d.Ho, 8) * cdiv(d.Wo, 16);
-    const int bn = (cfg == 51 || cfg == 53) ? 64 : (cfg == 52 || cfg == 54) ? 32 : (d.n_count % 64 == 0 && P.nchunks * 9 * 64 * 64 <= 80 * 1024) ? 64 : 32;
+    const int bn = (cfg == 51 || cfg == 53 || cfg == 55) ? 64 : (cfg == 52 || cfg == 54 || cfg == 56) ? 32 : (d.n_count % 64 == 0 && P.nchunks * 9 * 64 * 64 <= 80 * 1024) ? 64 : 32;
     const bool fits = P.nchunks * 9 * bn * 64 <= 80 * 1024;
     if (cfg >= 50 || (ws_on && fits && (long)ntiles * (d.n_count / bn) >= 512)) {
       if (!fits) { seg_set_error("conv_ws: K %d x BN %d does not fit in LDS", P.nchunks * 32, bn); return SEG_ERR_ARG; }
@@ -876,6 +900,8 @@ int launch_k(const ConvK& P, hipStream_t st) {
       if (sel == 51 && nload == 1) return launch_ws<8, 16, 64, 4, 1, 1>(P, st);
       if (sel == 51 && nload == 2) return launch_ws<8, 16, 64, 4, 1, 2>(P, st);
       if (sel == 51) return launch_ws<8, 16, 64, 4, 1, 4>(P, st);
+      if (sel == 55) return launch_ws<8, 16, 64, 4, 1, 4, 2>(P, st);      // two consumer teams on alternate tiles
+      if (sel == 56) return launch_ws<8, 16, 32, 4, 1, 4, 2>(P, st);
       if (sel == 53) return launch_ws<16, 16, 64, 4, 1, 3>(P, st);     // 256-pixel tiles: 64 ch x 64 px per wave halves the LDS reads per MFMA
       if (sel == 54) return launch_ws<16, 16, 32, 4, 1, 3>(P, st);
       if (sel == 52 && nload == 1) return launch_ws<8, 16, 32, 4, 1, 1>(P, st);

@@ -41,6 +41,11 @@ def _rand_params(layer, rng, dtype):
     (3, 'VALID', [32, 32], 32, 20, 20, 2, True, 52),
     (3, 'SAME', [64, 64], 32, 9, 40, 1, False, 52),
     (3, 'VALID', [32], 32, 130, 130, 8, True, 52),        # > 768 tiles: every workgroup walks several tiles
+    (3, 'VALID', [64], 64, 21, 19, 2, True, 55),          # two consumer teams on alternate tiles
+    (3, 'SAME', [32], 64, 13, 35, 3, True, 55),
+    (3, 'VALID', [32, 32], 32, 20, 20, 2, True, 56),
+    (3, 'VALID', [32], 32, 130, 130, 8, True, 56),        # several tiles per team (odd and even counts)
+    (3, 'VALID', [64], 64, 122, 122, 3, True, 55),
     (3, 'VALID', [160], 32, 21, 19, 1, True, 32),         # N-stage direct-to-LDS rings: 5 K chunks, 3 / 4 stages
     (3, 'VALID', [96, 64], 64, 13, 15, 2, True, 33),
     (3, 'SAME', [192], 32, 10, 10, 2, False, 34),
@@ -104,7 +109,7 @@ def test_conv_fwd_bwd(dtype, case):
     store.g.zero_()
     bplan = E.Plan('b')
     # two-source layers take the merged two-destination dgrad launch (n_split), which the tiled kernels serve
-    dcfg = 0 if (cfg < 50 or len(segs) > 1) else (cfg if all(c % 64 == 0 for c in layer.cin_p) or cfg == 52 else 52)
+    dcfg = 0 if (cfg < 50 or len(segs) > 1) else (cfg if all(c % 64 == 0 for c in layer.cin_p) or cfg in (52, 56) else (56 if cfg == 55 else 52))
     net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs, cfg=dcfg)
     net.flush_reduce(bplan)
     bplan.run(U.stream()); U.sync()

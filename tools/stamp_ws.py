@@ -17,20 +17,20 @@ def run(hw, cin, cout, cfg, B=16):
     plan = E.Plan('m'); net.conv_fwd(plan, layer, [(x, 0, 0)], hw, hw, y, cfg=cfg)
     for _ in range(3): plan.run(s)
     torch.cuda.synchronize()
-    st = torch.zeros(64 * 8 * 96, dtype=torch.int64, device=dev)
+    st = torch.zeros(64 * 12 * 96, dtype=torch.int64, device=dev)
     assert lib.seg_dbg_set_stamps(st.data_ptr()) == 0
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(); plan.run(s); e1.record(); torch.cuda.synchronize()
     lib.seg_dbg_set_stamps(None)
-    a = st.cpu().numpy().reshape(64, 8, 3, 32).astype(np.float64)
+    a = st.cpu().numpy().reshape(64, 12, 3, 32).astype(np.float64)
     print('hw', hw, cin, '->', cout, 'cfg', cfg, 'kernel %.1f us' % (e0.elapsed_time(e1) * 1e3))
     for wg in (17,):
         t0 = a[wg, 0, 2, 0]
-        ns = int((a[wg, 4, 0] > 0).sum())
-        print(' wg', wg, 'start->weights landed: consumer0 %.0f loader %.0f cycles; stages %d' % (a[wg, 0, 2, 1] - t0, a[wg, 4, 2, 1] - t0, ns))
+        ns = int((a[wg, -1, 0] > 0).sum())
+        print(' wg', wg, 'start->weights landed: consumer0 %.0f loader %.0f cycles; stages %d' % (a[wg, 0, 2, 1] - t0, a[wg, -1, 2, 1] - t0, ns))
         print('  stage: loader[wait_done barrier_done] consumer0[barrier_in barrier_out compute_done]  (cycles since wg start)')
         for s_ in range(min(ns, 18)):
-            print('   %2d  L %7.0f %7.0f   C %7.0f %7.0f %7.0f' % (s_, a[wg, 4, 0, s_] - t0, a[wg, 4, 1, s_] - t0, a[wg, 0, 0, s_] - t0, a[wg, 0, 1, s_] - t0, a[wg, 0, 2, 2 + s_] - t0))
+            print('   %2d  L %7.0f %7.0f   C %7.0f %7.0f %7.0f' % (s_, a[wg, -1, 0, s_] - t0, a[wg, -1, 1, s_] - t0, a[wg, 0, 0, s_] - t0, a[wg, 0, 1, s_] - t0, a[wg, 0, 2, 2 + s_] - t0))
 import os
 for c in os.environ.get('CFGS', '51,53').split(','):
     run(122, 64, 64, int(c))
