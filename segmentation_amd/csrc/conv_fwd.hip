@@ -895,7 +895,7 @@ int launch_k(const ConvK& P, hipStream_t st) {
     const bool fits = P.nchunks * 9 * bn * 64 <= 80 * 1024;
     if (cfg >= 50 || (ws_on && fits && (long)ntiles * (d.n_count / bn) >= 512)) {
       if (!fits) { seg_set_error("conv_ws: K %d x BN %d does not fit in LDS", P.nchunks * 32, bn); return SEG_ERR_ARG; }
-      const int sel = cfg >= 50 ? cfg : (bn == 64 ? 51 : 52);
+      const int sel = cfg >= 50 ? cfg : (bn == 64 ? 55 : 56);       // SEG_CONV_WS=1: the two-team form
       static const int nload = getenv("SEG_WS_LOADERS") ? atoi(getenv("SEG_WS_LOADERS")) : 4;
       if (sel == 51 && nload == 1) return launch_ws<8, 16, 64, 4, 1, 1>(P, st);
       if (sel == 51 && nload == 2) return launch_ws<8, 16, 64, 4, 1, 2>(P, st);
