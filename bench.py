@@ -38,7 +38,8 @@ def parse():
     ap.add_argument('--model', default='unet', choices=['unet', 'fcn8s'], help='fcn8s = BASELINE config 3 (use --size 512 --classes 21 --batch 8)')
     ap.add_argument('--nk', type=int, default=32, help='n_kernels')
     ap.add_argument('--dense', action='store_true', help='evaluate conv1_2 densely (no crop-aware window)')
-    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph)')
+    ap.add_argument('--graph', action='store_true', help='always replay the captured hipGraph (default: time both modes during warm-up, keep the faster)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--per-op', action='store_true', help='also print the per-op table to stderr')
@@ -60,7 +61,7 @@ def kernel_table(model, reps=5):
         rows = []
         for plan in (model.fwd_plan, model.bwd_upd_plan):       # the plans the timed step replays
             side = model._side if not os.environ.get('SEG_BENCH_SERIAL') else None
-            rows += plan.run_profiled(stream, torch, side)
+            rows += plan.run_profiled(stream, torch, side, flavor=model._flavor())
         if rep == 0:
             continue               # warm-up
         for i, (op, kern, ms, fl) in enumerate(rows):
@@ -141,6 +142,9 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    probe = None
+    if not args.no_graph and not args.graph:
+        probe = model.autotune_step_mode()          # graph replay vs eager launches: real train steps, part of the warm-up
     for _ in range(args.warmup):
         model.train_step()
     barrier()
@@ -167,7 +171,8 @@ def main():
                                    % ('U-Net' if args.model == 'unet' else 'FCN-8s', args.size, args.size, args.classes, args.batch, args.dtype, args.nk),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
                        'conv1_2': 'dense' if args.dense else 'crop-aware (only the window that survives the last skip crop is computed)',
-                       'hip_graph': not args.no_graph,
+                       'hip_graph': bool(model.use_graph),
+                       'step_mode_probe_ms': None if probe is None else {k: round(v, 4) for k, v in probe.items()},
                        'executed_gflop_per_step_per_gpu': round(flops_step / 1e9, 2),
                        'step_tflops_per_gpu': round(flops_step / (ms * 1e-3) / 1e12, 2),
                        'final_loss': round(loss, 5)},

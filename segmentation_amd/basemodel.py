@@ -177,19 +177,45 @@ class BaseModel(object):
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def _flavor(self):
+        """Which form of the slab reductions the plans run: per layer under hipGraph replay, batched when launched eagerly."""
+        return 'per_layer' if self.use_graph else 'batched'
+
+    def autotune_step_mode(self, steps=40):
+        """Times `steps` real train steps replayed as a hipGraph and launched eagerly and keeps the faster mode (the eager
+        launches win when the host is fast enough: cheaper cross-stream fork points; the graph wins on a slow / shared
+        host).  Returns {'graph': ms, 'eager': ms}.  Data-parallel: every rank adopts the decision of the slowest rank."""
+        res = {}
+        for mode, ug in (('eager', False), ('graph', True)):
+            self.use_graph = ug
+            for _ in range(4):
+                self.train_step()                     # warm-up / capture
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.train_step()
+            torch.cuda.synchronize(self.device)
+            res[mode] = (time.perf_counter() - t0) / steps * 1e3
+        if self.pg.enabled and self.pg.world > 1:
+            t = torch.tensor([res['graph'], res['eager']], dtype=torch.float64, device=self.device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.pg.group)
+            res = {'graph': float(t[0].item()), 'eager': float(t[1].item())}
+        self.use_graph = res['graph'] <= res['eager']
+        return res
+
     def _run_fwd_bwd(self):
         s = self._stream()
         if hasattr(self, '_bound'):
             self._bind_inputs(self.input_x, self.input_y)       # (tests) forward + backward on the model's own input buffers
         # loss accumulator and global_step are handled by the plan's first op (step_begin, aux stream); gradients need no
         # zeroing: every entry is overwritten by its wgrad launch
-        self.fwd_plan.run(s, self._side)
-        self.bwd_plan.run(s, self._side)
+        self.fwd_plan.run(s, self._side, flavor=self._flavor())
+        self.bwd_plan.run(s, self._side, flavor=self._flavor())
 
     def _run_step(self):
         s = self._stream()
-        self.fwd_plan.run(s, self._side)
-        self.bwd_upd_plan.run(s, self._side)
+        self.fwd_plan.run(s, self._side, flavor=self._flavor())
+        self.bwd_upd_plan.run(s, self._side, flavor=self._flavor())
         self._packed_dirty = True
 
     def _run_update(self):
@@ -226,7 +252,14 @@ class BaseModel(object):
             raise Exception('train_step() with INFERENCE mode invalid')
         key = self._bind_batch(self.dataset)
         if not self.pg.enabled:
-            self._replay(('step', key), self._run_step)
+            if self.use_graph and os.environ.get('SEG_HYBRID', '0') != '0':
+                # forward as a graph (a linear chain: nothing to gain from eager launches), backward + Adam launched eagerly
+                # (the cross-stream fork points cost ~7 us eagerly against ~12 us inside a captured graph)
+                self._replay(('fwd', key), lambda: self.fwd_plan.run(self._stream(), self._side, flavor='batched'))
+                self.bwd_upd_plan.run(self._stream(), self._side, flavor='batched')
+                self._packed_dirty = True
+            else:
+                self._replay(('step', key), self._run_step)
         else:
             self._train_step_dp(key)
         self._gs_host += 1
@@ -276,12 +309,12 @@ class BaseModel(object):
         s = self._stream()
 
         def head():
-            self.fwd_plan.run(self._stream(), self._side)
-            self.bwd_segments[0][0].run(self._stream(), self._side)
+            self.fwd_plan.run(self._stream(), self._side, flavor=self._flavor())
+            self.bwd_segments[0][0].run(self._stream(), self._side, flavor=self._flavor())
         self._replay(('dp0', key), head)
         self.pg.all_reduce_bucket(self.store.g, *self.bwd_segments[0][1])
         for i, (plan, (lo, hi)) in enumerate(self.bwd_segments[1:], 1):
-            self._replay('dp%d' % i, lambda plan=plan: plan.run(self._stream(), self._side))
+            self._replay('dp%d' % i, lambda plan=plan: plan.run(self._stream(), self._side, flavor=self._flavor()))
             self.pg.all_reduce_bucket(self.store.g, lo, hi)
         self.pg.wait_all()
         self._replay('upd', self._run_update)

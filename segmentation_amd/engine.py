@@ -164,7 +164,7 @@ class Plan(object):
         self.ops.append((name, fn, args))
         self.meta.append(meta)
 
-    def run(self, stream, side=None, skip=()):
+    def run(self, stream, side=None, skip=(), flavor='per_layer'):
         """Launches every op in order.  Ops tagged side=1 (filter gradients: nothing on the backward critical path
         consumes them) go round-robin onto the `side` torch streams; each first waits for an event recorded on the
         main stream at its program position (so everything launched before it is its dependency) and the side
@@ -172,8 +172,8 @@ class Plan(object):
         sp = C.c_void_p(stream)
         if not side:
             dbg = os.environ.get('SEG_DEBUG_SYNC')        # name every launch on stderr and synchronise after it (fault hunting)
-            for name, fn, args in self.ops:
-                if fn is None or name in skip:
+            for i_, (name, fn, args) in enumerate(self.ops):
+                if fn is None or name in skip or self.meta[i_].get('flavor', flavor) != flavor:
                     continue
                 if dbg:
                     import sys
@@ -206,7 +206,7 @@ class Plan(object):
 
         for i, (name, fn, args) in enumerate(self.ops):
             tag = self.meta[i].get('side', 0)
-            if name in skip:
+            if name in skip or self.meta[i].get('flavor', flavor) != flavor:
                 continue
             if fn is None and name == 'join_all':      # marker: the main stream waits for every side stream used so far
                 flush()
@@ -287,7 +287,7 @@ class Plan(object):
             return buf.value.decode()
         return self.meta[i].get('kernel', fn.__name__ if fn is not None else 'marker')
 
-    def run_profiled(self, stream, torch_mod, side=None):
+    def run_profiled(self, stream, torch_mod, side=None, flavor='per_layer'):
         """Like run(), with a HIP event recorded before and after every launch ON THE STREAM THE KERNEL IS LAUNCHED ON
         (main or side), so that the per-kernel durations include the same cross-stream overlap as the timed region.
         Returns [(op name, kernel name, ms, flops)]."""
@@ -299,6 +299,8 @@ class Plan(object):
         aux = side[-1] if side else None
         for i, (name, fn, args) in enumerate(self.ops):
             tag = self.meta[i].get('side', 0) if side else 0
+            if self.meta[i].get('flavor', flavor) != flavor:
+                continue
             if fn is None and name == 'join_all':
                 for o_ in used.values():
                     ev = torch_mod.cuda.Event(); ev.record(o_); main.wait_event(ev)
@@ -372,7 +374,8 @@ class Net(object):
         # slab reductions of the filter gradients: one launch per layer right behind its wgrad (default: best under
         # hipGraph replay), or batched into one launch per side stream and backward segment (models turn this on for
         # eager execution, where it saves a quarter of the launches; SEG_BATCH_REDUCE=0/1 overrides)
-        self.batch_reduce = os.environ.get('SEG_BATCH_REDUCE', '0') != '0'
+        # None: emit both flavours of the slab reduction (Plan.run chooses); True / False: only the batched / per-layer one
+        self.batch_reduce = None if 'SEG_BATCH_REDUCE' not in os.environ else (os.environ['SEG_BATCH_REDUCE'] != '0')
         self._pending_reduce = {}
         self.n_wgrad_streams = 2
         self._wg_rr = 0
@@ -497,17 +500,19 @@ class Net(object):
         self._wg_rr += 1
         if not self.side_enabled:
             sid = 0                                             # (experiments) keep it on the main stream
-        if w.ksplit > 1 and self.batch_reduce:
-            w.phase = 1
-            self._pending_reduce.setdefault(sid, []).append(w)
-            plan.add(name, self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=sid)
-        elif w.ksplit > 1:
+        if w.ksplit > 1:
+            # the slab reduction exists in two flavours and Plan.run(flavor=...) picks one: 'per_layer' right behind the
+            # partial sums (best under hipGraph replay) or 'batched' per side stream at the end of the segment (best for
+            # eager launches: a quarter fewer launches)
             w.phase = 1
             w2 = L.WgradDesc.from_buffer_copy(w)
             w2.phase = 2
             plan.keep.append(w2)
             plan.add(name, self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=sid)
-            plan.add(name + '/reduce', self.lib.seg_conv2d_wgrad, C.byref(w2), kernel='wgrad_reduce_kernel', side=sid)
+            if self.batch_reduce is not True:
+                plan.add(name + '/reduce', self.lib.seg_conv2d_wgrad, C.byref(w2), kernel='wgrad_reduce_kernel', side=sid, flavor='per_layer')
+            if self.batch_reduce is not False:
+                self._pending_reduce.setdefault(sid, []).append(w)
         else:
             w.phase = 0
             plan.add(name, self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=sid)
@@ -534,7 +539,7 @@ class Net(object):
             jobs = torch.frombuffer(bytearray(host), dtype=torch.uint8)[:96 * nj.value].clone().to(self.device)
             plan.keep += [jobs, arr]
             plan.add('dw/reduce[%d]' % nj.value, self.lib.seg_wgrad_reduce_batch, jobs.data_ptr(), nj.value, nb.value,
-                     kernel='wgrad_reduce_batch_kernel', side=sid)          # sid 0 = main stream
+                     kernel='wgrad_reduce_batch_kernel', side=sid, flavor='batched')          # sid 0 = main stream
 
     def first_im2col(self, plan, layer, x_f32, H, W):
         """im2col of the raw input (27 -> 32 channels) for the first layer's filter gradient.  It depends only on the

@@ -308,7 +308,7 @@ def test_batched_slab_reduction_is_bitwise_the_per_layer_one():
         names = [o[0] for o in plan.ops]
         assert any(n.startswith('dw/reduce[') for n in names) == batched
         store.g.fill_(float('nan'))
-        plan.run(U.stream()); U.sync()
+        plan.run(U.stream(), flavor='batched' if batched else 'per_layer'); U.sync()
         assert bool(torch.isfinite(store.g).all())
         got.append(store.g.clone())
     assert torch.equal(got[0], got[1])
