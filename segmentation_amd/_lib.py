@@ -116,3 +116,26 @@ def check(rc, what=''):
 
 def null_view():
     return View(None, 0, 0, 0, 0, 0, 0, 0)
+
+
+_hip = None
+
+
+def hip_runtime():
+    """ctypes handle of the HIP runtime torch uses, with the three event calls Plan.run needs (raw events carry the
+    hipEventReleaseToDevice flag torch.cuda.Event cannot express: a device-scope release instead of a system-scope one at
+    every fork point)."""
+    global _hip
+    if _hip is None:
+        import torch
+        rt = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+        h = C.CDLL(rt if os.path.exists(rt) else 'libamdhip64.so', mode=C.RTLD_GLOBAL)
+        h.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]; h.hipEventCreateWithFlags.restype = C.c_int
+        h.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]; h.hipEventRecord.restype = C.c_int
+        h.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]; h.hipStreamWaitEvent.restype = C.c_int
+        _hip = h
+    return _hip
+
+
+HIP_EVENT_DISABLE_TIMING = 0x2
+HIP_EVENT_RELEASE_TO_DEVICE = 0x40000000

@@ -150,6 +150,32 @@ class ParamStore(object):
         return self._unflatten(self.g)
 
 
+class _Forks(object):
+    """Cross-stream dependencies of one Plan.run: `dst waits for what src holds now`.  SEG_RAW_EVENTS=1 uses raw HIP
+    events created with hipEventDisableTiming | hipEventReleaseToDevice (recycled from a pool) instead of torch events."""
+
+    pool, raw = [], None
+
+    def __init__(self):
+        if _Forks.raw is None:
+            _Forks.raw = os.environ.get('SEG_RAW_EVENTS', '0') != '0'
+        self.i = 0
+
+    def __call__(self, src, dst):
+        if not _Forks.raw:
+            ev = torch.cuda.Event(); ev.record(src); dst.wait_event(ev)
+            return
+        h = L.hip_runtime()
+        if self.i == len(_Forks.pool):
+            e = C.c_void_p()
+            if h.hipEventCreateWithFlags(C.byref(e), L.HIP_EVENT_DISABLE_TIMING | L.HIP_EVENT_RELEASE_TO_DEVICE) != 0:
+                raise L.SegError('hipEventCreateWithFlags failed')
+            _Forks.pool.append(e)
+        e = _Forks.pool[self.i]; self.i += 1
+        if h.hipEventRecord(e, C.c_void_p(src.cuda_stream)) != 0 or h.hipStreamWaitEvent(C.c_void_p(dst.cuda_stream), e, 0) != 0:
+            raise L.SegError('hipEventRecord / hipStreamWaitEvent failed')
+
+
 class Plan(object):
     """Ordered list of C-ABI launches.  Every entry is (name, fn, args-without-stream)."""
 
@@ -185,6 +211,7 @@ class Plan(object):
                     torch.cuda.synchronize()
             return
         main = torch.cuda.current_stream()
+        fork = _Forks()
         used = {}
         aux = side[-1]                   # dedicated stream for side='aux' ops (weight re-pack), joined by a 'join_aux' marker
         aux_used = False
@@ -211,13 +238,13 @@ class Plan(object):
             if fn is None and name == 'join_all':      # marker: the main stream waits for every side stream used so far
                 flush()
                 for o_ in used.values():
-                    ev = torch.cuda.Event(); ev.record(o_); main.wait_event(ev)
+                    fork(o_, main)
                 if aux_used:
-                    ev = torch.cuda.Event(); ev.record(aux); main.wait_event(ev)
+                    fork(aux, main)
                 continue
             if fn is None:               # marker: make the main stream wait for the aux stream
                 if aux_used:
-                    ev = torch.cuda.Event(); ev.record(aux); main.wait_event(ev)
+                    fork(aux, main)
                     aux_used = False
                 continue
             if tag == 'aux' or tag == 'aux_join':
@@ -225,8 +252,8 @@ class Plan(object):
                     flush()
                     for o_ in used.values():             # everything the filter-gradient streams hold so far
                         if o_ is not aux:
-                            ev = torch.cuda.Event(); ev.record(o_); aux.wait_event(ev)
-                ev = torch.cuda.Event(); ev.record(main); aux.wait_event(ev)
+                            fork(o_, aux)
+                fork(main, aux)
                 aux_used = True
                 rc = fn(*args, C.c_void_p(aux.cuda_stream))
             elif tag:
@@ -237,13 +264,13 @@ class Plan(object):
                 if batch > 0:
                     pending.append((None, st, fn, args, name))
                     continue
-                ev = torch.cuda.Event(); ev.record(main)
                 if defer:
                     # same dependencies, but the side launch is ISSUED after the next main-stream launch: under capture
                     # the main-stream successor then is the first child of its predecessor (graph order)
+                    ev = torch.cuda.Event(); ev.record(main)
                     pending.append((ev, st, fn, args, name))
                     continue
-                st.wait_event(ev)
+                fork(main, st)
                 rc = fn(*args, C.c_void_p(st.cuda_stream))
             else:
                 rc = fn(*args, sp)
@@ -257,7 +284,7 @@ class Plan(object):
         if aux_used:
             used[id(aux)] = aux
         for st in used.values():
-            ev = torch.cuda.Event(); ev.record(st); main.wait_event(ev)
+            fork(st, main)
 
     def rebind(self, mapping):
         """Replaces raw device pointers among the launch arguments ({old: new}; the network inputs when a device-resident
