@@ -106,3 +106,27 @@ def test_device_prefetcher_feeds_identical_batches():
         assert torch.equal(a.store.p, b.store.p)
     finally:
         pf.stop()
+
+
+def test_zero_copy_device_batches_equal_copied_ones(monkeypatch):
+    """Device-resident batches consumed in place (launch arguments re-pointed, one graph per buffer) vs copied into the
+    model's own input buffers: identical parameters after a few steps, in graph and in eager mode."""
+    import numpy as np
+    from segmentation_amd.datasets import SyntheticDataSet
+    from segmentation_amd.unet import UNetModel
+    out = {}
+    for zc in ('1', '0'):
+        for graph in (True, False):
+            monkeypatch.setenv('SEG_ZERO_COPY', zc)
+            ds = SyntheticDataSet(2, 188, 3, seed=11, n_batches=3)
+            m = UNetModel(sess=None, dataset=ds, n_classes=3, input_dims=188, learning_rate=1e-3, log_dir=None, save_dir=None,
+                          load_snapshot=False, dtype='bf16', use_graph=graph, seed=3)
+            for _ in range(7):
+                m.train_step()
+            torch.cuda.synchronize()
+            out[(zc, graph)] = (m.store.p.clone(), m.last_loss())
+            if zc == '1':
+                assert len(m._slots) == 3          # three dataset buffers were bound in place
+    ref = out[('0', False)]
+    for k, v in out.items():
+        assert torch.equal(v[0], ref[0]) and v[1] == ref[1], k
