@@ -172,7 +172,7 @@ def main():
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
                        'conv1_2': 'dense' if args.dense else 'crop-aware (only the window that survives the last skip crop is computed)',
                        'hip_graph': bool(model.use_graph),
-                       'step_mode_probe_ms': None if probe is None else {k: round(v, 4) for k, v in probe.items()},
+                       'step_mode_probe_ms': None if not probe else {k: round(v, 4) for k, v in probe.items()},
                        'executed_gflop_per_step_per_gpu': round(flops_step / 1e9, 2),
                        'step_tflops_per_gpu': round(flops_step / (ms * 1e-3) / 1e12, 2),
                        'final_loss': round(loss, 5)},
