@@ -27,3 +27,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _restore_default_stream(request):
+    """Eager-mode training makes its high-priority stream the thread's current stream (BaseModel.train_step); every GPU
+    test starts and ends on the default stream with the device idle, so tests do not see each other's streams."""
+    yield
+    if 'gpu' in request.keywords and _has_gpu():
+        import torch
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream())
