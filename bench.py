@@ -59,7 +59,7 @@ def kernel_table(model, reps=5):
     for rep in range(reps + 1):
         model.loss_buf.zero_()
         rows = []
-        for plan in (model.fwd_plan, model.bwd_upd_plan):       # the plans the timed step replays
+        for plan in (model.step_plan,):                         # the plan the timed step runs
             side = model._side if not os.environ.get('SEG_BENCH_SERIAL') else None
             rows += plan.run_profiled(stream, torch, side, flavor=model._flavor())
         if rep == 0:

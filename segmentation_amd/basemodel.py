@@ -224,8 +224,7 @@ class BaseModel(object):
 
     def _run_step(self):
         s = self._stream()
-        self.fwd_plan.run(s, self._side, flavor=self._flavor())
-        self.bwd_upd_plan.run(s, self._side, flavor=self._flavor())
+        self.step_plan.run(s, self._side, flavor=self._flavor())
         self._packed_dirty = True
 
     def _run_update(self):
@@ -303,6 +302,7 @@ class BaseModel(object):
             if self._bound[1] != new[1]:
                 m[self._bound[1]] = new[1]
             self.fwd_plan.rebind(m)
+            self.step_plan.rebind(m)
             self._bound = new
         return new
 
@@ -451,6 +451,11 @@ class BaseModel(object):
                 self.net.adam(self.bwd_upd_plan, self.learning_rate, grad_scale=1.0, lo=0, hi=cut, side='aux_join')
         self.net.join_all(self.bwd_upd_plan)           # the last filter gradients / reductions are on the side streams
         self.net.adam(self.bwd_upd_plan, self.learning_rate, grad_scale=1.0, lo=cut, hi=self.store.n)
+        # the whole single-GPU step as ONE plan: no join of the side streams between forward and backward (the only forward
+        # side-stream product, the im2col of the input, is consumed on the same side stream)
+        self.step_plan = E.Plan('step')
+        self.step_plan.extend(self.fwd_plan)
+        self.step_plan.extend(self.bwd_upd_plan)
 
     def set_weights(self, params):
         """Load {scope: {'weights','biases'}} in TF layouts (tests / interchange)."""

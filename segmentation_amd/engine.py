@@ -520,11 +520,12 @@ class Net(object):
         self.ws_bytes = getattr(self, 'ws_bytes', 0) + nbytes.value
         plan.keep += [w, ws]
 
-    def _add_wgrad(self, plan, name, w, fl):
+    def _add_wgrad(self, plan, name, w, fl, sid=None):
         """One plan op for the partial-sum kernel and, when K is split, a second one for the slab reduction (same side
         stream): two C-ABI calls so that each kernel is timed on its own."""
-        sid = 1 + self._wg_rr % self.n_wgrad_streams        # side stream of this layer's filter gradient
-        self._wg_rr += 1
+        if sid is None:
+            sid = 1 + self._wg_rr % self.n_wgrad_streams    # side stream of this layer's filter gradient
+            self._wg_rr += 1
         if not self.side_enabled:
             sid = 0                                             # (experiments) keep it on the main stream
         if w.ksplit > 1:
@@ -598,7 +599,9 @@ class Net(object):
         self._tuned(w)
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
-        self._add_wgrad(plan, layer.name + '/dw', w, fl)
+        # same side stream as the im2col that feeds it (stream 1): in order behind it, so a plan that runs forward and
+        # backward back to back needs no join of the side streams in between
+        self._add_wgrad(plan, layer.name + '/dw', w, fl, sid=1)
         plan.flops += fl
 
     def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0):
