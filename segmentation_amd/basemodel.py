@@ -455,6 +455,8 @@ class BaseModel(object):
         # side-stream product, the im2col of the input, is consumed on the same side stream)
         self.step_plan = E.Plan('step')
         self.step_plan.extend(self.fwd_plan)
+        if self.pg.enabled:
+            self.net.join_all(self.step_plan)           # data-parallel builds do not pin the first layer's filter gradient to the im2col's stream
         self.step_plan.extend(self.bwd_upd_plan)
 
     def set_weights(self, params):

@@ -288,18 +288,27 @@ class Plan(object):
 
     def rebind(self, mapping):
         """Replaces raw device pointers among the launch arguments ({old: new}; the network inputs when a device-resident
-        dataset hands over its own buffers).  Returns the number of arguments changed."""
+        dataset hands over its own buffers).  The argument sites of a pointer are found once and remembered, so the
+        per-step re-pointing touches a handful of launches (the data-parallel step is host-bound: a full scan of two
+        plans per step made it 20 % slower and erratic).  Returns the number of arguments changed."""
+        sites = self.__dict__.setdefault('_ptr_sites', {})
         n = 0
-        for i, (name, fn, args) in enumerate(self.ops):
-            if any(isinstance(a, int) and a in mapping for a in args):
-                self.ops[i] = (name, fn, tuple(mapping.get(a, a) if isinstance(a, int) else a for a in args))
+        for old, new in mapping.items():
+            where = sites.pop(old, None)
+            if where is None:
+                where = [(i, j) for i, (_, _, args) in enumerate(self.ops) for j, a in enumerate(args) if isinstance(a, int) and a == old]
+            for i, j in where:
+                name, fn, args = self.ops[i]
+                self.ops[i] = (name, fn, args[:j] + (new,) + args[j + 1:])
                 n += 1
+            sites[new] = where
         return n
 
     def __len__(self):
         return len(self.ops)
 
     def extend(self, other):
+        self.__dict__.pop('_ptr_sites', None)
         self.ops += other.ops; self.meta += other.meta; self.keep += other.keep; self.flops += other.flops
 
     def kernel_name(self, i):
@@ -582,7 +591,7 @@ class Net(object):
                  self.dtype, kernel='im2col3x3_kernel', side=1)
         return col
 
-    def first_bwd(self, plan, layer, x_f32, H, W, dz, col=None):
+    def first_bwd(self, plan, layer, x_f32, H, W, dz, col=None, same_stream=True):
         """First-layer filter/bias gradient = the generic 1x1 MFMA wgrad over the im2col'd input; the [1][9*cin][cout]
         result is exactly the HWIO filter gradient."""
         Ho, Wo = H + 2 * layer.pad - 2, W + 2 * layer.pad - 2
@@ -601,7 +610,9 @@ class Net(object):
         fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
         # same side stream as the im2col that feeds it (stream 1): in order behind it, so a plan that runs forward and
         # backward back to back needs no join of the side streams in between
-        self._add_wgrad(plan, layer.name + '/dw', w, fl, sid=1)
+        # (same_stream=False: the data-parallel plans, which join the side streams after the forward anyway, keep the
+        # alternating assignment -- pinning changed the shape of their captured segment graph and made it 20 % slower)
+        self._add_wgrad(plan, layer.name + '/dw', w, fl, sid=1 if same_stream else None)
         plan.flops += fl
 
     def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0):

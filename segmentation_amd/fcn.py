@@ -225,7 +225,7 @@ class FCNModel(BaseModel):
             dz = act_like(a, 'dz_' + name)
             net.pool_bwd(seg, a, dP[i], None, (0, 0), (0, 0), dz, a.H, a.W)
             if i == 1:
-                net.first_bwd(seg, Ly[name], self.input_x, H, W, dz, col=col)
+                net.first_bwd(seg, Ly[name], self.input_x, H, W, dz, col=col, same_stream=not self.pg.enabled)
                 break
             pin = A['pool%d' % (i - 1)]
             # pool4 / pool3 already hold the score-branch gradient: the encoder path accumulates onto it
