@@ -39,8 +39,25 @@ struct EpiCtx {
   float bv[NJ][8];
 };
 
+// Bias of the workgroup's BN output channels, fetched once at kernel start into LDS (bias_to_lds) so that the epilogue
+// does not begin with a global round trip (every workgroup is a serial chain of such round trips, tools/ablate_conv.py).
+template <int BN>
+SEG_DEV float bias_fetch(const seg_conv_desc& d, int n0, int tid) {
+  float v = 0.f;
+  if (tid < BN) {
+    const int np = d.n_off + n0 + tid;
+    const int bi = d.up2 ? np % d.up_cout : np;
+    if (d.bias != nullptr && bi < d.bias_n) v = d.bias[bi];
+  }
+  return v;
+}
+template <int BN>
+SEG_DEV void bias_to_lds(float v, int tid, float* sb) {          // call AFTER the first chunk's loads have been issued
+  if (tid < BN) sb[tid] = v;
+}
+
 template <int BN, int WN, int NJ>
-SEG_DEV void epi_setup(const seg_conv_desc& d, int n0, int wn, int g, EpiCtx<NJ>& E) {
+SEG_DEV void epi_setup(const seg_conv_desc& d, int n0, int wn, int g, EpiCtx<NJ>& E, const float* sb = nullptr) {
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int nl = n0 + wn * (BN / WN) + j * 32 + 8 * g;       // launch-local channel
@@ -48,6 +65,7 @@ SEG_DEV void epi_setup(const seg_conv_desc& d, int n0, int wn, int g, EpiCtx<NJ>
     E.on[j] = nl < d.n_count;
     E.co[j] = nl; E.ua[j] = 0; E.uc[j] = 0;
     if (d.up2) { const int tp = np / d.up_cout; E.co[j] = np - tp * d.up_cout; E.ua[j] = tp >> 1; E.uc[j] = tp & 1; }
+    if (sb != nullptr) continue;                               // bias comes from LDS: epi_bias, after the last MFMAs
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int bi = d.up2 ? E.co[j] + e : np + e;
@@ -56,38 +74,67 @@ SEG_DEV void epi_setup(const seg_conv_desc& d, int n0, int wn, int g, EpiCtx<NJ>
   }
 }
 
-template <typename T, int TH, int TW, int BN, int WM, int WN, int FM, int FN, bool POOL = false>
-SEG_DEV void conv_epilogue(const seg_conv_desc& d, f32x4 (&acc)[FN][FM], const EpiCtx<FN / 2>& E, int b, int oy0, int ox0, int wm, int lr) {
+template <int BN, int WN, int NJ>
+SEG_DEV void epi_bias(const float* sb, int wn, int g, EpiCtx<NJ>& E) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb + wn * (BN / WN) + j * 32 + 8 * g);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(sb + wn * (BN / WN) + j * 32 + 8 * g + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { E.bv[j][e] = b0[e]; E.bv[j][4 + e] = b1[e]; }
+  }
+}
+
+// The epilogue in two parts: epi_issue computes the store offsets and ISSUES the ReLU-mask / accumulate loads (a dgrad
+// reads the forward activation it masks with); the tiled kernel calls it before the MFMAs of the LAST K chunk, when the
+// staging registers of the prefetch are free, so that this round trip overlaps them; conv_epilogue consumes them.
+template <typename T, int NJ, int FM>
+struct EpiPre {
+  int poff_d[FM];                      // in-window pixel offsets (elements) for tap (0,0); -1 = outside the output
+  int64_t dbase;
+  Vec8<T> mk[NJ][FM], old[NJ][FM];
+};
+
+template <typename T, int TH, int TW, int BN, int WM, int FM, int FN>
+SEG_DEV void epi_issue(const seg_conv_desc& d, const EpiCtx<FN / 2>& E, int b, int oy0, int ox0, int wm, int lr, EpiPre<T, FN / 2, FM>& R) {
   constexpr int BM = TH * TW, NJ = FN / 2;
   const int sc = d.up2 ? 2 : 1;
   const T* mbase = reinterpret_cast<const T*>(d.mask.ptr) + ((int64_t)(b * d.mask.H + d.mask.oy) * d.mask.W + d.mask.ox) * d.mask.cs + d.mask.coff;
-  const int64_t dbase = ((int64_t)(b * d.dst.H + d.dst.oy) * d.dst.W + d.dst.ox) * d.dst.cs + d.dst.coff;
-  int poff_d[FM], poff_m[FM];          // in-window pixel offsets (elements) for tap (0,0); -1 = outside the output
+  R.dbase = ((int64_t)(b * d.dst.H + d.dst.oy) * d.dst.W + d.dst.ox) * d.dst.cs + d.dst.coff;
+  int poff_m[FM];
 #pragma unroll
   for (int fm = 0; fm < FM; ++fm) {
     const int m = wm * (BM / WM) + fm * 16 + lr;
     const int oy = oy0 + m / TW, ox = ox0 + m % TW;
     const bool ok = oy < d.Ho && ox < d.Wo;
-    poff_d[fm] = ok ? (sc * oy * d.dst.W + sc * ox) * d.dst.cs : -1;
+    R.poff_d[fm] = ok ? (sc * oy * d.dst.W + sc * ox) * d.dst.cs : -1;
     poff_m[fm] = (sc * oy * d.mask.W + sc * ox) * d.mask.cs;
   }
+  if (d.mask.ptr != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm)
+        if (E.on[j] && R.poff_d[fm] >= 0) R.mk[j][fm].load(mbase + poff_m[fm] + (E.ua[j] * d.mask.W + E.uc[j]) * d.mask.cs + E.co[j]);
+  }
+  if (d.accum != 0) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm)
+        if (E.on[j] && R.poff_d[fm] >= 0)
+          R.old[j][fm].load(reinterpret_cast<const T*>(d.dst.ptr) + R.dbase + R.poff_d[fm] + (E.ua[j] * d.dst.W + E.uc[j]) * d.dst.cs + E.co[j]);
+  }
+}
+
+template <typename T, int TH, int TW, int BN, int WM, int WN, int FM, int FN, bool POOL = false>
+SEG_DEV void conv_epilogue(const seg_conv_desc& d, f32x4 (&acc)[FN][FM], const EpiCtx<FN / 2>& E, const EpiPre<T, FN / 2, FM>& R, int b, int oy0, int ox0, int wm, int lr) {
+  constexpr int NJ = FN / 2;
+  const int64_t dbase = R.dbase;
+  const int (&poff_d)[FM] = R.poff_d;
+  const Vec8<T> (&mk)[NJ][FM] = R.mk;
+  const Vec8<T> (&old)[NJ][FM] = R.old;
   const bool has_mask = d.mask.ptr != nullptr, has_acc = d.accum != 0;
-  Vec8<T> mk[NJ][FM], old[NJ][FM];
-  if (has_mask) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int fm = 0; fm < FM; ++fm)
-        if (E.on[j] && poff_d[fm] >= 0) mk[j][fm].load(mbase + poff_m[fm] + (E.ua[j] * d.mask.W + E.uc[j]) * d.mask.cs + E.co[j]);
-  }
-  if (has_acc) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int fm = 0; fm < FM; ++fm)
-        if (E.on[j] && poff_d[fm] >= 0)
-          old[j][fm].load(reinterpret_cast<const T*>(d.dst.ptr) + dbase + poff_d[fm] + (E.ua[j] * d.dst.W + E.uc[j]) * d.dst.cs + E.co[j]);
-  }
   const float lo = d.relu ? 0.f : -INFINITY;
   if constexpr (POOL) {
     // Fused 2x2/s2 VALID max-pool of this layer's output (the slim.max_pool2d that consumes it): with the 8x16 tile a wave
@@ -157,6 +204,13 @@ SEG_DEV void conv_epilogue(const seg_conv_desc& d, f32x4 (&acc)[FN][FM], const E
   }
 }
 
+template <typename T, int TH, int TW, int BN, int WM, int WN, int FM, int FN, bool POOL = false>
+SEG_DEV void conv_epilogue(const seg_conv_desc& d, f32x4 (&acc)[FN][FM], const EpiCtx<FN / 2>& E, int b, int oy0, int ox0, int wm, int lr) {
+  EpiPre<T, FN / 2, FM> R;
+  epi_issue<T, TH, TW, BN, WM, FM, FN>(d, E, b, oy0, ox0, wm, lr, R);
+  conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN, POOL>(d, acc, E, R, b, oy0, ox0, wm, lr);
+}
+
 // dgrad of a channel-concat input: one launch, two destinations; a workgroup's BN block lies entirely in one of them
 SEG_DEV void select_dst(seg_conv_desc& d, int n0) {
   if (d.n_split > 0 && n0 >= d.n_split) {
@@ -165,8 +219,28 @@ SEG_DEV void select_dst(seg_conv_desc& d, int n0) {
   }
 }
 
+#ifdef SEG_ABLATE
+// Debug builds only (SEG_EXTRA_FLAGS=-DSEG_ABLATE, tools/ablate_conv.py): parts of the tiled kernel switched off one at a
+// time to see which of them its run time follows.  1 patch loads, 2 filter loads, 4 LDS reads + MFMAs, 8 epilogue,
+// 16 LDS commits.  Results are garbage with any bit set.
+__device__ int g_ablate = 0;
+extern "C" int seg_dbg_set_ablate(int bits) { return hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &bits, sizeof(int)) == hipSuccess ? 0 : -1; }
+#define ABL(bit) (abl & (bit))
+#else
+#define ABL(bit) false
+#endif
+
+// Occupancy the register allocator must keep (waves per SIMD = workgroups per CU): what the LDS footprint allows for the
+// 128-pixel bf16 tiles (3 workgroups of 48 KB with 64 output channels, 4 of 30 KB with 32); the f32 parity mode is left alone.
+constexpr int conv_min_waves(int dt, int bm, int bn) { return dt != 1 || bm != 128 ? 1 : (bn == 64 ? 3 : 4); }
+
 template <int DT, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, bool POOL = false>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_min_waves(DT, TH * TW, BN))))
+void conv_fwd_kernel(const ConvK P) {
+#ifdef SEG_ABLATE
+  const int abl = __builtin_amdgcn_readfirstlane(g_ablate);
+  if (abl & 32) return;                            // launch + dispatch only
+#endif
   using T = typename DtSel<DT>::type;
   using TT = Tr<T>;
   constexpr int BM = TH * TW;
@@ -184,6 +258,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sP = smem;
   char* sW = smem + PATCH_BYTES;
+  float* sB = reinterpret_cast<float*>(smem + PATCH_BYTES + NT * BN * RSTR);
 
   seg_conv_desc d = P.d;
   const int tid = threadIdx.x;
@@ -197,6 +272,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int n0 = blockIdx.y * BN;                 // within this launch's n range
   select_dst(d, n0);
+  const float bias_r = bias_fetch<BN>(d, n0, tid);
 
   // ---- per-thread staging descriptors (constant over the K loop) ----
   int p_lds[NPP];
@@ -231,7 +307,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
     for (int i = 0; i < NPP; ++i) {
       const int off = first ? p_off0[i] : p_off1[i];
       rp[i] = u32x4{0, 0, 0, 0};
-      if (off >= 0) rp[i] = *reinterpret_cast<const u32x4*>(sb + off);
+      if (off >= 0 && !ABL(1)) rp[i] = *reinterpret_cast<const u32x4*>(sb + off);
     }
 #pragma unroll
     for (int i = 0; i < NWP; ++i) {
@@ -239,6 +315,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
       if (NT * BN * PIECES % 256 == 0 || idx < NT * BN * PIECES) {
         const int tap = idx / (BN * PIECES), row = (idx / PIECES) % BN, h = idx % PIECES;
         const int64_t off = ((int64_t)(tap * P.nchunks + c) * d.n_total + d.n_off + n0 + row) * 32 + h * EPP;
+        if (ABL(2)) { rw[i] = u32x4{1, 2, 3, 4}; continue; }
         rw[i] = *reinterpret_cast<const u32x4*>(wp + off);
       }
     }
@@ -256,6 +333,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
       }
     }
   };
+
+  prefetch(0);                                    // first: everything below runs in the shadow of this round trip
+  bias_to_lds<BN>(bias_r, tid, sB);               // visible after the K loop's barriers
 
   // ---- per-lane operand addresses ----
   int a_addr[FN];          // weight rows: packed order => fragment fn reads rows fn*16 + lr
@@ -278,12 +358,22 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = f32x4{0, 0, 0, 0};
 
-  prefetch(0);
-  for (int c = 0; c < P.nchunks; ++c) {
-    __syncthreads();
-    commit();
-    __syncthreads();
-    if (c + 1 < P.nchunks) prefetch(c + 1);
+#ifdef SEG_ABLATE
+  if (abl & 64) {                                  // prologue only (the address tables are kept alive by a never-taken store)
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) sum += p_lds[i] + p_off0[i] + p_off1[i];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) sum += a_addr[fn];
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+      for (int tp = 0; tp < NT; ++tp) sum += b_addr[tp][fm];
+    if (sum == 0x7fffffff) *reinterpret_cast<int*>(smem) = sum;
+    return;
+  }
+#endif
+  auto compute = [&]() {
     // fragments of tap t+1 are read from LDS before the MFMAs of tap t (explicit software pipeline)
     Frag<T> fa[2][FN], fb[2][FM];
 #pragma unroll
@@ -303,11 +393,27 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvK P) {
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm) mma32(acc[fn][fm], fa[tap & 1][fn], fb[tap & 1][fm]);
     }
-  }
+  };
 
-  EpiCtx<FN / 2> epi;                              // all bias loads issued together (one latency), then the mask loads
-  epi_setup<BN, WN, FN / 2>(d, n0, wn, g, epi);
-  conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN, POOL>(d, acc, epi, b, oy0, ox0, wm, lr);
+  for (int c = 0; c + 1 < P.nchunks; ++c) {
+    __syncthreads();
+    if (!ABL(16)) commit();
+    __syncthreads();
+    prefetch(c + 1);
+    if (!ABL(4)) compute();
+  }
+  // last chunk: nothing left to prefetch, so the epilogue's mask / accumulate loads fly during its MFMAs instead
+  __syncthreads();
+  if (!ABL(16)) commit();
+  __syncthreads();
+  EpiCtx<FN / 2> epi;
+  epi_setup<BN, WN, FN / 2>(d, n0, wn, g, epi, sB);
+  EpiPre<T, FN / 2, FM> pre;
+  epi_issue<T, TH, TW, BN, WM, FM, FN>(d, epi, b, oy0, ox0, wm, lr, pre);
+  if (!ABL(4)) compute();
+  epi_bias<BN, WN, FN / 2>(sB, wn, g, epi);
+  if (ABL(8) && acc[0][0][0] != 12345.f) return;
+  conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN, POOL>(d, acc, epi, pre, b, oy0, ox0, wm, lr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -385,6 +491,10 @@ __global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int n0 = blockIdx.y * BN;
   select_dst(d, n0);
+  constexpr bool SBIAS = NBUF * BUF + BN * 4 <= 160 * 1024;      // (the deepest rings fill the LDS: bias from global there)
+  float* sB = SBIAS ? reinterpret_cast<float*>(smem + NBUF * BUF) : nullptr;
+  float bias_r = 0.f;
+  if (SBIAS) bias_r = bias_fetch<BN>(d, n0, tid);
 
   // ---- per-lane source descriptors: instruction i of this wave covers LDS pieces [(i*4+wave)*64, +64) ----
   int p_off0[PPW], p_off1[PPW];                 // element offsets inside image b; -1 = zero word
@@ -464,12 +574,14 @@ __global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
 #pragma unroll
     for (int i = 0; i < PD; ++i) if (i < P.nchunks) issue(i, smem + i * BUF);
   }
+  if (SBIAS && NBUF >= 2) bias_to_lds<BN>(bias_r, tid, sB);   // after the first fills were issued; visible after the K loop's barriers
   int slot = 0;                                            // c % NBUF
   for (int c = 0; c < P.nchunks; ++c) {
     char* cur = smem + (NBUF >= 2 ? slot * BUF : 0);
     if (NBUF == 1) {
       if (c > 0) __syncthreads();                          // everyone finished reading the previous chunk
       issue(c, smem);
+      if (SBIAS && c == 0) bias_to_lds<BN>(bias_r, tid, sB);
     }
     if (NBUF <= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of chunk c has landed
     else {
@@ -503,7 +615,8 @@ __global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
     }
   }
   EpiCtx<FN / 2> epi;                              // all bias loads issued together (one latency), then the mask loads
-  epi_setup<BN, WN, FN / 2>(d, n0, wn, g, epi);
+  epi_setup<BN, WN, FN / 2>(d, n0, wn, g, epi, sB);
+  if (SBIAS) epi_bias<BN, WN, FN / 2>(sB, wn, g, epi);
   conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN>(d, acc, epi, b, oy0, ox0, wm, lr);
 }
 
@@ -792,7 +905,7 @@ int launch_cfg(const ConvK& P0, hipStream_t st) {
   }
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
   constexpr int PATCH_BYTES = ((PH * PW * TT::RSTR + 15) / 16) * 16;
-  constexpr int LDS = PATCH_BYTES + KH * KW * BN * TT::RSTR;
+  constexpr int LDS = PATCH_BYTES + KH * KW * BN * TT::RSTR + BN * 4;   // patch, filter rows, bias
   ConvK P = P0;
   P.tiles_x = cdiv(P.d.Wo, TW);
   P.tiles_y = cdiv(P.d.Ho, TH);
@@ -818,7 +931,8 @@ int launch_glds(const ConvK& P0, hipStream_t st) {
   }
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
   constexpr int PINST = (PH * PW * 4 + 63) / 64, WINST = KH * KW * BN * 4 / 64;
-  constexpr int LDS = NBUF * (PINST + WINST) * 1024;
+  constexpr int STAGES = NBUF * (PINST + WINST) * 1024;
+  constexpr int LDS = STAGES + (STAGES + BN * 4 <= 160 * 1024 ? BN * 4 : 0);   // stages, bias
   static_assert(LDS <= 160 * 1024, "LDS budget");
   ConvK P = P0;
   P.tiles_x = cdiv(P.d.Wo, TW);

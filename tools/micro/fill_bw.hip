@@ -10,22 +10,23 @@ __device__ __forceinline__ void glds16(const void* g, char* l) {
 }
 // pattern 0: contiguous 1 KiB per instruction; 1: 16 pixels x 64 B at 128-B stride (half lines); 2: 8 pixels x 128 B (full lines, 2 pixel rows apart every 18)
 template <int DEPTH, int MODE>
-__global__ __launch_bounds__(1024) void fill(const char* src, size_t bytes_per_wg, int iters, int pattern, unsigned* sink) {
+__global__ __launch_bounds__(1024) void fill(const char* src, size_t bytes_per_wg, int iters, int pattern, unsigned* sink, int shared) {
   extern __shared__ char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const char* base = src + (size_t)blockIdx.x * bytes_per_wg;
+  const char* base = src + (shared ? 0 : (size_t)blockIdx.x * bytes_per_wg);   // shared: every workgroup reads the SAME window
   unsigned acc = 0;
   // each wave walks its own interleaved 1-KiB (or 2-KiB span) units
   for (int it = 0; it < iters; it += DEPTH) {
     u32x4 r[DEPTH];
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j) {
-      const size_t unit = (size_t)(it + j) * nw + wave;
-      size_t off;
-      if (pattern == 0) off = unit * 1024 + lane * 16;
-      else if (pattern == 1) off = unit * 2048 + (lane >> 2) * 128 + (lane & 3) * 16;            // 64 B of every 128-B line
-      else off = unit * 1024 + lane * 16 + (unit / 2) * 13312;                                    // full lines, jumps to another image row every 2 KiB
-      off %= bytes_per_wg;
+      // 32-bit address arithmetic and a power-of-two window: the address math must stay far below the load issue rate
+      const unsigned unit = (unsigned)(it + j) * nw + wave;
+      unsigned off;
+      if (pattern == 0) off = unit * 1024u + lane * 16u;
+      else if (pattern == 1) off = unit * 2048u + (lane >> 2) * 128u + (lane & 3) * 16u;          // 64 B of every 128-B line
+      else off = unit * 1024u + lane * 16u + (unit >> 1) * 13312u;                                // full lines, jumps to another image row every 2 KiB
+      off &= (unsigned)bytes_per_wg - 1u;
       if (MODE == 0) glds16(base + off, lds + (wave * DEPTH + j) * 1024);
       else r[j] = *reinterpret_cast<const u32x4*>(base + off);
     }
@@ -48,7 +49,7 @@ int main() {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (int rep = 0; rep < 2; ++rep) {
       hipEventRecord(e0);
-      hipLaunchKernelGGL(kern, dim3(ncu), dim3(64 * nl), nl * depth * 1024, 0, src, per, iters, pattern, sink);
+      hipLaunchKernelGGL(kern, dim3(ncu), dim3(64 * nl), nl * depth * 1024, 0, src, per, iters, pattern, sink, 0);
       hipEventRecord(e1); hipEventSynchronize(e1);
     }
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -63,7 +64,7 @@ int main() {
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(kern, dim3(ncu), dim3(64 * nl), nl * depth * 1024, 0, src, small, iters, 0, sink);
+        hipLaunchKernelGGL(kern, dim3(ncu), dim3(64 * nl), nl * depth * 1024, 0, src, small, iters, 0, sink, 0);
         hipEventRecord(e1); hipEventSynchronize(e1);
       }
       float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -71,6 +72,21 @@ int main() {
       printf("L2-resident %-5s waves %2d depth %2d : %7.1f us  %6.2f TB/s  %5.1f GB/s/CU\n", name, nl, depth, ms * 1e3, bytes / ms / 1e9, bytes / ms / 1e6 / ncu);
     };
     for (int nl : {1, 4, 8, 12, 16}) { run2(fill<8, 0>, nl, 8, "glds"); run2(fill<8, 1>, nl, 8, "vgpr"); }
+    // the SAME 64 KiB for every workgroup (one layer's 64x64 3x3 filters): L2 / L1 hits
+    auto run3 = [&](auto kern, int nl, int depth, size_t win, const char* name) {
+      const int iters = 2048;
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(ncu), dim3(64 * nl), nl * depth * 1024, 0, src, win, iters, 0, sink, 1);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+      }
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      const double bytes = (double)ncu * nl * iters * 1024;
+      printf("shared %4zu KiB %-5s waves %2d depth %2d : %7.1f us  %6.2f TB/s  %5.1f GB/s/CU\n", win >> 10, name, nl, depth, ms * 1e3, bytes / ms / 1e9, bytes / ms / 1e6 / ncu);
+    };
+    for (size_t win : {(size_t)16 << 10, (size_t)64 << 10, (size_t)1024 << 10})
+      for (int nl : {1, 4, 12}) { run3(fill<8, 0>, nl, 8, win, "glds"); run3(fill<8, 1>, nl, 8, win, "vgpr"); }
   }
   for (int pattern = 0; pattern < 3; ++pattern)
     for (int nl : {1, 4}) {
