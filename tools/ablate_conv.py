@@ -9,8 +9,7 @@ lib = L.load()
 lib.seg_dbg_set_ablate.argtypes = [C.c_int]; lib.seg_dbg_set_ablate.restype = C.c_int
 NAMES = [(0, 'full kernel'), (1, '- patch loads'), (2, '- filter loads'), (3, '- all global loads'), (4, '- LDS reads + MFMAs'), (8, '- epilogue'),
          (16, '- LDS commits'), (12, '- compute - epilogue (loads + commits only)'), (7, '- loads - compute (commits + epilogue)'),
-         (11, '- loads - epilogue (commit + compute)'), (31, 'nothing but barriers'),
-         (64, 'address tables only, no K loop, no epilogue'), (32, 'empty kernel (launch + dispatch)')]
+         (11, '- loads - epilogue (commit + compute)'), (31, 'nothing but barriers'), (32, 'empty kernel (launch + dispatch)')]
 
 
 def run(hw, cin, cout, cfg, B=16, reps=40):
