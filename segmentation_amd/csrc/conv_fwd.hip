@@ -623,9 +623,9 @@ __global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
 // ---------------------------------------------------------------------------------------------------------
 // Weight-stationary persistent variant (bf16, 3x3 stride 1, K*BN small enough for LDS).
 // The tiled kernels above re-fetch all 9*K*BN filter bytes for every pixel tile: at 128 px x 64 ch that is 3x the
-// bytes of the input patch, and the global->LDS fill rate (~6.4 TB/s chip-wide measured) -- not the MFMA, not HBM --
-// bounds them.  Here a workgroup loads its BN filter rows for ALL K once, then walks pixel tiles
-// (blockIdx.x, +gridDim.x, ...); only input patches stream, through a ring of NST LDS stages (one 32-channel chunk of
+// bytes of the input patch (L2 hits, but every tile pays their round trip before its first MFMA -- DESIGN.md section 5).
+// Here a workgroup loads its BN filter rows for ALL K once, then walks pixel tiles (blockIdx.x, +gridDim.x, ...); only
+// input patches stream, through a ring of NST LDS stages (one 32-channel chunk of
 // one tile each) filled by a dedicated LOADER wave (wave 4) with global_load_lds.  The four consumer waves never wait
 // on vmcnt for a fill (their vmcnt only sees their own mask loads / output stores), so epilogue stores do not drain
 // the prefetch pipeline; one s_barrier per stage hands a landed stage to the consumers and a consumed one back.
