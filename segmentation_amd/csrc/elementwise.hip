@@ -416,67 +416,99 @@ SEG_DEV int seg_ci(const seg_pack_entry& e, int kpad) {   // padded concat chann
   const int k1 = kpad - e.seg0_cp;
   return (k1 < e.seg1_c) ? e.seg0_c + k1 : -1;
 }
-// One 256-thread block per 32(k) x 32(n) tile of one tap: reads run along the source's fastest axis, the tile is
-// transposed through LDS when that axis is n, writes are one contiguous 32x32 block of the packed arena.
+// 32(k) x 32(n) tiles of one tap: reads run along the source's fastest axis, the tile is transposed through LDS when that
+// axis is n, writes are one contiguous 32x32 block of the packed arena.  A 256-thread block owns PACK_TPB consecutive
+// tiles and requests the source elements of ALL of them before it touches any: with one tile per block the launch was
+// 15 000 blocks of three dependent round trips each (table -> entry -> elements), 46 us for 77 MB.
+constexpr int PACK_TPB = 4;
 template <typename T>
-__global__ __launch_bounds__(256) void pack_kernel(const float* arena, T* packed, const seg_pack_entry* tab, int n_entries) {
-  __shared__ int s_e;
-  __shared__ float tile[32][33];
+__global__ __launch_bounds__(256) void pack_kernel(const float* arena, T* packed, const seg_pack_entry* tab, int n_entries, int64_t total_tiles) {
+  __shared__ int s_e[PACK_TPB];
+  __shared__ float tile[PACK_TPB][32][33];
+  const int64_t tile0 = (int64_t)blockIdx.x * PACK_TPB;
   if (threadIdx.x < 64) {
-    // entries are sorted by blk_start: the owner is (number of entries starting at or before this block) - 1.
+    // entries are sorted by blk_start: the owner of a tile is (number of entries starting at or before it) - 1.
     // One wave tests 64 entries per pass in parallel (a serial scan by one lane cost ~4 us of latency per block).
-    int cnt = 0;
+    int cnt[PACK_TPB];
+#pragma unroll
+    for (int q = 0; q < PACK_TPB; ++q) cnt[q] = 0;
     for (int base = 0; base < n_entries; base += 64) {
       const int i = base + threadIdx.x;
-      const bool le = i < n_entries && (int64_t)blockIdx.x >= tab[i].blk_start;
-      cnt += __popcll(__ballot(le));
-    }
-    if (threadIdx.x == 0) s_e = cnt - 1;
-  }
-  __syncthreads();
-  const seg_pack_entry e = tab[s_e];
-  // tile index -> (tap, chunk, n block)
-  int64_t t = (int64_t)blockIdx.x - e.blk_start;
-  const int nblk = e.n_total / 32, nch = e.k_pad / 32;
-  const int nb = t % nblk; t /= nblk;
-  const int chunk = t % nch; const int tap = t / nch;
-  const float* src = arena + e.src_off;
-  const bool n_fast = (e.mode == SEG_PACK_CONV_FWD || e.mode == SEG_PACK_UP_DGRAD);   // source index runs fastest along n
+      const int64_t bs = i < n_entries ? tab[i].blk_start : INT64_MAX;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = threadIdx.x + i * 256;
-    const int fast = idx & 31, slow = idx >> 5;
-    const int kk = n_fast ? slow : fast, nn = n_fast ? fast : slow;     // element (k = chunk*32+kk, logical n = nb*32+nn)
-    const int k = chunk * 32 + kk, n = nb * 32 + nn;
-    float val = 0.f;
-    if (e.mode == SEG_PACK_CONV_FWD) {
-      const int ci = seg_ci(e, k);
-      if (ci >= 0 && n < e.cout) val = src[((int64_t)tap * e.cin + ci) * e.cout + n];
-    } else if (e.mode == SEG_PACK_CONV_DGRAD) {
-      const int ci = seg_ci(e, n);
-      const int u = e.KH - 1 - tap / e.KW, v = e.KW - 1 - tap % e.KW;
-      if (ci >= 0 && k < e.cout) val = src[((int64_t)(u * e.KW + v) * e.cin + ci) * e.cout + k];
-    } else if (e.mode == SEG_PACK_UP_FWD) {
-      const int ci = seg_ci(e, k);
-      const int tp = n / e.cout_pad, co = n % e.cout_pad;
-      if (ci >= 0 && co < e.cout && tp < 4) val = src[((int64_t)tp * e.cout + co) * e.cin + ci];
-    } else {  // SEG_PACK_UP_DGRAD
-      const int ci = seg_ci(e, n);
-      if (ci >= 0 && k < e.cout) val = src[((int64_t)tap * e.cout + k) * e.cin + ci];
+      for (int q = 0; q < PACK_TPB; ++q) cnt[q] += __popcll(__ballot(tile0 + q >= bs));
     }
-    tile[nn][kk] = val;
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < PACK_TPB; ++q) s_e[q] = cnt[q] - 1;
+    }
   }
   __syncthreads();
-  T* dst = packed + e.dst_off + (((int64_t)tap * nch + chunk) * e.n_total + nb * 32) * 32;
-  // 16-byte stores: 8 consecutive k of one packed row per thread (bf16: 128 threads cover the tile; f32: two passes)
+  float val[PACK_TPB][4];
+  T* dst[PACK_TPB];
+#pragma unroll
+  for (int q = 0; q < PACK_TPB; ++q) {
+    dst[q] = nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) val[q][i] = 0.f;
+    if (tile0 + q >= total_tiles) continue;
+    const seg_pack_entry e = tab[s_e[q]];
+    // tile index -> (tap, chunk, n block)
+    int64_t t = tile0 + q - e.blk_start;
+    const int nblk = e.n_total / 32, nch = e.k_pad / 32;
+    const int nb = t % nblk; t /= nblk;
+    const int chunk = t % nch; const int tap = t / nch;
+    const float* src = arena + e.src_off;
+    const bool n_fast = (e.mode == SEG_PACK_CONV_FWD || e.mode == SEG_PACK_UP_DGRAD);   // source index runs fastest along n
+    dst[q] = packed + e.dst_off + (((int64_t)tap * nch + chunk) * e.n_total + nb * 32) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = threadIdx.x + i * 256;
+      const int fast = idx & 31, slow = idx >> 5;
+      const int kk = n_fast ? slow : fast, nn = n_fast ? fast : slow;     // element (k = chunk*32+kk, logical n = nb*32+nn)
+      const int k = chunk * 32 + kk, n = nb * 32 + nn;
+      if (e.mode == SEG_PACK_CONV_FWD) {
+        const int ci = seg_ci(e, k);
+        if (ci >= 0 && n < e.cout) val[q][i] = src[((int64_t)tap * e.cin + ci) * e.cout + n];
+      } else if (e.mode == SEG_PACK_CONV_DGRAD) {
+        const int ci = seg_ci(e, n);
+        const int u = e.KH - 1 - tap / e.KW, v = e.KW - 1 - tap % e.KW;
+        if (ci >= 0 && k < e.cout) val[q][i] = src[((int64_t)(u * e.KW + v) * e.cin + ci) * e.cout + k];
+      } else if (e.mode == SEG_PACK_UP_FWD) {
+        const int ci = seg_ci(e, k);
+        const int tp = n / e.cout_pad, co = n % e.cout_pad;
+        if (ci >= 0 && co < e.cout && tp < 4) val[q][i] = src[((int64_t)tp * e.cout + co) * e.cin + ci];
+      } else {  // SEG_PACK_UP_DGRAD
+        const int ci = seg_ci(e, n);
+        if (ci >= 0 && k < e.cout) val[q][i] = src[((int64_t)tap * e.cout + k) * e.cin + ci];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PACK_TPB; ++q) {
+    if (dst[q] == nullptr) continue;
+    const bool n_fast = (tab[s_e[q]].mode == SEG_PACK_CONV_FWD || tab[s_e[q]].mode == SEG_PACK_UP_DGRAD);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = threadIdx.x + i * 256;
+      const int fast = idx & 31, slow = idx >> 5;
+      tile[q][n_fast ? fast : slow][n_fast ? slow : fast] = val[q][i];
+    }
+  }
+  __syncthreads();
+  // 16-byte stores: 8 consecutive k of one packed row per thread (bf16: 128 threads cover a tile; f32: two passes)
   constexpr int EPT = 8;
-  for (int idx = threadIdx.x; idx < 1024 / EPT; idx += 256) {
-    const int pos = idx >> 2, kk0 = (idx & 3) * EPT;                    // packed row position, first k
-    const int nn = (((pos >> 2) & 3) << 3) | (((pos >> 4) & 1) << 2) | (pos & 3);   // -> logical row
-    Vec8<T> o;
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) o.set(j, tile[nn][kk0 + j]);
-    o.store(dst + pos * 32 + kk0);
+  for (int q = 0; q < PACK_TPB; ++q) {
+    if (dst[q] == nullptr) continue;
+    for (int idx = threadIdx.x; idx < 1024 / EPT; idx += 256) {
+      const int pos = idx >> 2, kk0 = (idx & 3) * EPT;                    // packed row position, first k
+      const int nn = (((pos >> 2) & 3) << 3) | (((pos >> 4) & 1) << 2) | (pos & 3);   // -> logical row
+      Vec8<T> o;
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) o.set(j, tile[q][nn][kk0 + j]);
+      o.store(dst[q] + pos * 32 + kk0);
+    }
   }
 }
 
@@ -696,8 +728,8 @@ extern "C" int seg_pack_weights(const float* arena, void* packed, const seg_pack
                                 int64_t total_blocks, int32_t dtype, void* stream) {
   if (!arena || !packed || !table_dev || n_entries <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffff) { seg_set_error("pack: bad args"); return SEG_ERR_ARG; }
   DISPATCH(dtype,
-           SEG_LAUNCH(pack_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, ST(stream), arena, reinterpret_cast<float*>(packed), table_dev, n_entries),
-           SEG_LAUNCH(pack_kernel<bf16_t>, dim3((unsigned)total_blocks), dim3(256), 0, ST(stream), arena, reinterpret_cast<bf16_t*>(packed), table_dev, n_entries));
+           SEG_LAUNCH(pack_kernel<float>, dim3((unsigned)((total_blocks + PACK_TPB - 1) / PACK_TPB)), dim3(256), 0, ST(stream), arena, reinterpret_cast<float*>(packed), table_dev, n_entries, total_blocks),
+           SEG_LAUNCH(pack_kernel<bf16_t>, dim3((unsigned)((total_blocks + PACK_TPB - 1) / PACK_TPB)), dim3(256), 0, ST(stream), arena, reinterpret_cast<bf16_t*>(packed), table_dev, n_entries, total_blocks));
   return seg_check_launch("pack_weights");
 }
 
