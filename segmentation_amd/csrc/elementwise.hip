@@ -98,6 +98,14 @@ __global__ void maxpool_bwd_kernel(seg_view yact, seg_view dpool, seg_view add, 
     Vec8<T> dp; dp.zero();
     const bool route = full && dpool.ptr != nullptr;
     if (route) dp.load(reinterpret_cast<const T*>(dpool.ptr) + view_off(dpool, b, wy, wx) + c8 * 8);
+    Vec8<T> adv[4];                     // the skip gradient of the four pixels: requested with everything else (one round trip)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      adv[k].zero();
+      const int ay = 2 * wy + (k >> 1) - ay0, ax = 2 * wx + (k & 1) - ax0;
+      if (ok[k] && add.ptr != nullptr && ay >= 0 && ay < add_h && ax >= 0 && ax < add_w)
+        adv[k].load(reinterpret_cast<const T*>(add.ptr) + view_off(add, b, ay, ax) + c8 * 8);
+    }
     int mi[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -109,14 +117,10 @@ __global__ void maxpool_bwd_kernel(seg_view yact, seg_view dpool, seg_view add, 
     for (int k = 0; k < 4; ++k) {
       if (!ok[k]) continue;
       const int yy = 2 * wy + (k >> 1), xx = 2 * wx + (k & 1);
-      Vec8<T> ad; ad.zero();
-      const int ay = yy - ay0, ax = xx - ax0;
-      if (add.ptr != nullptr && ay >= 0 && ay < add_h && ax >= 0 && ax < add_w)
-        ad.load(reinterpret_cast<const T*>(add.ptr) + view_off(add, b, ay, ax) + c8 * 8);
       Vec8<T> o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float gsum = ad.get(e);
+        float gsum = adv[k].get(e);
         if (route && mi[e] == k) gsum += dp.get(e);
         o.set(e, y[k].get(e) > 0.f ? gsum : 0.f);
       }
