@@ -230,8 +230,12 @@ class UNetModel(BaseModel):
         seg = E.Plan('bwd0')
         segs = []
 
+        cuts = os.environ.get('SEG_DP_CUTS', 'conv5_1,conv3_1').split(',')      # gradient-bucket boundaries (backward order)
+
         def close_segment(last_layer):
             nonlocal seg
+            if last_layer != 'conv1_1' and last_layer not in cuts:
+                return
             l = Ly[last_layer]
             net.flush_reduce(seg)             # one slab-reduction launch per segment
             segs.append((seg, l.b_off + l.cout))
