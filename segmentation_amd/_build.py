@@ -26,6 +26,20 @@ def build(force=False, verbose=True):
         return LIB
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
+    # one builder at a time (torch.distributed.run starts one process per GPU, all of which come through here): the others
+    # wait for the lock and then find the library fresh
+    import fcntl
+    with open(os.path.join(objdir, '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB
+            return _build_locked(objdir, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(objdir, verbose):
 
     def cc(src):
         obj = os.path.join(objdir, src.replace('.hip', '.o'))
@@ -37,9 +51,11 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(cc, SOURCES))
-    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs, capture_output=True, text=True)
+    tmp = LIB + '.tmp.%d' % os.getpid()
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n%s' % r.stderr[-4000:])
+    os.replace(tmp, LIB)                 # atomic: a concurrent loader sees the old or the new library, never half of one
     if verbose:
         print('built', LIB, file=sys.stderr)
     return LIB
