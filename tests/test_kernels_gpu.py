@@ -314,6 +314,44 @@ def test_batched_slab_reduction_is_bitwise_the_per_layer_one():
     assert torch.equal(got[0], got[1])
 
 
+@pytest.mark.parametrize('dtype', DT)
+def test_pack_of_several_layers_equals_packing_each_alone(dtype):
+    """The re-pack launch owns four 32x32 tiles per block and finds each tile's table entry itself: a store of several
+    layers whose tile count is not a multiple of four must give, slice by slice, the bytes each layer packs to alone."""
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(11)
+    specs = [('a', 'conv', 3, [32], 32), ('b', 'conv', 1, [64], 32), ('u', 'up', 2, [64], 32), ('c', 'conv', 3, [32, 32], 64), ('d', 'conv', 1, [32], 32), ('e', 'conv', 3, [32], 32)]
+
+    def mk(spec):
+        name, kind, k, cin, cout = spec
+        return E.Layer(name, kind, k, cin if kind == 'conv' else cin, cout, 'VALID', True)
+
+    def packed_of(layers, params):
+        store = E.ParamStore(layers, dtype, dev, training=True)
+        store.set_params({l.name: params[l.name] for l in layers})
+        net = E.Net(store, 1, dtype, dev)
+        plan = E.Plan('pack'); net.pack(plan); plan.run(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return store, store.packed.float().cpu().numpy()
+
+    layers = [mk(sp) for sp in specs]
+    params = {l.name: _rand_params(l, rng, dtype) for l in layers}
+    store, whole = packed_of(layers, params)
+    assert store.pack_blocks % 4 != 0, 'the case must leave a partial block of tiles'
+    for sp in specs:
+        one = mk(sp)
+        s1, alone = packed_of([one], params)
+        full = store.layers[sp[0]]
+        for attr in ('pk_fwd', 'pk_dgrad'):
+            o1 = getattr(one, attr, None)
+            if o1 is None:
+                continue
+            o = getattr(full, attr)
+            nxt = min([x for l in s1.layers.values() for x in (getattr(l, 'pk_fwd', None), getattr(l, 'pk_dgrad', None)) if x is not None and x > o1] + [alone.size])
+            n = nxt - o1
+            assert np.array_equal(whole[o:o + n], alone[o1:o1 + n]), (sp[0], attr)
+
+
 def test_adam_matches_tf_variant():
     n = 1003
     rng = np.random.default_rng(1)
