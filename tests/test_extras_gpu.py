@@ -30,10 +30,10 @@ def test_dp_world1_rccl_path_equals_plain_step():
     torch.distributed.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     try:
         dp = UNetModel(dataset=ArrayDataSet(x, y), use_graph=True, **kw)
-        assert dp.pg.enabled and dp.pg.world == 1 and len(dp.bwd_segments) == 3
+        assert dp.pg.enabled and dp.pg.world == 1 and len(dp.bwd_segments) == 2
         bounds = [b for _, b in dp.bwd_segments]
-        assert bounds[0][0] == 0 and bounds[0][1] == bounds[1][0] and bounds[1][1] == bounds[2][0] and bounds[2][1] == dp.store.n
-        assert (bounds[2][1] - bounds[2][0]) * 4 < 300e3            # last (exposed) bucket: conv2_x + conv1_x only
+        assert bounds[0][0] == 0 and bounds[0][1] == bounds[1][0] and bounds[1][1] == dp.store.n
+        assert (bounds[1][1] - bounds[1][0]) * 4 < 300e3            # last (exposed) bucket: conv2_x + conv1_x only
         for _ in range(4):
             dp.train_step()
         torch.cuda.synchronize()
