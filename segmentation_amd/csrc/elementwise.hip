@@ -376,6 +376,14 @@ __global__ void bias_grad_kernel(seg_view dz, int B, int H, int W, int C8, int n
 // ------------------------------------------------------------------------------------------
 // Adam (TF variant) on a flat arena
 // ------------------------------------------------------------------------------------------
+// one element of the TF-Adam update: the ONLY place the arithmetic is written (flat and fused kernels must agree bit for bit)
+SEG_DEV void adam1(float& p, float g, float& m, float& v, float lr_t, float b1, float b2, float eps, float gs) {
+#pragma clang fp contract(off)      // no mul+add fusion: which products get fused would depend on the surrounding kernel
+  const float gr = g * gs;
+  m = b1 * m + (1.f - b1) * gr;
+  v = b2 * v + (1.f - b2) * gr * gr;
+  p = p - lr_t * m / (sqrtf(v) + eps);
+}
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                             float eps, float gs, const int64_t* step_dev) {
   __shared__ float s_lrt;
@@ -391,18 +399,17 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_
     f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float gr = gg[e] * gs;
-      mm[e] = b1 * mm[e] + (1.f - b1) * gr;
-      vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
-      pp[e] = pp[e] - lr_t * mm[e] / (sqrtf(vv[e]) + eps);
+      float p1 = pp[e], m1 = mm[e], v1 = vv[e];
+      adam1(p1, gg[e], m1, v1, lr_t, b1, b2, eps, gs);
+      pp[e] = p1; mm[e] = m1; vv[e] = v1;
     }
     reinterpret_cast<f32x4*>(p)[i] = pp; reinterpret_cast<f32x4*>(m)[i] = mm; reinterpret_cast<f32x4*>(v)[i] = vv;
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = n4 * 4 + threadIdx.x;
-    const float gr = g[i] * gs;
-    const float mm = b1 * m[i] + (1.f - b1) * gr, vv = b2 * v[i] + (1.f - b2) * gr * gr;
-    m[i] = mm; v[i] = vv; p[i] = p[i] - lr_t * mm / (sqrtf(vv) + eps);
+    float p1 = p[i], m1 = m[i], v1 = v[i];
+    adam1(p1, g[i], m1, v1, lr_t, b1, b2, eps, gs);
+    p[i] = p1; m[i] = m1; v[i] = v1;
   }
 }
 __global__ void step_inc_kernel(int64_t* s) { if (threadIdx.x == 0 && blockIdx.x == 0) *s += 1; }
@@ -512,6 +519,152 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* arena, T* packed
 #pragma unroll
       for (int j = 0; j < EPT; ++j) o.set(j, tile[q][nn][kk0 + j]);
       o.store(dst[q] + pos * 32 + kk0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam fused with the re-pack: the optimiser walks the weights in the 32(k) x 32(n) tiles of the FORWARD packed layout
+// (reads and writes of p / g / m / v are still whole 128-byte lines of the TF-layout arena), and the block that has just
+// updated a tile writes its packed copies -- the forward tile and, transposed, the one dgrad tile that holds the same
+// weights (taps flipped, the roles of the channel blocks swapped) -- from LDS.  The separate re-pack at the head of the
+// next step (two more reads of the fp32 arena, on the auxiliary stream beside the first layer) disappears.  The tile
+// blocks of tap 0 / chunk 0 also update their 32 biases; one flat range (the unpacked first layer) follows the tiles.
+// ------------------------------------------------------------------------------------------
+constexpr int AP_TPB = 2;
+template <typename T>
+__global__ __launch_bounds__(256) void adam_pack_kernel(float* p, const float* g, float* m, float* v, T* packed, const seg_pack_entry* tab,
+                                                        const int64_t* dgrad_off, int n_entries, int64_t total_tiles, int64_t flat_off,
+                                                        int64_t flat_len, float lr, float b1, float b2, float eps, float gs,
+                                                        const int64_t* step_dev) {
+  __shared__ float s_lrt;
+  __shared__ int s_e[AP_TPB];
+  __shared__ float tile[AP_TPB][32][33];
+  if (threadIdx.x == 64) {
+    const double t = (double)(*step_dev + 1);
+    s_lrt = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+  }
+  const int64_t tile_blocks = (total_tiles + AP_TPB - 1) / AP_TPB;
+  if ((int64_t)blockIdx.x >= tile_blocks) {
+    // flat range (first layer: weights + biases, contiguous in the arena)
+    __syncthreads();
+    const float lr_t = s_lrt;
+    for (int64_t i = ((int64_t)blockIdx.x - tile_blocks) * 256 + threadIdx.x; i < flat_len; i += ((int64_t)gridDim.x - tile_blocks) * 256) {
+      const int64_t a = flat_off + i;
+      float pp = p[a], mm = m[a], vv = v[a];
+      adam1(pp, g[a], mm, vv, lr_t, b1, b2, eps, gs);
+      p[a] = pp; m[a] = mm; v[a] = vv;
+    }
+    return;
+  }
+  const int64_t tile0 = (int64_t)blockIdx.x * AP_TPB;
+  if (threadIdx.x < 64) {
+    int cnt[AP_TPB];
+#pragma unroll
+    for (int q = 0; q < AP_TPB; ++q) cnt[q] = 0;
+    for (int base = 0; base < n_entries; base += 64) {
+      const int i = base + threadIdx.x;
+      const int64_t bs = i < n_entries ? tab[i].blk_start : INT64_MAX;
+#pragma unroll
+      for (int q = 0; q < AP_TPB; ++q) cnt[q] += __popcll(__ballot(tile0 + q >= bs));
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < AP_TPB; ++q) s_e[q] = cnt[q] - 1;
+    }
+  }
+  __syncthreads();
+  const float lr_t = s_lrt;
+  float pp[AP_TPB][4], gg[AP_TPB][4], mm[AP_TPB][4], vv[AP_TPB][4];
+  int64_t sidx[AP_TPB][4];
+  T* dstf[AP_TPB]; T* dstd[AP_TPB];
+  bool nfast[AP_TPB];
+  int64_t bidx[AP_TPB];                          // this thread's bias element of the tile (or -1)
+  float bp[AP_TPB], bg[AP_TPB], bm[AP_TPB], bv[AP_TPB];
+#pragma unroll
+  for (int q = 0; q < AP_TPB; ++q) {
+    dstf[q] = nullptr; dstd[q] = nullptr; nfast[q] = true; bidx[q] = -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sidx[q][i] = -1; pp[q][i] = 0.f; gg[q][i] = 0.f; mm[q][i] = 0.f; vv[q][i] = 0.f; }
+    if (tile0 + q >= total_tiles) continue;
+    const seg_pack_entry e = tab[s_e[q]];
+    int64_t t = tile0 + q - e.blk_start;
+    const int nblk = e.n_total / 32, nch = e.k_pad / 32;
+    const int nb = t % nblk; t /= nblk;
+    const int chunk = t % nch; const int tap = t / nch;
+    const bool conv = e.mode == SEG_PACK_CONV_FWD;
+    nfast[q] = conv;                             // source index runs fastest along n (conv) / along k (transposed conv)
+    dstf[q] = packed + e.dst_off + (((int64_t)tap * nch + chunk) * e.n_total + nb * 32) * 32;
+    const int64_t doff = dgrad_off[s_e[q]];
+    const int ntaps = e.KH * e.KW;
+    if (doff >= 0) {
+      if (conv) dstd[q] = packed + doff + (((int64_t)(ntaps - 1 - tap) * nblk + nb) * e.k_pad + chunk * 32) * 32;
+      else {
+        const int tp = (nb * 32) / e.cout_pad, cob = ((nb * 32) % e.cout_pad) / 32;
+        dstd[q] = packed + doff + (((int64_t)tp * (e.cout_pad / 32) + cob) * e.k_pad + chunk * 32) * 32;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = threadIdx.x + i * 256;
+      const int fast = idx & 31, slow = idx >> 5;
+      const int kk = conv ? slow : fast, nn = conv ? fast : slow;
+      const int k = chunk * 32 + kk, n = nb * 32 + nn;
+      const int ci = seg_ci(e, k);
+      if (conv) {
+        if (ci >= 0 && n < e.cout) sidx[q][i] = e.src_off + ((int64_t)tap * e.cin + ci) * e.cout + n;
+      } else {
+        const int tp = n / e.cout_pad, co = n % e.cout_pad;
+        if (ci >= 0 && co < e.cout && tp < 4) sidx[q][i] = e.src_off + ((int64_t)tp * e.cout + co) * e.cin + ci;
+      }
+      if (sidx[q][i] >= 0) { pp[q][i] = p[sidx[q][i]]; gg[q][i] = g[sidx[q][i]]; mm[q][i] = m[sidx[q][i]]; vv[q][i] = v[sidx[q][i]]; }
+    }
+    if (tap == 0 && chunk == 0 && threadIdx.x < 32) {
+      const int n = nb * 32 + threadIdx.x;
+      const int co = conv ? n : n % e.cout_pad;
+      const bool mine = conv ? n < e.cout : (n / e.cout_pad == 0 && co < e.cout);
+      if (mine) {
+        bidx[q] = e.src_off + (int64_t)(conv ? ntaps : 4) * e.cin * e.cout + co;
+        bp[q] = p[bidx[q]]; bg[q] = g[bidx[q]]; bm[q] = m[bidx[q]]; bv[q] = v[bidx[q]];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < AP_TPB; ++q) {
+    if (dstf[q] == nullptr) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (sidx[q][i] >= 0) {
+        adam1(pp[q][i], gg[q][i], mm[q][i], vv[q][i], lr_t, b1, b2, eps, gs);
+        p[sidx[q][i]] = pp[q][i]; m[sidx[q][i]] = mm[q][i]; v[sidx[q][i]] = vv[q][i];
+      }
+      const int idx = threadIdx.x + i * 256;
+      const int fast = idx & 31, slow = idx >> 5;
+      tile[q][nfast[q] ? fast : slow][nfast[q] ? slow : fast] = pp[q][i];       // [n][k]; 0 where the tile is padding
+    }
+    if (bidx[q] >= 0) {
+      adam1(bp[q], bg[q], bm[q], bv[q], lr_t, b1, b2, eps, gs);
+      p[bidx[q]] = bp[q]; m[bidx[q]] = bm[q]; v[bidx[q]] = bv[q];
+    }
+  }
+  __syncthreads();
+  constexpr int EPT = 8;
+#pragma unroll
+  for (int q = 0; q < AP_TPB; ++q) {
+    if (dstf[q] == nullptr) continue;
+    for (int idx = threadIdx.x; idx < 1024 / EPT; idx += 256) {
+      const int pos = idx >> 2, kk0 = (idx & 3) * EPT;                    // packed row position, first k
+      const int nn = (((pos >> 2) & 3) << 3) | (((pos >> 4) & 1) << 2) | (pos & 3);   // -> logical row
+      Vec8<T> o;
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) o.set(j, tile[q][nn][kk0 + j]);
+      o.store(dstf[q] + pos * 32 + kk0);
+      if (dstd[q] != nullptr) {                                           // dgrad tile: rows = input channels, k = output channels
+        Vec8<T> od;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) od.set(j, tile[q][kk0 + j][nn]);
+        od.store(dstd[q] + pos * 32 + kk0);
+      }
     }
   }
 }
@@ -714,6 +867,20 @@ extern "C" int seg_adam(float* p, const float* g, float* m, float* v, int64_t n,
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) { seg_set_error("adam: arenas must be 16-byte aligned"); return SEG_ERR_ARG; }
   SEG_LAUNCH(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, b1, b2, eps, grad_scale, step_dev);
   return seg_check_launch("adam");
+}
+
+extern "C" int seg_adam_pack(float* p, const float* g, float* m, float* v, int64_t n, void* packed, const seg_pack_entry* fwd_table_dev,
+                             const int64_t* dgrad_dst_off_dev, int32_t n_entries, int64_t total_tiles, int64_t flat_off, int64_t flat_len,
+                             float lr, float b1, float b2, float eps, float grad_scale, const int64_t* step_dev, int32_t dtype, void* stream) {
+  if (!p || !g || !m || !v || !packed || !fwd_table_dev || !dgrad_dst_off_dev || !step_dev || n <= 0 || n_entries <= 0 || total_tiles <= 0) { seg_set_error("adam_pack: bad args"); return SEG_ERR_ARG; }
+  if (flat_len < 0 || flat_off < 0 || flat_off + flat_len > n) { seg_set_error("adam_pack: flat range outside the arena"); return SEG_ERR_ARG; }
+  const int64_t tb = (total_tiles + AP_TPB - 1) / AP_TPB;
+  const int64_t fb = flat_len > 0 ? (flat_len + 255) / 256 : 0;
+  if (tb + fb > 0x7fffffff) { seg_set_error("adam_pack: too many blocks"); return SEG_ERR_ARG; }
+  DISPATCH(dtype,
+           SEG_LAUNCH(adam_pack_kernel<float>, dim3((unsigned)(tb + fb)), dim3(256), 0, ST(stream), p, g, m, v, reinterpret_cast<float*>(packed), fwd_table_dev, dgrad_dst_off_dev, n_entries, total_tiles, flat_off, flat_len, lr, b1, b2, eps, grad_scale, step_dev),
+           SEG_LAUNCH(adam_pack_kernel<bf16_t>, dim3((unsigned)(tb + fb)), dim3(256), 0, ST(stream), p, g, m, v, reinterpret_cast<bf16_t*>(packed), fwd_table_dev, dgrad_dst_off_dev, n_entries, total_tiles, flat_off, flat_len, lr, b1, b2, eps, grad_scale, step_dev));
+  return seg_check_launch("adam_pack");
 }
 
 extern "C" int seg_step_begin(int64_t* step2_dev, float* loss_sum, void* stream) {

@@ -107,6 +107,26 @@ class ParamStore(object):
                 blk += ne // 1024                 # one block per 32x32 tile
         self.packed = torch.zeros(max(poff, 8), dtype=torch_dtype(dtype), device=device)
         self.n_pack_entries, self.pack_blocks = len(entries), blk
+        # Adam fused with the re-pack (seg_adam_pack): the forward entries only, tiles counted over them, each with the packed
+        # offset of its dgrad copy; the unpacked first layer(s) form one flat range.  Usable when every parameter is covered.
+        self.adam_pack = None
+        if training and entries:
+            fwd, dg, tiles = [], [], 0
+            for i, e in enumerate(entries):
+                if e.mode not in (L.PACK_CONV_FWD, L.PACK_UP_FWD):
+                    continue
+                f = L.PackEntry.from_buffer_copy(e)
+                f.blk_start = tiles
+                tiles += e.n_elems // 1024
+                nxt = entries[i + 1] if i + 1 < len(entries) else None
+                dg.append(nxt.dst_off if nxt is not None and nxt.src_off == e.src_off and nxt.mode in (L.PACK_CONV_DGRAD, L.PACK_UP_DGRAD) else -1)
+                fwd.append(f)
+            firsts = [l for l in layers if l.kind == 'first']
+            lo = min([l.w_off for l in firsts] or [0]); hi = max([l.b_off + l.cout for l in firsts] or [0])
+            covered = sum(l.wsize + l.cout for l in layers if l.kind != 'first') + (hi - lo)
+            if covered == off and sum(l.wsize + l.cout for l in firsts) == hi - lo:
+                self.adam_pack = (torch.frombuffer(bytearray(b''.join(bytes(f) for f in fwd)), dtype=torch.uint8).to(device),
+                                  torch.tensor(dg, dtype=torch.int64, device=device), len(fwd), tiles, lo, hi - lo)
         if entries:
             raw = b''.join(bytes(e) for e in entries)
             self.pack_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
@@ -815,6 +835,15 @@ class Net(object):
         o = lo * 4
         plan.add('adam[%d:%d]' % (lo, hi), self.lib.seg_adam, s.p.data_ptr() + o, s.g.data_ptr() + o, s.m.data_ptr() + o, s.v.data_ptr() + o,
                  hi - lo, lr, b1, b2, eps, grad_scale, s.step.data_ptr() + 8, **meta)
+
+    def adam_pack(self, plan, lr, grad_scale=1.0, b1=0.9, b2=0.999, eps=1e-8):
+        """TF-Adam over the whole arena fused with the re-pack of the updated weights (seg_adam_pack): same arithmetic and
+        the same packed bytes as adam() followed by pack(), without the two extra reads of the fp32 arena."""
+        s = self.store
+        tab, dg, ne, tiles, flo, flen = s.adam_pack
+        plan.add('adam+pack', self.lib.seg_adam_pack, s.p.data_ptr(), s.g.data_ptr(), s.m.data_ptr(), s.v.data_ptr(), s.n,
+                 s.packed.data_ptr(), tab.data_ptr(), dg.data_ptr(), ne, tiles, flo, flen, lr, b1, b2, eps, grad_scale,
+                 s.step.data_ptr() + 8, self.dtype, kernel='adam_pack_kernel')
 
     def step_begin(self, plan, loss_buf, aux=True):
         """global_step += 1 and loss accumulator = 0, first thing of a training forward (auxiliary stream: off the

@@ -352,6 +352,37 @@ def test_pack_of_several_layers_equals_packing_each_alone(dtype):
             assert np.array_equal(whole[o:o + n], alone[o1:o1 + n]), (sp[0], attr)
 
 
+@pytest.mark.parametrize('dtype', DT)
+def test_fused_adam_pack_is_bitwise_adam_then_pack(dtype):
+    """seg_adam_pack against seg_adam followed by seg_pack_weights on a store with every layer kind (first, plain and
+    two-source convs, 1x1, transposed conv): parameters, both moments and the packed arena must agree bit for bit."""
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(23)
+    layers = [E.Layer('f', 'first', 3, [3], 32, 'VALID', True), E.Layer('a', 'conv', 3, [32], 64, 'VALID', True),
+              E.Layer('u', 'up', 2, [64], 32, 'VALID', True), E.Layer('c', 'conv', 3, [32, 32], 40, 'VALID', True),
+              E.Layer('o', 'conv', 1, [40], 4, 'SAME', False)]
+    params = {l.name: _rand_params(l, rng, dtype) for l in layers}
+
+    def fresh():
+        st = E.ParamStore(layers, dtype, dev, training=True)
+        st.set_params(params)
+        g = torch.Generator(device='cpu'); g.manual_seed(5)
+        st.g.copy_(torch.randn(st.n, generator=g)); st.m.copy_(torch.randn(st.n, generator=g) * 0.1); st.v.copy_(torch.rand(st.n, generator=g) * 0.01)
+        st.step.fill_(3)
+        return st, E.Net(st, 1, dtype, dev)
+
+    s0, n0 = fresh()
+    s1, n1 = fresh()
+    assert s1.adam_pack is not None
+    stream = torch.cuda.current_stream().cuda_stream
+    a = E.Plan('a'); n0.adam(a, 1e-3, grad_scale=0.5); n0.pack(a); a.run(stream)
+    b = E.Plan('b'); n1.adam_pack(b, 1e-3, grad_scale=0.5); b.run(stream)
+    torch.cuda.synchronize()
+    for name in ('p', 'm', 'v'):
+        assert torch.equal(getattr(s0, name), getattr(s1, name)), name
+    assert torch.equal(s0.packed.view(torch.uint8), s1.packed.view(torch.uint8))
+
+
 def test_adam_matches_tf_variant():
     n = 1003
     rng = np.random.default_rng(1)
