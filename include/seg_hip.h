@@ -227,6 +227,11 @@ int seg_adam_pack(float* p, const float* g, float* m, float* v, int64_t n, void*
                   int64_t total_tiles, int64_t flat_off, int64_t flat_len, float lr, float b1, float b2, float eps,
                   float grad_scale, const int64_t* step_dev, int32_t dtype, void* stream);
 
+/* seg_pack_weights with ONE read of the fp32 arena for both packed copies (same tables as seg_adam_pack, same packed bytes as
+ * seg_pack_weights): each 32x32 source tile is written as its forward tile and, transposed, as its dgrad tile. */
+int seg_pack_weights_dual(const float* arena, void* packed, const seg_pack_entry* fwd_table_dev,
+                          const int64_t* dgrad_dst_off_dev, int32_t n_entries, int64_t total_tiles, int32_t dtype, void* stream);
+
 /* Depthwise bilinear transposed conv = tf.nn.conv2d_transpose(x, bilinear_upsample_weights(f,C), SAME)
  * (models/fcn.py:199-216; filter bank utils/upsampling.py:27-46, channel-diagonal => depthwise),
  * fused with the following resize_image_with_crop_or_pad and skip addition:

@@ -532,7 +532,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* arena, T* packed
 // blocks of tap 0 / chunk 0 also update their 32 biases; one flat range (the unpacked first layer) follows the tiles.
 // ------------------------------------------------------------------------------------------
 constexpr int AP_TPB = 2;
-template <typename T>
+// ADAM = false: the re-pack alone in the same walk -- ONE read of the fp32 arena for both packed copies (the table-driven
+// pack_kernel reads it once per copy).
+template <typename T, bool ADAM>
 __global__ __launch_bounds__(256) void adam_pack_kernel(float* p, const float* g, float* m, float* v, T* packed, const seg_pack_entry* tab,
                                                         const int64_t* dgrad_off, int n_entries, int64_t total_tiles, int64_t flat_off,
                                                         int64_t flat_len, float lr, float b1, float b2, float eps, float gs,
@@ -540,12 +542,13 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(float* p, const float* g
   __shared__ float s_lrt;
   __shared__ int s_e[AP_TPB];
   __shared__ float tile[AP_TPB][32][33];
-  if (threadIdx.x == 64) {
+  if (ADAM && threadIdx.x == 64) {
     const double t = (double)(*step_dev + 1);
     s_lrt = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
   }
   const int64_t tile_blocks = (total_tiles + AP_TPB - 1) / AP_TPB;
   if ((int64_t)blockIdx.x >= tile_blocks) {
+    if (!ADAM) return;
     // flat range (first layer: weights + biases, contiguous in the arena)
     __syncthreads();
     const float lr_t = s_lrt;
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(float* p, const float* g
     }
   }
   __syncthreads();
-  const float lr_t = s_lrt;
+  const float lr_t = ADAM ? s_lrt : 0.f;
   float pp[AP_TPB][4], gg[AP_TPB][4], mm[AP_TPB][4], vv[AP_TPB][4];
   int64_t sidx[AP_TPB][4];
   T* dstf[AP_TPB]; T* dstd[AP_TPB];
@@ -617,9 +620,12 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(float* p, const float* g
         const int tp = n / e.cout_pad, co = n % e.cout_pad;
         if (ci >= 0 && co < e.cout && tp < 4) sidx[q][i] = e.src_off + ((int64_t)tp * e.cout + co) * e.cin + ci;
       }
-      if (sidx[q][i] >= 0) { pp[q][i] = p[sidx[q][i]]; gg[q][i] = g[sidx[q][i]]; mm[q][i] = m[sidx[q][i]]; vv[q][i] = v[sidx[q][i]]; }
+      if (sidx[q][i] >= 0) {
+        pp[q][i] = p[sidx[q][i]];
+        if (ADAM) { gg[q][i] = g[sidx[q][i]]; mm[q][i] = m[sidx[q][i]]; vv[q][i] = v[sidx[q][i]]; }
+      }
     }
-    if (tap == 0 && chunk == 0 && threadIdx.x < 32) {
+    if (ADAM && tap == 0 && chunk == 0 && threadIdx.x < 32) {
       const int n = nb * 32 + threadIdx.x;
       const int co = conv ? n : n % e.cout_pad;
       const bool mine = conv ? n < e.cout : (n / e.cout_pad == 0 && co < e.cout);
@@ -634,7 +640,7 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(float* p, const float* g
     if (dstf[q] == nullptr) continue;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (sidx[q][i] >= 0) {
+      if (ADAM && sidx[q][i] >= 0) {
         adam1(pp[q][i], gg[q][i], mm[q][i], vv[q][i], lr_t, b1, b2, eps, gs);
         p[sidx[q][i]] = pp[q][i]; m[sidx[q][i]] = mm[q][i]; v[sidx[q][i]] = vv[q][i];
       }
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(float* p, const float* g
       const int fast = idx & 31, slow = idx >> 5;
       tile[q][nfast[q] ? fast : slow][nfast[q] ? slow : fast] = pp[q][i];       // [n][k]; 0 where the tile is padding
     }
-    if (bidx[q] >= 0) {
+    if (ADAM && bidx[q] >= 0) {
       adam1(bp[q], bg[q], bm[q], bv[q], lr_t, b1, b2, eps, gs);
       p[bidx[q]] = bp[q]; m[bidx[q]] = bm[q]; v[bidx[q]] = bv[q];
     }
@@ -878,9 +884,21 @@ extern "C" int seg_adam_pack(float* p, const float* g, float* m, float* v, int64
   const int64_t fb = flat_len > 0 ? (flat_len + 255) / 256 : 0;
   if (tb + fb > 0x7fffffff) { seg_set_error("adam_pack: too many blocks"); return SEG_ERR_ARG; }
   DISPATCH(dtype,
-           SEG_LAUNCH(adam_pack_kernel<float>, dim3((unsigned)(tb + fb)), dim3(256), 0, ST(stream), p, g, m, v, reinterpret_cast<float*>(packed), fwd_table_dev, dgrad_dst_off_dev, n_entries, total_tiles, flat_off, flat_len, lr, b1, b2, eps, grad_scale, step_dev),
-           SEG_LAUNCH(adam_pack_kernel<bf16_t>, dim3((unsigned)(tb + fb)), dim3(256), 0, ST(stream), p, g, m, v, reinterpret_cast<bf16_t*>(packed), fwd_table_dev, dgrad_dst_off_dev, n_entries, total_tiles, flat_off, flat_len, lr, b1, b2, eps, grad_scale, step_dev));
+           SEG_LAUNCH((adam_pack_kernel<float, true>), dim3((unsigned)(tb + fb)), dim3(256), 0, ST(stream), p, g, m, v, reinterpret_cast<float*>(packed), fwd_table_dev, dgrad_dst_off_dev, n_entries, total_tiles, flat_off, flat_len, lr, b1, b2, eps, grad_scale, step_dev),
+           SEG_LAUNCH((adam_pack_kernel<bf16_t, true>), dim3((unsigned)(tb + fb)), dim3(256), 0, ST(stream), p, g, m, v, reinterpret_cast<bf16_t*>(packed), fwd_table_dev, dgrad_dst_off_dev, n_entries, total_tiles, flat_off, flat_len, lr, b1, b2, eps, grad_scale, step_dev));
   return seg_check_launch("adam_pack");
+}
+
+extern "C" int seg_pack_weights_dual(const float* arena, void* packed, const seg_pack_entry* fwd_table_dev, const int64_t* dgrad_dst_off_dev,
+                                     int32_t n_entries, int64_t total_tiles, int32_t dtype, void* stream) {
+  if (!arena || !packed || !fwd_table_dev || !dgrad_dst_off_dev || n_entries <= 0 || total_tiles <= 0) { seg_set_error("pack_dual: bad args"); return SEG_ERR_ARG; }
+  const int64_t tb = (total_tiles + AP_TPB - 1) / AP_TPB;
+  if (tb > 0x7fffffff) { seg_set_error("pack_dual: too many blocks"); return SEG_ERR_ARG; }
+  float* a = const_cast<float*>(arena);            // (never written: ADAM = false)
+  DISPATCH(dtype,
+           SEG_LAUNCH((adam_pack_kernel<float, false>), dim3((unsigned)tb), dim3(256), 0, ST(stream), a, nullptr, nullptr, nullptr, reinterpret_cast<float*>(packed), fwd_table_dev, dgrad_dst_off_dev, n_entries, total_tiles, 0, 0, 0.f, 0.f, 0.f, 0.f, 0.f, nullptr),
+           SEG_LAUNCH((adam_pack_kernel<bf16_t, false>), dim3((unsigned)tb), dim3(256), 0, ST(stream), a, nullptr, nullptr, nullptr, reinterpret_cast<bf16_t*>(packed), fwd_table_dev, dgrad_dst_off_dev, n_entries, total_tiles, 0, 0, 0.f, 0.f, 0.f, 0.f, 0.f, nullptr));
+  return seg_check_launch("pack_weights_dual");
 }
 
 extern "C" int seg_step_begin(int64_t* step2_dev, float* loss_sum, void* stream) {

@@ -810,6 +810,13 @@ class Net(object):
         meta = {'kernel': 'pack_kernel'}
         if aux:
             meta['side'] = 'aux'
+        if getattr(s, 'adam_pack', None) is not None and os.environ.get('SEG_PACK_DUAL', '1') != '0':
+            # training stores: both packed copies of a tile from ONE read of the arena
+            tab, dg, ne, tiles, _, _ = s.adam_pack
+            meta['kernel'] = 'adam_pack_kernel'
+            plan.add('pack', self.lib.seg_pack_weights_dual, s.p.data_ptr(), s.packed.data_ptr(), tab.data_ptr(), dg.data_ptr(), ne, tiles,
+                     self.dtype, **meta)
+            return
         plan.add('pack', self.lib.seg_pack_weights, s.p.data_ptr(), s.packed.data_ptr(), s.pack_table.data_ptr(),
                  s.n_pack_entries, s.pack_blocks, self.dtype, **meta)
 

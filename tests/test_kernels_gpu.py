@@ -353,9 +353,10 @@ def test_pack_of_several_layers_equals_packing_each_alone(dtype):
 
 
 @pytest.mark.parametrize('dtype', DT)
-def test_fused_adam_pack_is_bitwise_adam_then_pack(dtype):
-    """seg_adam_pack against seg_adam followed by seg_pack_weights on a store with every layer kind (first, plain and
-    two-source convs, 1x1, transposed conv): parameters, both moments and the packed arena must agree bit for bit."""
+def test_fused_adam_pack_is_bitwise_adam_then_pack(dtype, monkeypatch):
+    """seg_adam_pack, and seg_adam followed by seg_pack_weights_dual, against seg_adam followed by the table-driven
+    seg_pack_weights on a store with every layer kind (first, plain and two-source convs, 1x1, transposed conv):
+    parameters, both moments and the packed arena must agree bit for bit."""
     dev = torch.device('cuda', 0)
     rng = np.random.default_rng(23)
     layers = [E.Layer('f', 'first', 3, [3], 32, 'VALID', True), E.Layer('a', 'conv', 3, [32], 64, 'VALID', True),
@@ -373,14 +374,21 @@ def test_fused_adam_pack_is_bitwise_adam_then_pack(dtype):
 
     s0, n0 = fresh()
     s1, n1 = fresh()
+    s2, n2 = fresh()
     assert s1.adam_pack is not None
     stream = torch.cuda.current_stream().cuda_stream
+    monkeypatch.setenv('SEG_PACK_DUAL', '0')
     a = E.Plan('a'); n0.adam(a, 1e-3, grad_scale=0.5); n0.pack(a); a.run(stream)
+    assert a.meta[-1]['kernel'] == 'pack_kernel'
+    monkeypatch.setenv('SEG_PACK_DUAL', '1')
     b = E.Plan('b'); n1.adam_pack(b, 1e-3, grad_scale=0.5); b.run(stream)
+    c = E.Plan('c'); n2.adam(c, 1e-3, grad_scale=0.5); n2.pack(c); c.run(stream)
+    assert c.meta[-1]['kernel'] == 'adam_pack_kernel'
     torch.cuda.synchronize()
-    for name in ('p', 'm', 'v'):
-        assert torch.equal(getattr(s0, name), getattr(s1, name)), name
-    assert torch.equal(s0.packed.view(torch.uint8), s1.packed.view(torch.uint8))
+    for other in (s1, s2):
+        for name in ('p', 'm', 'v'):
+            assert torch.equal(getattr(s0, name), getattr(other, name)), name
+        assert torch.equal(s0.packed.view(torch.uint8), other.packed.view(torch.uint8))
 
 
 def test_adam_matches_tf_variant():
