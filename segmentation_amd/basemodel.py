@@ -187,8 +187,11 @@ class BaseModel(object):
                 and os.environ.get('SEG_EARLY_ADAM', '0') == '0')
 
     def _flavor(self):
-        """Which form of the slab reductions the plans run: per layer under hipGraph replay, batched when launched eagerly."""
-        return 'per_layer' if self.use_graph else 'batched'
+        """Which form of the slab reductions the plans run.  Per layer (right behind each filter gradient, on its stream) in
+        both step modes: eagerly it needs no fork of its own (Plan.run), and then beats the batched form (one launch per
+        side stream and segment) by 4 %; SEG_REDUCE_FLAVOR=batched selects that one."""
+        f = os.environ.get('SEG_REDUCE_FLAVOR')
+        return f if f in ('per_layer', 'batched') else 'per_layer'
 
     def autotune_step_mode(self, steps=40):
         """Times `steps` real train steps replayed as a hipGraph and launched eagerly and keeps the faster mode (the eager
@@ -288,8 +291,8 @@ class BaseModel(object):
             if self.use_graph and os.environ.get('SEG_HYBRID', '0') != '0':
                 # forward as a graph (a linear chain: nothing to gain from eager launches), backward + Adam launched eagerly
                 # (the cross-stream fork points cost ~7 us eagerly against ~12 us inside a captured graph)
-                self._replay(('fwd', key), lambda: self.fwd_plan.run(self._stream(), self._side, flavor='batched'))
-                self.bwd_upd_plan.run(self._stream(), self._side, flavor='batched')
+                self._replay(('fwd', key), lambda: self.fwd_plan.run(self._stream(), self._side, flavor=self._flavor()))
+                self.bwd_upd_plan.run(self._stream(), self._side, flavor=self._flavor())
                 self._packed_dirty = not self.fused_adam_pack
             else:
                 self._replay(('step', key), self._run_step)

@@ -239,6 +239,8 @@ class Plan(object):
         batch = int(os.environ.get('SEG_SIDE_BATCH', '0'))     # > 0: fork the side streams once per `batch` main launches
         pending = []
         since = 0
+        main_epoch, forked_at = 0, {}             # launches on the main stream so far; per side stream: the count at its last fork
+        capturing = torch.cuda.is_current_stream_capturing()
 
         def flush():
             ev1 = None
@@ -273,7 +275,9 @@ class Plan(object):
                     for o_ in used.values():             # everything the filter-gradient streams hold so far
                         if o_ is not aux:
                             fork(o_, aux)
-                fork(main, aux)
+                if capturing or forked_at.get(id(aux)) != main_epoch:
+                    fork(main, aux)
+                    forked_at[id(aux)] = main_epoch
                 aux_used = True
                 rc = fn(*args, C.c_void_p(aux.cuda_stream))
             elif tag:
@@ -290,9 +294,16 @@ class Plan(object):
                     ev = torch.cuda.Event(); ev.record(main)
                     pending.append((ev, st, fn, args, name))
                     continue
-                fork(main, st)
+                # A fork (event recorded on the main stream + wait on the side stream) is only needed if something was launched
+                # on the main stream since this side stream last forked from it: a launch right behind its producer on the SAME
+                # side stream (the slab reduction behind its filter gradient) is already ordered.  Each fork costs ~20 us of step
+                # time (eleven redundant ones: 1.44 against 1.21 ms), far more than the launch it guards.
+                if capturing or forked_at.get(id(st)) != main_epoch:
+                    fork(main, st)
+                    forked_at[id(st)] = main_epoch
                 rc = fn(*args, C.c_void_p(st.cuda_stream))
             else:
+                main_epoch += 1
                 rc = fn(*args, sp)
                 if rc == 0 and pending:
                     since += 1
