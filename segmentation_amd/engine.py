@@ -242,12 +242,21 @@ class Plan(object):
         main_epoch, forked_at = 0, {}             # launches on the main stream so far; per side stream: the count at its last fork
         capturing = torch.cuda.is_current_stream_capturing()
 
+        dirty = set()                             # side streams with launches the main stream has not waited for yet
+
+        def join(st_):
+            # (eagerly a stream that has launched nothing since the main stream last waited for it needs no second wait)
+            if capturing or id(st_) in dirty:
+                fork(st_, main)
+                dirty.discard(id(st_))
+
         def flush():
             ev1 = None
             if batch > 0 and pending:
                 ev1 = torch.cuda.Event(); ev1.record(main)      # one fork point for everything queued (later = still a valid dependency)
             for ev_, st_, fn_, args_, name_ in pending:
                 st_.wait_event(ev1 if ev1 is not None else ev_)
+                dirty.add(id(st_))
                 rc_ = fn_(*args_, C.c_void_p(st_.cuda_stream))
                 if rc_ != 0:
                     L.check(rc_, '%s/%s' % (self.name, name_))
@@ -260,13 +269,13 @@ class Plan(object):
             if fn is None and name == 'join_all':      # marker: the main stream waits for every side stream used so far
                 flush()
                 for o_ in used.values():
-                    fork(o_, main)
+                    join(o_)
                 if aux_used:
-                    fork(aux, main)
+                    join(aux)
                 continue
             if fn is None:               # marker: make the main stream wait for the aux stream
                 if aux_used:
-                    fork(aux, main)
+                    join(aux)
                     aux_used = False
                 continue
             if tag == 'aux' or tag == 'aux_join':
@@ -279,6 +288,7 @@ class Plan(object):
                     fork(main, aux)
                     forked_at[id(aux)] = main_epoch
                 aux_used = True
+                dirty.add(id(aux))
                 rc = fn(*args, C.c_void_p(aux.cuda_stream))
             elif tag:
                 # side stream ids are assigned when the plan is built (Net._add_wgrad alternates 1, 2): a filter
@@ -296,11 +306,14 @@ class Plan(object):
                     continue
                 # A fork (event recorded on the main stream + wait on the side stream) is only needed if something was launched
                 # on the main stream since this side stream last forked from it: a launch right behind its producer on the SAME
-                # side stream (the slab reduction behind its filter gradient) is already ordered.  Each fork costs ~20 us of step
-                # time (eleven redundant ones: 1.44 against 1.21 ms), far more than the launch it guards.
+                # side stream (the slab reduction behind its filter gradient) is already ordered.  Each redundant fork costs ~20 us
+                # of step time when launched eagerly (eleven of them: 1.44 against 1.19 ms), far more than the launch it guards.
+                # Under stream capture every edge is kept: the captured graph's split into streams depends on them (1.38 against
+                # 1.25 ms without).
                 if capturing or forked_at.get(id(st)) != main_epoch:
                     fork(main, st)
                     forked_at[id(st)] = main_epoch
+                dirty.add(id(st))
                 rc = fn(*args, C.c_void_p(st.cuda_stream))
             else:
                 main_epoch += 1
@@ -315,7 +328,7 @@ class Plan(object):
         if aux_used:
             used[id(aux)] = aux
         for st in used.values():
-            fork(st, main)
+            join(st)
 
     def rebind(self, mapping):
         """Replaces raw device pointers among the launch arguments ({old: new}; the network inputs when a device-resident
