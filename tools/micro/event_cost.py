@@ -9,7 +9,8 @@ import ctypes as C
 lib = L.load()
 dev = torch.device('cuda', 0)
 N = 400
-x = torch.zeros(1 << 20, device=dev)          # 4 MB: x.add_(1) is a ~5 us kernel
+SZ = int(sys.argv[1]) if len(sys.argv) > 1 else 24        # log2 elements: 2^24 floats = 64 MB, x.add_(1) ~ 25-30 us (GPU-bound loop); 20 = host-bound
+x = torch.zeros(1 << SZ, device=dev)
 y = torch.zeros(1 << 20, device=dev)
 def run(mode, prio):
     a = torch.cuda.Stream(dev, priority=prio); b = torch.cuda.Stream(dev)
@@ -32,3 +33,33 @@ def run(mode, prio):
 for prio in (0, -1):
     for mode in ('bare', 'record', 'fork', 'wait_other'):
         run(mode, prio)
+
+# stream memory operations as a cheaper fork?  main: hipStreamWriteValue32(flag, i) after each kernel; side: hipStreamWaitValue32(flag >= i)
+h = L.hip_runtime()
+def run_value(prio, with_wait):
+    a = torch.cuda.Stream(dev, priority=prio); b = torch.cuda.Stream(dev)
+    flag = torch.zeros(4, dtype=torch.int32, device=dev)
+    h.hipStreamWriteValue32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint]
+    h.hipStreamWaitValue32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint, C.c_uint32]
+    base = [0]
+    def body():
+        for i in range(N):
+            base[0] += 1
+            with torch.cuda.stream(a):
+                x.add_(1)
+            rc = h.hipStreamWriteValue32(C.c_void_p(a.cuda_stream), C.c_void_p(flag.data_ptr()), base[0], 0)
+            assert rc == 0, rc
+            if with_wait:
+                rc = h.hipStreamWaitValue32(C.c_void_p(b.cuda_stream), C.c_void_p(flag.data_ptr()), base[0], 0, 0xffffffff)   # 0 = hipStreamWaitValueGte
+                assert rc == 0, rc
+                with torch.cuda.stream(b):
+                    y.add_(1)
+    body(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); body(); t_issue = time.perf_counter() - t0
+    torch.cuda.synchronize(); t = time.perf_counter() - t0
+    print('%-11s priority %2d : %6.2f us per iteration on the GPU timeline (host issue %5.2f us)' % ('writevalue' + ('+wait' if with_wait else ''), prio, t / N * 1e6, t_issue / N * 1e6))
+try:
+    for prio in (0, -1):
+        run_value(prio, False); run_value(prio, True)
+except Exception as e:
+    print('stream memory operations unavailable:', repr(e)[:200])
