@@ -303,6 +303,45 @@ def miou(pred, label, n_classes):
 
 
 # ----------------------------------------------------------------------------
+# slim.dropout-style mask (BUILD-DEFINED for the U-Net; the only reference precedent is
+# models/deconvolution.py:128-129,143-144,153-154: slim.dropout, keep_prob 0.5, always on)
+# ----------------------------------------------------------------------------
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(k):
+    """splitmix64 finaliser on uint64 arrays (wrap-around arithmetic)."""
+    k = np.asarray(k, np.uint64)
+    with np.errstate(over='ignore'):
+        k = k + np.uint64(0x9E3779B97F4A7C15)
+        k = (k ^ (k >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        k = (k ^ (k >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return k ^ (k >> np.uint64(31))
+
+
+def dropout_mask(shape, keep, seed, offset, c_pad=None):
+    """Boolean keep-mask of an NHWC tensor [B,H,W,C] whose buffer pads the channels to c_pad (default: C rounded up to 32).
+    Element (b,y,x,c) draws the counter offset + ((b*H + y)*W + x)*c_pad + c from the stream keyed by splitmix64(seed):
+    r = high 32 bits of splitmix64(key ^ counter); kept iff r <= uint32(keep * 4294967295.0)."""
+    B, H, W, Cc = shape
+    cp = c_pad if c_pad is not None else (Cc + 31) // 32 * 32
+    idx = (np.arange(B * H * W, dtype=np.uint64)[:, None] * np.uint64(cp) + np.arange(Cc, dtype=np.uint64)[None, :]).reshape(B, H, W, Cc)
+    key = splitmix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF))
+    with np.errstate(over='ignore'):
+        ctr = idx + np.uint64(offset & 0xFFFFFFFFFFFFFFFF)
+    r = (splitmix64(key ^ ctr) >> np.uint64(32)).astype(np.uint32)
+    thr = np.uint32(int(np.float64(np.float32(keep)) * 4294967295.0))
+    return r <= thr
+
+
+def dropout(x, keep, seed, offset, dt=np.float64, c_pad=None):
+    """y = x * mask / keep (the 1/keep factor is formed in float32 like the kernel's `1.f / keep`)."""
+    x = np.asarray(x, dt)
+    inv = np.float32(1.0) / np.float32(keep)
+    return x * dropout_mask(x.shape, keep, seed, offset, c_pad) * dt(inv)
+
+
+# ----------------------------------------------------------------------------
 # bilinear filter bank  (restates utils/upsampling.py:6-46)
 # ----------------------------------------------------------------------------
 def get_kernel_size(factor):

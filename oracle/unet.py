@@ -77,8 +77,12 @@ def output_size(n):
     return v
 
 
-def forward(p, x, dt=np.float64):
-    """Returns (logits, cache)."""
+MC_SITES = {'conv2_2': 2, 'conv5_2': 5, 'conv6_2': 10}      # site -> seed increment (build-defined, a19)
+
+
+def forward(p, x, dt=np.float64, dropout=None):
+    """Returns (logits, cache).  dropout = {'keep':, 'seed':, 'offset':} applies the build-defined MC-dropout masks
+    (ops.dropout) after conv2_2, conv5_2 and conv6_2 with per-site seeds seed + MC_SITES[site]."""
     c = {}
     W = lambda n: p[n]['weights']
     b = lambda n: p[n]['biases']
@@ -90,6 +94,9 @@ def forward(p, x, dt=np.float64):
     c['pool1'], c['idx1'] = ops.max_pool2x2(c['conv1_1'])          # F12: pool of conv1_1
     c['conv2_1'] = conv(c['pool1'], 'conv2_1')
     c['conv2_2'] = conv(c['conv2_1'], 'conv2_2')
+    drop = (lambda t, site: t) if dropout is None else \
+        (lambda t, site: ops.dropout(t, dropout['keep'], dropout['seed'] + MC_SITES[site], dropout['offset'], dt))
+    c['conv2_2'] = drop(c['conv2_2'], 'conv2_2')
     c['pool2'], c['idx2'] = ops.max_pool2x2(c['conv2_2'])
     c['conv3_1'] = conv(c['pool2'], 'conv3_1')
     c['conv3_2'] = conv(c['conv3_1'], 'conv3_2')
@@ -98,7 +105,7 @@ def forward(p, x, dt=np.float64):
     c['conv4_2'] = conv(c['conv4_1'], 'conv4_2')
     c['pool4'], c['idx4'] = ops.max_pool2x2(c['conv4_2'])
     c['conv5_1'] = conv(c['pool4'], 'conv5_1')
-    c['conv5_2'] = conv(c['conv5_1'], 'conv5_2')
+    c['conv5_2'] = drop(conv(c['conv5_1'], 'conv5_2'), 'conv5_2')
     prev = c['conv5_2']
     for lvl, (upn, skip, ca, cb) in enumerate([('upconv1', 'conv4_2', 'conv6_1', 'conv6_2'),
                                                ('upconv2', 'conv3_2', 'conv7_1', 'conv7_2'),
@@ -110,6 +117,8 @@ def forward(p, x, dt=np.float64):
         c['cat%d' % (lvl + 1)] = np.concatenate([crop, c[upn]], axis=-1)     # skip first
         c[ca] = conv(c['cat%d' % (lvl + 1)], ca)
         c[cb] = conv(c[ca], cb)
+        if cb in MC_SITES:
+            c[cb] = drop(c[cb], cb)
         prev = c[cb]
     c['logits'] = conv(prev, 'output', relu=False)
     return c['logits'], c
@@ -195,3 +204,17 @@ def infer(p, x, dt=np.float64):
     logits, _ = forward(p, x, dt)
     sig, out = ops.sigmoid_argmax(logits.astype(np.float32))
     return [sig, out]
+
+
+def infer_mc(p, x, passes=30, keep=0.5, seed=5555, dt=np.float64):
+    """Build-defined MC-dropout inference (a19): `passes` stochastic forwards, pass t (0-based) uses the counter offset
+    (t + 1) << 40; returns [mean sigmoid, variance of sigmoid, float32 argmax of the mean, per-pass float32 sigmoids]."""
+    sigs = []
+    for t in range(passes):
+        logits, _ = forward(p, x, dt, dropout={'keep': keep, 'seed': seed, 'offset': (t + 1) << 40})
+        sig, _ = ops.sigmoid_argmax(logits.astype(np.float32))
+        sigs.append(sig)
+    s = np.stack(sigs).astype(np.float64)
+    mean = s.mean(0)
+    var = np.maximum((s * s).mean(0) - mean * mean, 0)
+    return [mean, var, np.argmax(mean, -1).astype(np.float32)[..., None], sigs]

@@ -39,7 +39,7 @@ class BaseModel(object):
                  load_snapshot_from=None,
                  adversarial_training=False,
                  dtype='bf16', use_graph=True, crop_aware=True, device=None, process_group=None, seed=5555,
-                 overlap_allreduce=True, wgrad_streams=2):
+                 overlap_allreduce=True, wgrad_streams=2, dp_cuts=None):
         self.mode = mode
         self.log_dir = log_dir
         self.dataset = dataset
@@ -86,6 +86,7 @@ class BaseModel(object):
         self.use_graph = use_graph
         self.crop_aware = crop_aware
         self.seed = seed
+        self.dp_cuts = dp_cuts                   # gradient-bucket boundaries (layer names, backward order); None = model default
         self.pg = D.DataParallel(process_group, overlap=overlap_allreduce)
         self._graphs = {}
         # side streams: wgrad_streams for the filter gradients + one auxiliary (weight re-pack)
@@ -131,22 +132,36 @@ class BaseModel(object):
         self._pin_i = 0
 
     def _init_saver(self, name='model'):
-        if self.save_dir is None:
-            self.save_path = None
-            return
-        os.makedirs(self.save_dir, exist_ok=True)
-        self.save_path = os.path.join(self.save_dir, '{}.ckpt'.format(name))
-        if self.load_snapshot:
-            try:
-                path = self.load_snapshot_from if self.load_snapshot_from else self._latest_checkpoint()
-                self.restore(path)
-                print('Success! Resuming from global step {}'.format(self.global_step))
-            except Exception as e:           # the reference swallows restore failures (basemodel.py:120-134)
-                print('Failed to load snapshot; proceed with training ({})'.format(e))
-        else:
+        """Checkpoint wiring (models/basemodel.py:112-136).  An explicit `load_snapshot_from` is honoured whether or not a
+        save_dir exists; only the 'latest checkpoint' lookup needs one.  TRAINING mode keeps the reference's behaviour of
+        printing and continuing when a restore fails; INFERENCE mode must not serve random weights silently: a failed
+        explicit restore raises, and a model left without restored weights says so (set_weights() / restore() clear it)."""
+        self.save_path = None
+        self.weights_restored = False
+        if self.save_dir is not None:
+            os.makedirs(self.save_dir, exist_ok=True)
+            self.save_path = os.path.join(self.save_dir, '{}.ckpt'.format(name))
+        if not self.load_snapshot:
             print('Training from scratch. Set load_snapshot = True to resume training.')
+            return
+        path = None
+        try:
+            path = self.load_snapshot_from if self.load_snapshot_from else self._latest_checkpoint()
+            self.restore(path)
+            print('Success! Resuming from global step {}'.format(self.global_step))
+        except Exception as e:           # the reference swallows restore failures (basemodel.py:120-134)
+            if self.mode == 'INFERENCE' and self.load_snapshot_from:
+                raise Exception('INFERENCE mode: cannot restore weights from {!r}: {}'.format(self.load_snapshot_from, e))
+            if self.mode == 'INFERENCE':
+                import warnings
+                warnings.warn('INFERENCE-mode model holds RANDOM (xavier) weights: no snapshot was restored ({}); call '
+                              'restore(path) or set_weights(params) before infer()'.format(e), RuntimeWarning)
+            else:
+                print('Failed to load snapshot; proceed with training ({})'.format(e))
 
     def _latest_checkpoint(self):
+        if self.save_path is None:
+            raise IOError('no save_dir and no load_snapshot_from: nothing to restore')
         cands = glob.glob(self.save_path + '-*.npz')
         if not cands:
             raise IOError('no checkpoint under %s' % self.save_dir)
@@ -339,12 +354,12 @@ class BaseModel(object):
             self._load_batch(dataset, self.input_x, self.input_y)
         return self._bind_inputs(self.input_x, self.input_y)
 
-    def _train_step_dp(self, key=None):
+    def _train_step_dp(self, key=None, probe=None):
         """Data-parallel step: backward is cut into segments at gradient-bucket boundaries; each finished
         bucket (a contiguous slice of the flat gradient arena) is all-reduced on RCCL's stream while
-        the next segment's dgrad/wgrad kernels run; Adam runs after the last bucket lands."""
-        s = self._stream()
-
+        the next segment's dgrad/wgrad kernels run; Adam runs after the last bucket lands.
+        probe (a list): instrumented step -- an event after the last backward segment and one behind the wait for each
+        bucket are appended, so that the EXPOSED part of every all-reduce can be read off (dp_exposure_report)."""
         def head():
             self.fwd_plan.run(self._stream(), self._side, flavor=self._flavor())
             self.bwd_segments[0][0].run(self._stream(), self._side, flavor=self._flavor())
@@ -353,8 +368,38 @@ class BaseModel(object):
         for i, (plan, (lo, hi)) in enumerate(self.bwd_segments[1:], 1):
             self._replay('dp%d' % i, lambda plan=plan: plan.run(self._stream(), self._side, flavor=self._flavor()))
             self.pg.all_reduce_bucket(self.store.g, lo, hi)
-        self.pg.wait_all()
+        if probe is None:
+            self.pg.wait_all()
+        else:
+            evs = [torch.cuda.Event(enable_timing=True)]
+            evs[0].record()
+            for w in self.pg.pending:
+                w.wait()
+                e = torch.cuda.Event(enable_timing=True); e.record()
+                evs.append(e)
+            self.pg.pending = []
+            probe.append(evs)
         self._replay('upd', self._run_update)
+
+    def dp_exposure_report(self, steps=5):
+        """Per-bucket exposure of the gradient all-reduce: the time the compute stream idles for bucket i AFTER the last backward
+        segment has run and the buckets before it have landed (0 = fully hidden behind backward).  Real train steps."""
+        if not self.pg.enabled:
+            return None
+        probe = []
+        for _ in range(steps):
+            key = self._bind_batch(self.dataset)
+            self._train_step_dp(key, probe)
+            self._gs_host += 1
+        torch.cuda.synchronize(self.device)
+        nb = len(self.bwd_segments)
+        us = [0.0] * nb
+        for evs in probe:
+            for i in range(min(nb, len(evs) - 1)):
+                us[i] += evs[i].elapsed_time(evs[i + 1]) * 1e3 / len(probe)
+        return {'buckets_mb': [round((hi - lo) * 4 / 1e6, 3) for _, (lo, hi) in self.bwd_segments],
+                'cuts': list(getattr(self, 'dp_cuts_used', [])), 'exposed_us': [round(u, 1) for u in us],
+                'exposed_total_us': round(sum(us), 1), 'world': self.pg.world}
 
     def last_loss(self):
         """Mean x-entropy of the most recent train_step (synchronises)."""
@@ -374,10 +419,12 @@ class BaseModel(object):
             print('test() with INFERENCE mode invalid')
             return
         ds = self.test_dataset if self.test_dataset is not None else self.dataset
+        train_loss = self.loss_buf.clone()            # last_loss() keeps reporting the most recent TRAIN step
         self._bind_batch(ds)
         self.loss_buf.zero_()
         self.fwd_plan.run(self._stream(), skip=('step_begin',))     # a test pass does not advance global_step
         self.last_test_loss = float(self.loss_buf.item())
+        self.loss_buf.copy_(train_loss)
         print('TEST LOSS', self.last_test_loss, self.global_step)
         self.write_summary({'test_loss': self.last_test_loss})
 
@@ -386,6 +433,8 @@ class BaseModel(object):
         if self.mode == 'INFERENCE':
             print('snapshot() with INFERENCE mode invalid')
             return
+        if self.save_path is None:
+            raise Exception('snapshot(): the model was built with save_dir=None')
         gs = self.global_step
         path = '{}-{}.npz'.format(self.save_path, gs)
         print('Global step {}, snapshotting to {}'.format(gs, path))
@@ -410,6 +459,7 @@ class BaseModel(object):
             self.store.v.copy_(torch.from_numpy(z['v']))
         self._gs_host = int(z['global_step'])
         self.store.step.fill_(self._gs_host)          # both counters: nothing is in flight here
+        self.weights_restored = True
         self._repack()
 
     def _repack(self):
@@ -481,6 +531,7 @@ class BaseModel(object):
     def set_weights(self, params):
         """Load {scope: {'weights','biases'}} in TF layouts (tests / interchange)."""
         self.store.set_params(params)
+        self.weights_restored = True
         self._repack()
 
     # ------------------------------------------------------------------ inference

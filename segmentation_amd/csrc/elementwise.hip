@@ -162,15 +162,21 @@ __global__ void cast_pad_kernel(const float* x, int64_t npix, int c, seg_view ds
   }
 }
 
-SEG_DEV uint32_t mix32(uint64_t k) {  // splitmix64 finaliser -> 32 random bits per (seed, counter)
+// Counter-based Bernoulli bits: one independent stream per seed.  key = splitmix64(seed) is XOR-ed into the 64-bit counter
+// (offset + element index) and the result goes through the splitmix64 finaliser again; the draw is its high 32 bits.  The
+// per-site seeds (seed+2, seed+5, ...) and the per-pass offsets (t << 40) of infer_mc therefore cannot alias: two streams
+// meet only if key1 ^ key2 equals the XOR of two counters, and counters stay far below 2^48.  Restated bit for bit in
+// oracle/np_ops.py (dropout_mask).
+SEG_DEV uint64_t splitmix64(uint64_t k) {
   k += 0x9E3779B97F4A7C15ull; k = (k ^ (k >> 30)) * 0xBF58476D1CE4E5B9ull; k = (k ^ (k >> 27)) * 0x94D049BB133111EBull;
-  return (uint32_t)((k ^ (k >> 31)) >> 16);
+  return k ^ (k >> 31);
 }
 template <typename T>
 __global__ void dropout_kernel(seg_view xin, seg_view yout, int B, int H, int W, int C8, float keep, uint64_t seed, uint64_t offset) {
   const int64_t total = (int64_t)B * H * W * C8;
   const float inv = 1.f / keep;
   const uint32_t thr = (uint32_t)(keep * 4294967295.0);
+  const uint64_t key = splitmix64(seed);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t t = i;
     const int c8 = t % C8; t /= C8;
@@ -180,7 +186,7 @@ __global__ void dropout_kernel(seg_view xin, seg_view yout, int B, int H, int W,
     v.load(reinterpret_cast<const T*>(xin.ptr) + view_off(xin, b, y, x) + c8 * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const uint32_t r = mix32(seed * 0x100000001B3ull + offset + (uint64_t)i * 8 + e);
+      const uint32_t r = (uint32_t)(splitmix64(key ^ (offset + (uint64_t)i * 8 + e)) >> 32);
       o.set(e, r <= thr ? v.get(e) * inv : 0.f);
     }
     o.store(reinterpret_cast<T*>(yout.ptr) + view_off(yout, b, y, x) + c8 * 8);

@@ -97,25 +97,74 @@ class ArrayDataSet(object):
         return self.images[i], self.masks[i]
 
 
-class ThreadedImageMaskDataSet(object):
-    """Image/mask folder loader: aligned shuffle (one permutation for both lists = the reference's same-seed
-    string_input_producer pair, utils/datasets.py:136-143), /255, joint random crop of the 3+1 channel stack
-    (:176-190), binary masks (255 -> 1, else 0; F15), batches assembled by producer threads into a bounded
-    queue of pinned host buffers (back-pressure = queue full)."""
+class _WorkerError(object):
+    """An exception caught in a producer thread, carried through the queue and re-raised in the consumer."""
 
-    def __init__(self, image_dir, mask_dir, n_classes=2, batch_size=96, crop_size=256, ratio=1.0, capacity=8,
-                 image_ext='jpg', mask_ext='png', seed=5555, threads=4, min_holding=0, loader=None):
+    def __init__(self, exc, where):
+        self.exc, self.where = exc, where
+
+
+def _get_checked(q, alive, what, poll=0.2):
+    """q.get() that cannot hang on dead producers: polls, re-raises a producer's exception, and raises when every
+    producer has exited with nothing queued."""
+    while True:
+        try:
+            item = q.get(timeout=poll)
+        except queue.Empty:
+            if not alive():
+                try:
+                    item = q.get_nowait()         # (something may have been queued just before the last producer exited)
+                except queue.Empty:
+                    raise RuntimeError('%s: every producer thread has stopped and the queue is empty' % what)
+            else:
+                continue
+        if isinstance(item, _WorkerError):
+            raise RuntimeError('%s: producer thread failed in %s: %r' % (what, item.where, item.exc)) from item.exc
+        return item
+
+
+class ThreadedImageMaskDataSet(object):
+    """Image/mask folder loader behind the reference's ImageMaskDataSet keyword set (utils/datasets.py:94-197), built on
+    the producer-thread -> bounded FIFO pattern of utils/threaded_dataset.py:82-90,124-166:
+
+      file order   one permutation per EPOCH shared by the image and the mask list (= the reference's pair of
+                   string_input_producer(shuffle=True, seed=seed), utils/datasets.py:136-143)
+      sample       decode, /255, joint random crop of the 3+1 channel stack (:176-190), mask -> uint8 (255 -> 1, else 0: F15)
+      batching     tf.train.shuffle_batch (:166-171): decoded samples enter a pool of at most `capacity`; a batch is drawn
+                   uniformly from the pool once it holds `min_holding` + batch_size samples (min_after_dequeue)
+      hand-over    batches are assembled IN a ring of pre-allocated pinned host buffers (no allocation, no pin_memory() per
+                   batch); get_batch() returns views of a ring slot that stay valid until the second-next get_batch()
+
+    `ratio` is accepted and unused exactly as in the reference (its only use there, decode_jpeg(ratio=), is commented out:
+    utils/datasets.py:160,164).  `threads` decode workers + one batch assembler; any exception in them (unreadable file, image
+    smaller than the crop) is re-raised by get_batch() instead of hanging the training loop."""
+
+    RING = 4
+
+    def __init__(self, image_dir, mask_dir, image_names=None, mask_names=None, split_train_val=False, n_classes=2,
+                 batch_size=96, crop_size=256, ratio=1.0, capacity=5000, image_ext='jpg', mask_ext='png', seed=5555,
+                 threads=4, min_holding=1250, loader=None):
         self.image_names = sorted(glob.glob(os.path.join(image_dir, '*.' + image_ext)))
         self.mask_names = sorted(glob.glob(os.path.join(mask_dir, '*.' + mask_ext)))
         if len(self.image_names) != len(self.mask_names) or not self.image_names:
             raise Exception('image / mask lists differ or are empty')
         self.batch_size, self.crop_size, self.n_classes = batch_size, crop_size, n_classes
+        self.ratio, self.capacity, self.min_holding = ratio, max(int(capacity), batch_size), max(int(min_holding), 0)
+        if self.min_holding + batch_size > self.capacity:
+            self.min_holding = self.capacity - batch_size
         self.has_masks, self.use_feed = True, False
-        self.threads, self.seed = threads, seed
-        self.q = queue.Queue(maxsize=capacity)
+        self.threads, self.seed = max(1, int(threads)), seed
+        self._samples = queue.Queue(maxsize=max(2 * batch_size, 64))      # decoded samples (back-pressure on the decoders)
+        self._ready = queue.Queue()                                       # ring slots holding an assembled batch
+        self._free = queue.Queue()
         self._stop = threading.Event()
         self._workers = []
         self._loader = loader or self._pil_loader
+        self._order_lock = threading.Lock()
+        self._order_rng = np.random.default_rng(seed)
+        self._order, self._pos = None, 0
+        self._ring = None
+        self._held = []
         self.sess = None
 
     @staticmethod
@@ -126,47 +175,117 @@ class ThreadedImageMaskDataSet(object):
     def set_tf_sess(self, sess):
         self.sess = sess
 
-    def _produce(self, wid):
-        rng = np.random.default_rng(self.seed + wid)
-        n, c = len(self.image_names), self.crop_size
-        pin = torch.cuda.is_available()
-        while not self._stop.is_set():
-            img = torch.empty((self.batch_size, c, c, 3), dtype=torch.float32)
-            msk = torch.empty((self.batch_size, c, c, 1), dtype=torch.uint8)
-            if pin:
-                img, msk = img.pin_memory(), msk.pin_memory()
-            for b in range(self.batch_size):
-                i = int(rng.integers(0, n))
-                im = self._loader(self.image_names[i]).astype(np.float32) / 255.0
-                mk = self._loader(self.mask_names[i]).astype(np.float32) / 255.0
+    def _next_index(self):
+        with self._order_lock:
+            if self._order is None or self._pos >= len(self._order):
+                self._order, self._pos = self._order_rng.permutation(len(self.image_names)), 0
+            i = int(self._order[self._pos]); self._pos += 1
+            return i
+
+    def _decode(self, wid):
+        rng = np.random.default_rng([self.seed, 1 + wid])
+        c = self.crop_size
+        try:
+            while not self._stop.is_set():
+                i = self._next_index()
+                im = self._loader(self.image_names[i])
+                mk = self._loader(self.mask_names[i])
                 if mk.ndim == 3:
                     mk = mk[..., 0]
+                if im.ndim == 2:
+                    im = np.repeat(im[..., None], 3, axis=2)
                 h, w = im.shape[:2]
+                if h < c or w < c or mk.shape[:2] != (h, w):
+                    raise ValueError('%s is %dx%d (mask %s): cannot take a %dx%d crop' % (self.image_names[i], h, w, mk.shape[:2], c, c))
                 y0, x0 = int(rng.integers(0, h - c + 1)), int(rng.integers(0, w - c + 1))
-                img[b] = torch.from_numpy(np.ascontiguousarray(im[y0:y0 + c, x0:x0 + c, :3]))
-                msk[b, ..., 0] = torch.from_numpy(np.ascontiguousarray(mk[y0:y0 + c, x0:x0 + c]).astype(np.uint8))
+                x = im[y0:y0 + c, x0:x0 + c, :3].astype(np.float32) / np.float32(255.0)
+                y = (mk[y0:y0 + c, x0:x0 + c].astype(np.float32) / np.float32(255.0)).astype(np.uint8)
+                while not self._stop.is_set():
+                    try:
+                        self._samples.put((x, y), timeout=0.1)
+                        break
+                    except queue.Full:
+                        continue
+        except Exception as e:                      # noqa: surfaces in get_batch()
+            self._ready.put(_WorkerError(e, 'decode worker %d' % wid))
+
+    def _assemble(self):
+        rng = np.random.default_rng([self.seed, 0])
+        pool, B = [], self.batch_size
+        try:
             while not self._stop.is_set():
-                try:
-                    self.q.put((img, msk), timeout=0.1)
-                    break
-                except queue.Full:
-                    continue
+                while len(pool) < self.min_holding + B and not self._stop.is_set():      # fill to min_after_dequeue + one batch
+                    pool.append(_get_checked(self._samples, self._decoders_alive, 'ThreadedImageMaskDataSet'))
+                while len(pool) < self.capacity:                                        # then take what is there, up to capacity
+                    try:
+                        pool.append(self._samples.get_nowait())
+                    except queue.Empty:
+                        break
+                slot = None
+                while slot is None and not self._stop.is_set():
+                    try:
+                        slot = self._free.get(timeout=0.1)
+                    except queue.Empty:
+                        continue
+                if slot is None:
+                    return
+                img, msk = self._ring[slot]
+                for b in range(B):
+                    j = int(rng.integers(0, len(pool)))
+                    pool[j], pool[-1] = pool[-1], pool[j]
+                    x, y = pool.pop()
+                    img[b] = torch.from_numpy(x)
+                    msk[b, ..., 0] = torch.from_numpy(y)
+                self._ready.put(slot)
+        except Exception as e:                      # noqa
+            self._ready.put(_WorkerError(e, 'batch assembler'))
+
+    def _decoders_alive(self):
+        return any(t.is_alive() for t in self._workers[1:])
+
+    def _producers_alive(self):
+        return bool(self._workers) and self._workers[0].is_alive()
 
     def start(self):
         if self._workers:
             return
-        for i in range(self.threads):
-            t = threading.Thread(target=self._produce, args=(i,), daemon=True)
+        c, B = self.crop_size, self.batch_size
+        pin = torch.cuda.is_available()
+        self._ring = []
+        for i in range(self.RING):
+            img = torch.empty((B, c, c, 3), dtype=torch.float32)
+            msk = torch.empty((B, c, c, 1), dtype=torch.uint8)
+            if pin:
+                img, msk = img.pin_memory(), msk.pin_memory()
+            self._ring.append((img, msk))
+            self._free.put(i)
+        ts = [threading.Thread(target=self._assemble, daemon=True)]
+        ts += [threading.Thread(target=self._decode, args=(i,), daemon=True) for i in range(self.threads)]
+        self._workers = ts
+        for t in reversed(ts):
             t.start()
-            self._workers.append(t)
 
     def stop(self):
         self._stop.set()
 
     def get_batch(self):
+        """-> (float32 [B,c,c,3] in [0,1], uint8 [B,c,c,1]); views of a pinned ring slot, valid until the second-next call."""
         self.start()
-        img, msk = self.q.get()
+        while len(self._held) >= 2:
+            self._free.put(self._held.pop(0))
+        slot = _get_checked(self._ready, self._producers_alive, 'ThreadedImageMaskDataSet')
+        self._held.append(slot)
+        img, msk = self._ring[slot]
         return img.numpy(), msk.numpy()
+
+    def get_pinned_batch(self):
+        """Same, as the pinned torch tensors themselves (DevicePrefetcher copies H2D straight out of them)."""
+        self.start()
+        while len(self._held) >= 2:
+            self._free.put(self._held.pop(0))
+        slot = _get_checked(self._ready, self._producers_alive, 'ThreadedImageMaskDataSet')
+        self._held.append(slot)
+        return self._ring[slot]
 
 
 class DevicePrefetcher(object):
@@ -199,51 +318,72 @@ class DevicePrefetcher(object):
         if hasattr(self.ds, 'set_tf_sess'):
             self.ds.set_tf_sess(sess)
 
-    def _alloc(self, img, msk):
+    def _alloc(self, img, msk, staging=True):
+        """depth device slots (+ pinned staging buffers unless the dataset hands out pinned memory itself): allocated once."""
         self._slots = []
         for i in range(self.depth):
-            px = torch.empty(img.shape, dtype=torch.float32).pin_memory()
-            py = torch.empty(msk.shape, dtype=torch.uint8).pin_memory()
+            px = torch.empty(img.shape, dtype=torch.float32).pin_memory() if staging else None
+            py = torch.empty(msk.shape, dtype=torch.uint8).pin_memory() if staging else None
             dx = torch.empty(img.shape, dtype=torch.float32, device=self.device)
             dy = torch.empty(msk.shape, dtype=torch.uint8, device=self.device)
             self._slots.append({'px': px, 'py': py, 'dx': dx, 'dy': dy, 'ready': None, 'consumed': None})
             self._free.put(i)
 
-    def _produce(self):
-        torch.cuda.set_device(self.device)
+    def _take_slot(self):
         while not self._stop.is_set():
-            with self._lock:
-                img, msk = self.ds.get_batch()
-            img = img.numpy() if isinstance(img, torch.Tensor) else np.asarray(img, np.float32)
-            msk = msk.numpy() if isinstance(msk, torch.Tensor) else np.asarray(msk, np.uint8)
-            with self._alloc_lock:
-                if self._slots is None:
-                    self._alloc(img, msk)
-            while not self._stop.is_set():
-                try:
-                    i = self._free.get(timeout=0.1)
-                    break
-                except queue.Empty:
-                    continue
-            else:
-                return
+            try:
+                i = self._free.get(timeout=0.1)
+            except queue.Empty:
+                continue
             s = self._slots[i]
             if s['consumed'] is not None:
-                s['consumed'].synchronize()          # the consumer's D2D copy out of this slot has finished
-            s['px'].copy_(torch.from_numpy(np.ascontiguousarray(img)))
-            s['py'].copy_(torch.from_numpy(np.ascontiguousarray(msk)))
-            with torch.cuda.stream(self._copy):
-                s['dx'].copy_(s['px'], non_blocking=True)
-                s['dy'].copy_(s['py'], non_blocking=True)
-                ev = torch.cuda.Event(); ev.record(self._copy)
-            s['ready'] = ev
-            self._ready.put(i)
+                s['consumed'].synchronize()          # the consumer's reads of this slot have finished
+            return i, s
+        return None, None
+
+    def _produce(self, tid=0):
+        try:
+            torch.cuda.set_device(self.device)
+            direct = hasattr(self.ds, 'get_pinned_batch')      # the loader's own pinned ring: H2D straight out of it
+            if direct and tid != 0:
+                return
+            prev = None
+            while not self._stop.is_set():
+                if direct:
+                    if prev is not None:
+                        prev.synchronize()           # the ring slot handed out two fetches ago is recycled by the next fetch
+                    img, msk = self.ds.get_pinned_batch()
+                else:
+                    with self._lock:
+                        img, msk = self.ds.get_batch()
+                    img = img if isinstance(img, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img, np.float32))
+                    msk = msk if isinstance(msk, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(msk, np.uint8))
+                with self._alloc_lock:
+                    if self._slots is None:
+                        self._alloc(img, msk, staging=not direct)
+                i, s = self._take_slot()
+                if s is None:
+                    return
+                if direct:
+                    hx, hy = img, msk
+                else:
+                    s['px'].copy_(img.reshape(s['px'].shape)); s['py'].copy_(msk.reshape(s['py'].shape))
+                    hx, hy = s['px'], s['py']
+                with torch.cuda.stream(self._copy):
+                    s['dx'].copy_(hx.reshape(s['dx'].shape), non_blocking=True)
+                    s['dy'].copy_(hy.reshape(s['dy'].shape), non_blocking=True)
+                    ev = torch.cuda.Event(); ev.record(self._copy)
+                s['ready'] = ev
+                prev = ev
+                self._ready.put(i)
+        except Exception as e:                      # noqa: surfaces in get_device_batch()
+            self._ready.put(_WorkerError(e, 'DevicePrefetcher producer %d' % tid))
 
     def start(self):
         if self._thr is None:
             if hasattr(self.ds, 'start'):
                 self.ds.start()
-            self._thr = [threading.Thread(target=self._produce, daemon=True) for _ in range(self.threads)]
+            self._thr = [threading.Thread(target=self._produce, args=(i,), daemon=True) for i in range(self.threads)]
             for t in self._thr:
                 t.start()
 
@@ -258,7 +398,7 @@ class DevicePrefetcher(object):
             ev = torch.cuda.Event(); ev.record()
             self._slots[self._last]['consumed'] = ev
             self._free.put(self._last)
-        i = self._ready.get()
+        i = _get_checked(self._ready, lambda: any(t.is_alive() for t in self._thr), 'DevicePrefetcher')
         s = self._slots[i]
         torch.cuda.current_stream().wait_event(s['ready'])
         self._last = i

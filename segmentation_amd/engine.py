@@ -246,9 +246,13 @@ class Plan(object):
 
         def join(st_):
             # (eagerly a stream that has launched nothing since the main stream last waited for it needs no second wait)
+            nonlocal main_epoch
             if capturing or id(st_) in dirty:
                 fork(st_, main)
                 dirty.discard(id(st_))
+                # the main stream now holds st_'s work: a side stream that forked at the current epoch has NOT seen it, so the
+                # fork elision below must not treat it as up to date (a later op on it may consume st_'s output)
+                main_epoch += 1
 
         def flush():
             ev1 = None
@@ -370,7 +374,7 @@ class Plan(object):
     def run_profiled(self, stream, torch_mod, side=None, flavor='per_layer'):
         """Like run(), with a HIP event recorded before and after every launch ON THE STREAM THE KERNEL IS LAUNCHED ON
         (main or side), so that the per-kernel durations include the same cross-stream overlap as the timed region.
-        Returns [(op name, kernel name, ms, flops)]."""
+        Returns [(op name, kernel name, ms, flops, algorithmic HBM bytes)]."""
         sp = C.c_void_p(stream)
         main = torch_mod.cuda.current_stream()
         E_ = lambda: torch_mod.cuda.Event(enable_timing=True)
@@ -416,7 +420,7 @@ class Plan(object):
         for st in used.values():
             ev = torch_mod.cuda.Event(); ev.record(st); main.wait_event(ev)
         torch_mod.cuda.synchronize()
-        return [(self.ops[i][0], self.kernel_name(i), e0.elapsed_time(e1), self.meta[i].get('flops', 0)) for i, e0, e1 in recs]
+        return [(self.ops[i][0], self.kernel_name(i), e0.elapsed_time(e1), self.meta[i].get('flops', 0), self.meta[i].get('bytes', 0)) for i, e0, e1 in recs]
 
 
 def tune_key(d):
@@ -463,6 +467,11 @@ class Net(object):
         self.pool_fused = False
         self.tune = load_tuning() if dtype == L.SEG_BF16 else {}
 
+    @property
+    def es(self):
+        """bytes per activation element in HBM"""
+        return 4 if self.dtype == L.SEG_F32 else 2
+
     def _tuned(self, d):
         if d.cfg == 0 and self.tune:
             d.cfg = self.tune.get(tune_key(d), 0)
@@ -484,6 +493,7 @@ class Net(object):
         plan.keep.append(dv)
         fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
         plan.flops += fl
+        by = self.B * (H * W * layer.cin * 4 + Ho * Wo * layer.cout * self.es + (pool.H * pool.W * layer.cout * self.es if pool is not None else 0))
         mfma = self.dtype == L.SEG_BF16 and layer.cin <= 3 and layer.cout <= 64
         kern = 'conv_first_mfma_kernel' if mfma else 'conv_first_fwd_kernel'
         if pool is not None and mfma and os.environ.get('SEG_FUSE_POOL1', '1') != '0':
@@ -491,11 +501,11 @@ class Net(object):
             plan.keep.append(pv)
             plan.add(layer.name + '+pool', self.lib.seg_conv_first_pool_fwd, x_f32.data_ptr(), self.B, H, W, layer.cin,
                      self.store.p_ptr(layer.w_off), self.store.p_ptr(layer.b_off), layer.cout, layer.pad, C.byref(dv), Ho, Wo,
-                     1 if layer.relu else 0, C.byref(pv), pool.H, pool.W, self.dtype, kernel=kern, flops=fl)
+                     1 if layer.relu else 0, C.byref(pv), pool.H, pool.W, self.dtype, kernel=kern, flops=fl, bytes=by)
             return True
         plan.add(layer.name, self.lib.seg_conv_first_fwd, x_f32.data_ptr(), self.B, H, W, layer.cin,
                  self.store.p_ptr(layer.w_off), self.store.p_ptr(layer.b_off), layer.cout, layer.pad, C.byref(dv), Ho, Wo,
-                 1 if layer.relu else 0, self.dtype, kernel=kern, flops=fl)
+                 1 if layer.relu else 0, self.dtype, kernel=kern, flops=fl, bytes=by)
         return False
 
     def conv_fwd(self, plan, layer, srcs, Hi, Wi, dst, dst_off=(0, 0), out_f32=False, cfg=0, pool=None):
@@ -531,7 +541,10 @@ class Net(object):
                 d.pool = L.null_view(); d.pool_h = d.pool_w = 0
         plan.keep.append(d)
         fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
-        plan.add(name, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl)
+        # algorithmic HBM bytes: every tensor touched once (input window, output, filters; + the fused pooled map)
+        by = (self.B * (Hi * Wi * layer.cin * self.es + Ho * Wo * layer.cout * (4 if out_f32 else self.es)) + k * k * layer.cin * layer.cout * self.es
+              + (self.B * pool.H * pool.W * layer.cout * self.es if self.pool_fused else 0))
+        plan.add(name, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl, bytes=by)
         plan.flops += fl
         return Ho, Wo
 
@@ -549,7 +562,8 @@ class Net(object):
         self._tuned(d)
         plan.keep.append(d)
         fl = 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
-        plan.add(layer.name, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl)
+        by = self.B * Hi * Wi * (layer.cin + 4 * layer.cout) * self.es + 4 * layer.cin * layer.cout * self.es
+        plan.add(layer.name, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl, bytes=by)
         plan.flops += fl
 
     def pool_fwd(self, plan, src, dst, Ho, Wo):
@@ -589,14 +603,14 @@ class Net(object):
             w2 = L.WgradDesc.from_buffer_copy(w)
             w2.phase = 2
             plan.keep.append(w2)
-            plan.add(name, self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=sid)
+            plan.add(name, self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=sid, bytes=getattr(self, '_wg_bytes', 0))
             if self.batch_reduce is not True:
                 plan.add(name + '/reduce', self.lib.seg_conv2d_wgrad, C.byref(w2), kernel='wgrad_reduce_kernel', side=sid, flavor='per_layer')
             if self.batch_reduce is not False:
                 self._pending_reduce.setdefault(sid, []).append(w)
         else:
             w.phase = 0
-            plan.add(name, self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=sid)
+            plan.add(name, self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=sid, bytes=getattr(self, '_wg_bytes', 0))
 
     def flush_reduce(self, plan, on_main=False):
         """Reduces the slabs of every filter gradient emitted since the last flush: one launch per side stream (each
@@ -652,6 +666,7 @@ class Net(object):
         self._tuned(w)
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
+        self._wg_bytes = self.B * (H * W * layer.cin * 4 + Ho * Wo * layer.cout * self.es) + 9 * layer.cin * layer.cout * 4
         # same side stream as the im2col that feeds it (stream 1): in order behind it, so a plan that runs forward and
         # backward back to back needs no join of the side streams in between
         # (same_stream=False: the data-parallel plans, which join the side streams after the forward anyway, keep the
@@ -678,6 +693,7 @@ class Net(object):
         self._tuned(w)
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
+        self._wg_bytes = self.B * (Hi * Wi * layer.cin + Ho * Wo * layer.cout) * self.es + k * k * layer.cin * layer.cout * 4
         self._add_wgrad(plan, layer.name + '/dw', w, fl)
         plan.flops += fl
         n_off = 0
@@ -702,7 +718,9 @@ class Net(object):
             self._tuned(d)
             plan.keep.append(d)
             fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
-            plan.add(layer.name + '/dx01', self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl)
+            nmask = sum(layer.cin_segs[i] for i, m_ in enumerate((mask0, mask1)) if m_ is not None)
+            by = self.B * (Ho * Wo * layer.cout + Hi * Wi * (layer.cin + nmask)) * self.es + k * k * layer.cin * layer.cout * self.es
+            plan.add(layer.name + '/dx01', self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl, bytes=by)
             plan.flops += fl
             return
         for i, ds in enumerate(dsrcs):
@@ -723,7 +741,9 @@ class Net(object):
                 self._tuned(d)
                 plan.keep.append(d)
                 fl = 2 * self.B * Ho * Wo * k * k * layer.cin_segs[i] * layer.cout
-                plan.add(layer.name + '/dx%d' % i, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl)
+                by = (self.B * (Ho * Wo * layer.cout + Hi * Wi * layer.cin_segs[i] * (1 + (1 if mask is not None else 0) + (1 if d.accum else 0))) * self.es
+                      + k * k * layer.cin_segs[i] * layer.cout * self.es)
+                plan.add(layer.name + '/dx%d' % i, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl, bytes=by)
                 plan.flops += fl
             n_off += layer.cin_p[i]
 
@@ -740,6 +760,7 @@ class Net(object):
         self._tuned(w)
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
+        self._wg_bytes = self.B * Hi * Wi * (layer.cin + 4 * layer.cout) * self.es + 4 * layer.cin * layer.cout * 4
         self._add_wgrad(plan, layer.name + '/dw', w, fl)
         plan.flops += fl
         if dsrc is not None:
@@ -756,7 +777,8 @@ class Net(object):
             d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
             self._tuned(d)
             plan.keep.append(d)
-            plan.add(layer.name + '/dx', self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl)
+            by = self.B * Hi * Wi * (4 * layer.cout + layer.cin * (2 if mask is not None else 1)) * self.es + 4 * layer.cin * layer.cout * self.es
+            plan.add(layer.name + '/dx', self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl, bytes=by)
             plan.flops += fl
 
     def pool_bwd(self, plan, y_act, dpool, add, add_hw, add_off, dz, H, W):
@@ -767,12 +789,13 @@ class Net(object):
         plan.add('pool/bwd', self.lib.seg_maxpool2x2_bwd, C.byref(yv), C.byref(pv), C.byref(av), add_hw[0], add_hw[1],
                  add_off[0], add_off[1], C.byref(zv), self.B, H, W, y_act.Cp, self.dtype, kernel='maxpool_bwd_kernel')
 
-    def dropout(self, plan, act, keep, seed, offset_ref):
-        """In-place slim.dropout-style mask: x * Bernoulli(keep) / keep.  offset_ref is a ctypes c_uint64 whose current
-        value is read at every launch (a fresh mask per stochastic pass without rebuilding the plan)."""
+    def dropout(self, plan, act, keep, seed, offset_ref, dst=None):
+        """slim.dropout-style mask: dst = act * Bernoulli(keep) / keep (in place when dst is None).  offset_ref is a ctypes
+        c_uint64 whose current value is read at every launch (a fresh mask per stochastic pass without rebuilding the plan)."""
         v = act.view()
-        plan.keep += [v, offset_ref]
-        plan.add('dropout', self.lib.seg_dropout, C.byref(v), C.byref(v), self.B, act.H, act.W, act.Cp, float(keep), int(seed), offset_ref,
+        o = dst.view() if dst is not None else v
+        plan.keep += [v, o, offset_ref]
+        plan.add('dropout', self.lib.seg_dropout, C.byref(v), C.byref(o), self.B, act.H, act.W, act.Cp, float(keep), int(seed), offset_ref,
                  self.dtype, kernel='dropout_kernel')
 
     def relu_grad(self, plan, dy, y_act, dz, H, W):
@@ -817,7 +840,8 @@ class Net(object):
         fl = 2 * 2 * self.B * H * W * layer.cin * layer.cout          # forward + input gradient
         plan.add(layer.name + '+xent+dx', self.lib.seg_head_xent, C.byref(av), self.store.p_ptr(layer.w_off), self.store.p_ptr(layer.b_off),
                  layer.cin, labels_u8.data_ptr(), LH, LW, loff[0], loff[1], self.B, H, W, n_classes, inv_n, loss_buf.data_ptr(),
-                 C.byref(lv), C.byref(dv), C.byref(gv), self.dtype, kernel='head_xent_kernel', flops=fl)
+                 C.byref(lv), C.byref(dv), C.byref(gv), self.dtype, kernel='head_xent_kernel', flops=fl,
+                 bytes=self.B * H * W * (2 * layer.cin * self.es + n_classes * (4 + self.es) + 1))
         plan.flops += fl
 
     def sigmoid_argmax(self, plan, logits, H, W, n_classes, sig, out):

@@ -166,7 +166,16 @@ class UNetModel(BaseModel):
             net.conv_fwd(plan, Ly[c2], [(A[c1], 0, 0)], sh[c1], sw[c1], A[c2], pool=None if drop else nxt)
             pooled = net.pool_fused
             if drop:
-                net.dropout(plan, A[c2], dropout['keep'], dropout['seed'] + i, dropout['offset'])
+                split = dropout.get('split')
+                if split is not None and plan is not split:
+                    # everything up to here is deterministic: it stays in `plan` (run once per input); the stochastic rest
+                    # goes into dropout['split'] (run once per pass) and reads the un-masked map, so the mask is out of place
+                    raw, A[c2 + '/raw'] = A[c2], A[c2]
+                    A[c2] = net.act(sh[c2], sw[c2], Ly[c2].cout, name=c2 + '/drop')
+                    plan = split
+                    net.dropout(plan, raw, dropout['keep'], dropout['seed'] + i, dropout['offset'], dst=A[c2])
+                else:
+                    net.dropout(plan, A[c2], dropout['keep'], dropout['seed'] + i, dropout['offset'])
             prev = A[c2]
         skip_off = {}
         for i, (upn, skip, ca, cb) in enumerate(LEVELS):
@@ -231,10 +240,20 @@ class UNetModel(BaseModel):
         seg = E.Plan('bwd0')
         segs = []
 
-        # gradient-bucket boundaries (backward order).  Default ONE cut, after conv3_1: bucket 0 = decoder + conv5..conv3 = 99 % of
-        # the bytes, complete with the high-resolution 40 % of backward (conv2_x, conv1_x) still to run; bucket 1 = 0.26 MB, the
-        # only exposed collective.  Every boundary costs 17-30 us of drained side streams.
-        cuts = os.environ.get('SEG_DP_CUTS', 'conv3_1').split(',')
+        # gradient-bucket boundaries (backward order = arena order): a bucket is a contiguous slice of the flat gradient arena and
+        # its all-reduce is issued as soon as the backward segment that completes it has been enqueued.  Default: four buckets
+        # of ~10 / 11.5 / 9.2 / 0.26 MB cut after conv6_1, conv5_2 and conv3_1 (several medium messages launched as
+        # they complete; the big tensors conv6_1 / conv5_2 / conv5_1 appear in the MIDDLE of backward and the last bucket --
+        # conv2_x + conv1_x, the only one with nothing left to hide behind -- is tiny).  Every boundary drains the side streams
+        # (17-30 us on one GPU), so SEG_DP_CUTS / dp_cuts= can trade boundaries for message size once an
+        # N > 1 run has been measured ('conv3_1' = the two-bucket form; 'conv6_2,upconv1,conv5_2,conv5_1,conv3_1' = 4-9 MB messages);
+        # bench.py --dp-cuts auto times the candidates on the actual node and keeps the fastest.
+        cuts = getattr(self, 'dp_cuts', None) or os.environ.get('SEG_DP_CUTS', 'conv6_1,conv5_2,conv3_1')
+        cuts = [c for c in (cuts.split(',') if isinstance(cuts, str) else list(cuts)) if c]
+        for c_ in cuts:
+            if c_ not in Ly:
+                raise Exception('dp cut %r is not a layer (one of %s)' % (c_, ', '.join(BWD_ORDER)))
+        self.dp_cuts_used = cuts
 
         def close_segment(last_layer):
             nonlocal seg
@@ -248,12 +267,14 @@ class UNetModel(BaseModel):
         # output layer
         net.conv_bwd(seg, Ly['output'], [(A['conv9_2'], 0, 0)], A['conv9_2'].H, A['conv9_2'].W, dlog,
                      [None if fuse_head else (gz('conv9_2'), (0, 0), A['conv9_2'], (0, 0))])
+        close_segment('output')
         dskip = {}
         prev_of = {'upconv1': 'conv5_2', 'upconv2': 'conv6_2', 'upconv3': 'conv7_2', 'upconv4': 'conv8_2'}
         for lvl in (3, 2, 1, 0):
             upn, skip, ca, cb = LEVELS[lvl]
             # conv?_2
             net.conv_bwd(seg, Ly[cb], [(A[ca], 0, 0)], A[ca].H, A[ca].W, G[cb], [(gz(ca), (0, 0), A[ca], (0, 0))])
+            close_segment(cb)
             # conv?_1 on [skip_crop | up]: two dgrad launches (skip half, up half)
             so = skip_off[skip]
             uh, uw = A[upn].H, A[upn].W
@@ -267,12 +288,15 @@ class UNetModel(BaseModel):
             dskip[skip] = dsk
             net.conv_bwd(seg, Ly[ca], [(A[skip], so[0], so[1]), (A[upn], 0, 0)], uh, uw, G[ca],
                          [skip_spec, (gz(upn), (0, 0), A[upn], (0, 0))])
+            close_segment(ca)
             # transposed conv
             pn = prev_of[upn]
             net.up_bwd(seg, Ly[upn], A[pn], A[pn].H, A[pn].W, G[upn], gz(pn), A[pn])
+            close_segment(upn)
         # bottleneck
         net.conv_bwd(seg, Ly['conv5_2'], [(A['conv5_1'], 0, 0)], A['conv5_1'].H, A['conv5_1'].W, G['conv5_2'],
                      [(gz('conv5_1'), (0, 0), A['conv5_1'], (0, 0))])
+        close_segment('conv5_2')
         dP = {}
         dP[4] = net.act(A['pool4'].H, A['pool4'].W, A['pool4'].C, name='dpool4')
         net.conv_bwd(seg, Ly['conv5_1'], [(A['pool4'], 0, 0)], A['pool4'].H, A['pool4'].W, G['conv5_1'], [(dP[4], (0, 0), None, (0, 0))])
@@ -282,16 +306,17 @@ class UNetModel(BaseModel):
             so = skip_off[c2]
             net.pool_bwd(seg, A[c2], dP[i], dskip[c2], (dskip[c2].H, dskip[c2].W), so, gz(c2), A[c2].H, A[c2].W)
             net.conv_bwd(seg, Ly[c2], [(A[c1], 0, 0)], A[c1].H, A[c1].W, G[c2], [(gz(c1), (0, 0), A[c1], (0, 0))])
+            close_segment(c2)
             pin = A['pool%d' % (i - 1)]
             dP[i - 1] = net.act(pin.H, pin.W, pin.C, name='dpool%d' % (i - 1))
             net.conv_bwd(seg, Ly[c1], [(pin, 0, 0)], pin.H, pin.W, G[c1], [(dP[i - 1], (0, 0), None, (0, 0))])
-            if i == 3:
-                close_segment('conv3_1')      # third bucket = conv2_x + conv1_x only (0.26 MB): the exposed all-reduce is tiny
+            close_segment(c1)
         # conv1_2 (window of conv1_1 at o4, extent t4+2) then pool1 + skip add -> dZ(conv1_1)
         t4h, t4w = A['upconv4'].H, A['upconv4'].W
         d11s = net.act(t4h + 2, t4w + 2, A['conv1_1'].C, name='d_conv1_1_skip')
         net.conv_bwd(seg, Ly['conv1_2'], [(A['conv1_1'], o4[0], o4[1])], t4h + 2, t4w + 2, dskip['conv1_2'],
                      [(d11s, (0, 0), None, (0, 0))])
+        close_segment('conv1_2')
         net.pool_bwd(seg, A['conv1_1'], dP[1], d11s, (t4h + 2, t4w + 2), o4, gz('conv1_1'), A['conv1_1'].H, A['conv1_1'].W)
         net.first_bwd(seg, Ly['conv1_1'], self.input_x, H, W, G['conv1_1'], col=col, same_stream=not self.pg.enabled)
         close_segment('conv1_1')
@@ -319,42 +344,63 @@ class UNetModel(BaseModel):
     # ---- Monte-Carlo dropout inference (BASELINE config 5; BUILD-DEFINED, parity unpinned) ----
     MC_SITES = ('conv2_2', 'conv5_2', 'conv6_2')      # stage-2 encoder, bottleneck, first decoder
 
-    def infer_mc(self, imgs, passes=30, keep_prob=0.5, seed=5555):
+    def infer_mc(self, imgs, passes=30, keep_prob=0.5, seed=5555, return_passes=False):
         """The reference U-Net accepts `bayesian` and ignores it; no Kendall-Gal head or dropout exists in it (SURVEY
         F13).  This method DEFINES the stochastic variant: slim.dropout-style masks x*Bernoulli(keep)/keep, always on,
         after conv2_2, conv5_2 and conv6_2 (the placement pattern of models/deconvolution.py:128-154), `passes`
-        forward passes with fresh masks; returns [mean sigmoid, variance of sigmoid, float32 argmax of the mean].
-        Every pass recomputes the whole graph (layers ahead of the first dropout are not cached)."""
-        import ctypes as C
+        forward passes with fresh masks (pass t draws its counters from offset (t+1) << 40); returns [mean sigmoid,
+        variance of sigmoid, float32 argmax of the mean] (+ the per-pass sigmoids with return_passes=True).
+        The layers ahead of the first mask (conv1_1, pool1, conv1_2, conv2_1, conv2_2) are deterministic and are computed
+        ONCE per input (SURVEY a19 allows it if stated); every pass runs from the first mask on.  The mean / variance
+        accumulate in float64 on the device.  Restated in oracle/unet.py (infer_mc) with bit-identical masks."""
         imgs = np.ascontiguousarray(imgs, np.float32)
+        ent = self._mc_entry(imgs.shape, keep_prob, seed)
+        ent[2].copy_(torch.from_numpy(imgs))
+        per = [] if return_passes else None
+        mean, var, amax = self._mc_run(ent, passes, per)
+        torch.cuda.synchronize(self.device)
+        res = [mean.cpu().numpy(), var.cpu().numpy(), amax.cpu().numpy()]
+        if return_passes:
+            res.append(per)
+        return res
+
+    def _mc_entry(self, shape, keep_prob=0.5, seed=5555):
+        """(prefix plan, per-pass plan, input buffer, sigmoid buffer, argmax buffer, counter offset) for an input shape"""
+        import ctypes as C
         if self._packed_dirty:
             self._repack()
-        key = ('mc',) + tuple(imgs.shape) + (keep_prob,)
+        key = ('mc',) + tuple(shape) + (keep_prob, seed)
         ent = self._infer_cache.get(key)
         if ent is None:
-            B, H, W, Cin = imgs.shape
+            B, H, W, Cin = shape
             net = E.Net(self.store, B, self.dtype, self.device)
-            plan = E.Plan('infer_mc')
+            prefix, plan = E.Plan('infer_mc/prefix'), E.Plan('infer_mc/pass')
             x_in = torch.zeros((B, H, W, Cin), dtype=torch.float32, device=self.device)
             off = C.c_uint64(0)
-            A, sh, sw, _, _ = self._emit_forward(net, plan, x_in, H, W, self.crop_aware,
-                                                 dropout={'sites': self.MC_SITES, 'keep': keep_prob, 'seed': seed, 'offset': off})
+            A, sh, sw, _, _ = self._emit_forward(net, prefix, x_in, H, W, self.crop_aware,
+                                                 dropout={'sites': self.MC_SITES, 'keep': keep_prob, 'seed': seed, 'offset': off, 'split': plan})
             oh, ow = sh['output'], sw['output']
             sig = torch.zeros((B, oh, ow, self.n_classes), dtype=torch.float32, device=self.device)
             out = torch.zeros((B, oh, ow, 1), dtype=torch.float32, device=self.device)
             net.sigmoid_argmax(plan, A['logits'], oh, ow, self.n_classes, sig, out)
             plan.net, plan.acts = net, A
-            ent = (plan, x_in, sig, out, off)
+            ent = (prefix, plan, x_in, sig, out, off)
             self._infer_cache[key] = ent
-        plan, x_in, sig, out, off = ent
-        x_in.copy_(torch.from_numpy(imgs))
-        s1 = torch.zeros_like(sig); s2 = torch.zeros_like(sig)
+        return ent
+
+    def _mc_run(self, ent, passes, per=None):
+        """Device side of infer_mc: the input is already in ent[2]; returns (mean, variance, argmax) device tensors."""
+        prefix, plan, x_in, sig, out, off = ent
+        prefix.run(self._stream())
+        s1 = torch.zeros(sig.shape, dtype=torch.float64, device=self.device); s2 = torch.zeros_like(s1)
         for t in range(passes):
-            off.value = (t + 1) * (1 << 40)              # disjoint counter ranges per pass
+            off.value = (t + 1) << 40                    # disjoint counter ranges per pass
             plan.run(self._stream())
-            s1 += sig; s2 += sig * sig                   # moments of the outputs (post-processing)
+            d = sig.double()
+            s1 += d; s2 += d * d                         # moments of the outputs (post-processing)
+            if per is not None:
+                per.append(sig.cpu().numpy())
         mean = s1 / passes
         var = torch.clamp(s2 / passes - mean * mean, min=0)
         amax = mean.argmax(dim=-1, keepdim=True).to(torch.float32)
-        torch.cuda.synchronize(self.device)
-        return [mean.cpu().numpy(), var.cpu().numpy(), amax.cpu().numpy()]
+        return mean, var, amax

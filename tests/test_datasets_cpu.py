@@ -44,3 +44,54 @@ def test_array_dataset_cycles():
     x = np.zeros((2, 1, 8, 8, 3), np.float32); x[1] = 1
     ds = ArrayDataSet(x, np.zeros((2, 1, 8, 8, 1), np.uint8))
     assert ds.get_batch()[0].max() == 0 and ds.get_batch()[0].min() == 1 and ds.get_batch()[0].max() == 0
+
+
+def _write_folder(tmp_path, n=6, hw=(48, 56)):
+    Image = pytest.importorskip('PIL.Image')
+    fd, md = tmp_path / 'f', tmp_path / 'm'
+    fd.mkdir(); md.mkdir()
+    rng = np.random.default_rng(1)
+    for i in range(n):
+        im = np.full(hw + (3,), i * 10, np.uint8)              # the image index is recoverable from any pixel
+        im[..., 1] = rng.integers(0, 256, hw)
+        mk = np.zeros(hw, np.uint8); mk[:, : hw[1] // 2] = 255
+        Image.fromarray(im).save(fd / ('%02d.png' % i)); Image.fromarray(mk).save(md / ('%02d.png' % i))
+    return str(fd), str(md)
+
+
+def test_threaded_loader_epoch_shuffle_alignment_and_ring(tmp_path):
+    """One permutation per epoch shared by images and masks (utils/datasets.py:136-143): with min_holding 0 and a pool of one
+    batch every epoch of 6 files shows each file exactly once; batches live in the pre-allocated ring (no new buffers)."""
+    fd, md = _write_folder(tmp_path)
+    ds = ThreadedImageMaskDataSet(fd, md, batch_size=3, crop_size=32, image_ext='png', threads=1, capacity=3, min_holding=0, ratio=0.5)
+    seen, ptrs = [], set()
+    try:
+        for _ in range(8):
+            img, mask = ds.get_batch()
+            ptrs.add(img.__array_interface__['data'][0])
+            seen += [int(round(float(v) * 255 / 10)) for v in img[:, 0, 0, 0]]
+            assert set(np.unique(mask)) <= {0, 1}
+    finally:
+        ds.stop()
+    assert len(ptrs) <= ThreadedImageMaskDataSet.RING
+    for e in range(4):
+        assert sorted(seen[6 * e:6 * e + 6]) == list(range(6)), seen
+
+
+def test_threaded_loader_min_holding_shuffles_across_files(tmp_path):
+    fd, md = _write_folder(tmp_path, n=6)
+    ds = ThreadedImageMaskDataSet(fd, md, batch_size=2, crop_size=32, image_ext='png', threads=2, capacity=12, min_holding=8)
+    try:
+        img, _ = ds.get_batch()
+        assert img.shape == (2, 32, 32, 3)
+    finally:
+        ds.stop()
+
+
+def test_threaded_loader_surfaces_worker_errors(tmp_path):
+    """An image smaller than the crop (tf.random_crop would raise) must fail get_batch(), not hang it."""
+    fd, md = _write_folder(tmp_path, n=3, hw=(24, 24))
+    ds = ThreadedImageMaskDataSet(fd, md, batch_size=2, crop_size=32, image_ext='png', threads=2, capacity=4, min_holding=0)
+    with pytest.raises(RuntimeError, match='cannot take a 32x32 crop'):
+        ds.get_batch()
+    ds.stop()

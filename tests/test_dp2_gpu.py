@@ -15,19 +15,26 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, x, y, out):
+def _worker(rank, world, port, x, y, out, backend='gloo', cuts=None):
     import torch.distributed as dist
     from segmentation_amd.datasets import ArrayDataSet
     from segmentation_amd.dist import shard_batch
     from segmentation_amd.unet import UNetModel
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev = rank if backend == 'nccl' else 0                       # RCCL needs one GPU per rank; gloo shares the single test GPU
+    torch.cuda.set_device(dev)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', dev))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         lo, hi = shard_batch(x.shape[1], world, rank)
         m = UNetModel(sess=None, dataset=ArrayDataSet(x[:, lo:hi], y[:, lo:hi]), n_classes=2, input_dims=188, learning_rate=1e-3,
-                      log_dir=None, save_dir=None, load_snapshot=False, dtype='f32', use_graph=True)
+                      log_dir=None, save_dir=None, load_snapshot=False, dtype='f32', use_graph=True, dp_cuts=cuts)
         assert m.pg.world == world and m.pg.enabled
+        if cuts:
+            assert len(m.bwd_segments) == len(cuts.split(',')) + 1
         m.pg.broadcast_(m.store.p); m._repack()
         m.train_step()
         torch.cuda.synchronize()
@@ -38,11 +45,14 @@ def _worker(rank, world, port, x, y, out):
         torch.cuda.synchronize()
         if rank == 0:
             out['p'] = m.store.p.cpu().numpy()
+        rep = m.dp_exposure_report(steps=2)                      # (collective: every rank takes the instrumented steps)
+        if rank == 0:
+            out['rep'] = dict(rep)
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_equal_single_process_global_batch():
+def _run_two_ranks(backend, cuts=None):
     import torch.multiprocessing as mp
     from segmentation_amd.datasets import ArrayDataSet
     from segmentation_amd.unet import UNetModel
@@ -59,7 +69,7 @@ def test_two_ranks_equal_single_process_global_batch():
     torch.cuda.synchronize()
     pref = ref.store.p.cpu().numpy()
     mgr = mp.Manager(); out = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), x, y, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), x, y, out, backend, cuts), nprocs=2, join=True)
     # same math up to summation order (mean over 2 images vs mean of two per-image means)
     for name, l in ref.store.layers.items():
         for lo, n in ((l.w_off, l.wsize), (l.b_off, l.cout)):
@@ -69,3 +79,23 @@ def test_two_ranks_equal_single_process_global_batch():
     # (Adam then moves that weight by a full +-lr); such elements must stay a vanishing fraction
     d = np.abs(out['p'] - pref)
     assert np.median(d) < 1e-6 and (d > 1e-4).mean() < 1e-3 and d.max() < 3.5e-3
+    rep = out['rep']
+    assert rep['world'] == 2 and len(rep['buckets_mb']) == len(rep['exposed_us']) and abs(sum(rep['buckets_mb']) - 31.04) < 0.05
+    return rep
+
+
+def test_two_ranks_equal_single_process_global_batch():
+    """default bucket plan (4 buckets) over gloo on the one test GPU"""
+    rep = _run_two_ranks('gloo')
+    assert len(rep['buckets_mb']) == 4
+
+
+def test_two_ranks_six_bucket_plan():
+    rep = _run_two_ranks('gloo', 'conv6_2,upconv1,conv5_2,conv5_1,conv3_1')
+    assert len(rep['buckets_mb']) == 6 and max(rep['buckets_mb']) < 9.5
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one GPU per rank: runs only where >= 2 GPUs are visible')
+def test_two_ranks_nccl_over_xgmi():
+    """the same equality through the real backend: 2 ranks, 2 GPUs, RCCL all-reduce of the gradient buckets"""
+    _run_two_ranks('nccl')

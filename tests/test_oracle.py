@@ -36,6 +36,46 @@ def test_bilinear_golden_vectors():
         assert np.isclose(w.sum(), c * f * f)
 
 
+def test_product_upsampling_module_matches_golden_vectors():
+    """segmentation_amd/upsampling.py (what FCNModel actually uploads) against the vectors generated from the reference's
+    utils/upsampling.py by tests/golden/make_bilinear_golden.py -- bit for bit, like the oracle copy above."""
+    from segmentation_amd import upsampling as up
+    g = np.load(GOLD)
+    for f in (1, 2, 3, 4, 8, 16, 32):
+        assert up.get_kernel_size(f) == int(g['ksize_%d' % f])
+    for s in (1, 2, 3, 4, 5, 8, 16, 32, 64):
+        mine = up.upsample_filt(s)
+        assert mine.dtype == np.float64 and np.array_equal(mine, g['filt_%d' % s])
+    for key, want in zip(g['sha_keys'].tolist(), g['sha_vals'].tolist()):
+        f, c = map(int, key.split('_'))
+        w = up.bilinear_upsample_weights(f, c)
+        assert w.dtype == np.float32 and w.shape == (up.get_kernel_size(f),) * 2 + (c, c)
+        assert hashlib.sha256(np.ascontiguousarray(w).tobytes()).hexdigest() == want
+        if 'weights_' + key in g:
+            assert np.array_equal(w, g['weights_' + key])
+
+
+def test_dropout_oracle_mask_properties():
+    """Build-defined MC-dropout mask generator (a19): deterministic in (seed, offset), independent across the per-site
+    seeds and the per-pass offsets the product uses, Bernoulli(keep) marginals, pad channels excluded from the index."""
+    shape = (2, 9, 7, 40)
+    m0 = ops.dropout_mask(shape, 0.5, 5557, 1 << 40)
+    assert m0.dtype == bool and np.array_equal(m0, ops.dropout_mask(shape, 0.5, 5557, 1 << 40))
+    assert abs(m0.mean() - 0.5) < 0.03
+    # the aliasing the old generator had: site seed +3 at pass t vs site seed +0 at pass t+3 -- now uncorrelated
+    for ds, dt in ((3, 3), (5, 1), (8, 2)):
+        m1 = ops.dropout_mask(shape, 0.5, 5557 + ds, (1 + dt) << 40)
+        assert abs((m0 == m1).mean() - 0.5) < 0.03
+    assert ops.dropout_mask(shape, 1.0, 1, 0).all() and abs(ops.dropout_mask(shape, 0.25, 1, 0).mean() - 0.25) < 0.03
+    # counter layout: element (b,y,x,c) -> ((b*H+y)*W+x)*c_pad + c with c_pad = 64 here
+    a = ops.dropout_mask((1, 1, 2, 40), 0.5, 9, 0)
+    b = ops.dropout_mask((1, 1, 1, 40), 0.5, 9, 64)
+    assert np.array_equal(a[0, 0, 1], b[0, 0, 0])
+    x = np.ones(shape)
+    y = ops.dropout(x, 0.5, 5557, 1 << 40)
+    assert set(np.unique(y)) == {0.0, 2.0}
+
+
 # ---------------- known answers from the reference text ----------------
 def test_unet_shape_ladder():
     assert ounet.output_size(256) == 68
