@@ -156,7 +156,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   auto gload_s = [&](u32x4& r, unsigned voff, uint64_t sbase) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory"); };
   auto uniform64 = [&](const void* p) -> uint64_t {      // the pointer IS wave-uniform; make it so for the register allocator
     const uint64_t a = reinterpret_cast<uint64_t>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    // gfx9 hazard: a VALU write of an SGPR (v_readfirstlane) needs 5 wait states before a VMEM instruction reads that SGPR
+    // as its base.  hipcc pads nothing for inline asm (the loads below ARE inline asm), and with no pad the first load of a
+    // tile can go out with the PREVIOUS contents of the register pair: a stale base (silently the previous tile's data) or
+    // garbage (memory access fault: f32 8x16 stride-2 tile at 512x512, where the pair had just held kernel arguments).
+    // The nops are tied to the pair as in/out operands, so every use of the base is ordered behind them.
+    asm volatile("s_nop 4" : "+s"(lo), "+s"(hi));
     return ((uint64_t)hi << 32) | lo;
   };
   unsigned sp_boff[NPP], sz_boff[NZP];

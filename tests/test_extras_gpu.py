@@ -30,10 +30,11 @@ def test_dp_world1_rccl_path_equals_plain_step():
     torch.distributed.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     try:
         dp = UNetModel(dataset=ArrayDataSet(x, y), use_graph=True, **kw)
-        assert dp.pg.enabled and dp.pg.world == 1 and len(dp.bwd_segments) == 2
+        assert dp.pg.enabled and dp.pg.world == 1 and len(dp.bwd_segments) == 4 and dp.dp_cuts_used == ['conv6_1', 'conv5_2', 'conv3_1']
         bounds = [b for _, b in dp.bwd_segments]
-        assert bounds[0][0] == 0 and bounds[0][1] == bounds[1][0] and bounds[1][1] == dp.store.n
-        assert (bounds[1][1] - bounds[1][0]) * 4 < 300e3            # last (exposed) bucket: conv2_x + conv1_x only
+        assert bounds[0][0] == 0 and all(bounds[i][1] == bounds[i + 1][0] for i in range(3)) and bounds[3][1] == dp.store.n
+        assert all(8e6 < (hi - lo) * 4 < 12e6 for lo, hi in bounds[:3])   # three medium messages in the middle of backward
+        assert (bounds[3][1] - bounds[3][0]) * 4 < 300e3            # last (exposed) bucket: conv2_x + conv1_x only
         for _ in range(4):
             dp.train_step()
         torch.cuda.synchronize()
@@ -130,3 +131,96 @@ def test_zero_copy_device_batches_equal_copied_ones(monkeypatch):
     ref = out[('0', False)]
     for k, v in out.items():
         assert torch.equal(v[0], ref[0]) and v[1] == ref[1], k
+
+
+class _Recorder(object):
+    """dataset proxy that keeps a copy of every batch it hands out (in hand-out order)"""
+
+    def __init__(self, ds):
+        self.ds, self.log = ds, []
+        self.batch_size, self.has_masks, self.use_feed = ds.batch_size, True, False
+
+    def set_tf_sess(self, sess):
+        pass
+
+    def start(self):
+        self.ds.start()
+
+    def stop(self):
+        self.ds.stop()
+
+    def get_batch(self):
+        img, msk = self.ds.get_batch()
+        self.log.append((np.array(img), np.array(msk)))
+        return img, msk
+
+
+class _PinnedRecorder(_Recorder):
+    """... and passes the loader's pinned ring slots through (DevicePrefetcher then copies H2D straight out of them)"""
+
+    def get_pinned_batch(self):
+        img, msk = self.ds.get_pinned_batch()
+        self.log.append((img.clone().numpy(), msk.clone().numpy()))
+        return img, msk
+
+
+def _png_folder(tmp_path, n=6, hw=(200, 220)):
+    from PIL import Image
+    fd, md = tmp_path / 'feature', tmp_path / 'label'
+    fd.mkdir(); md.mkdir()
+    rng = np.random.default_rng(12)
+    for i in range(n):
+        im = rng.integers(0, 256, hw + (3,)).astype(np.uint8)
+        mk = np.zeros(hw, np.uint8); mk[20 + 5 * i:150, 30:120 + 10 * i] = 255; mk[0, :5] = 128
+        Image.fromarray(im).save(fd / ('%02d.png' % i)); Image.fromarray(mk).save(md / ('%02d.png' % i))
+    return str(fd), str(md)
+
+
+def test_image_folder_loader_prefetcher_train_step(tmp_path):
+    """N1 end to end: PNG folder -> ThreadedImageMaskDataSet (decode threads, shuffle pool, pinned ring) -> DevicePrefetcher
+    (H2D on a copy stream straight out of the ring) -> train_step (batches consumed in place).  The trajectory must equal
+    feeding the very same decoded batches directly (utils/datasets.py:136-190 semantics are checked on the CPU side)."""
+    from segmentation_amd.datasets import DevicePrefetcher, ThreadedImageMaskDataSet
+    fd, md = _png_folder(tmp_path)
+    kw = dict(sess=None, n_classes=2, input_dims=188, learning_rate=1e-3, log_dir=None, save_dir=None, load_snapshot=False, dtype='bf16', seed=9)
+    for wrap in (True, False):               # through the prefetcher, and through BaseModel's own host path
+        loader = ThreadedImageMaskDataSet(fd, md, batch_size=2, crop_size=188, image_ext='png', threads=3, capacity=8, min_holding=2)
+        rec = _PinnedRecorder(loader) if wrap else _Recorder(loader)     # (BaseModel's own host path uses get_batch())
+        ds = DevicePrefetcher(rec, depth=3) if wrap else rec
+        try:
+            b = UNetModel(dataset=ds, use_graph=True, **kw)
+            steps = 6
+            for _ in range(steps):
+                b.train_step()
+            torch.cuda.synchronize()
+        finally:
+            ds.stop()
+            loader.stop()
+        assert len(rec.log) >= steps
+        for img, msk in rec.log[:steps]:
+            assert img.dtype == np.float32 and 0 <= img.min() and img.max() <= 1 and set(np.unique(msk)) <= {0, 1} and msk.any()
+        x = np.stack([r[0] for r in rec.log[:steps]]); y = np.stack([r[1] for r in rec.log[:steps]])
+        a = UNetModel(dataset=ArrayDataSet(x, y), use_graph=True, **kw)
+        for _ in range(steps):
+            a.train_step()
+        torch.cuda.synchronize()
+        assert torch.equal(a.store.p, b.store.p), wrap
+        assert a.last_loss() == b.last_loss()
+
+
+@pytest.mark.parametrize('folder', [False, True])
+def test_example_unet_script_runs(tmp_path, folder):
+    """BASELINE config C1 (the plumbing config, 188x188 because the all-VALID graph is infeasible at 128): the authored
+    examples/example_unet.py end to end -- train loop, test(), snapshot(), infer() -- on the synthetic set and on a folder."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'examples', 'example_unet.py'), '--outer', '1', '--inner', '4', '--test-iter', '2', '--dtype', 'bf16']
+    if folder:
+        fd, md = _png_folder(tmp_path)
+        cmd += ['--feat-dir', fd, '--mask-dir', md, '--image-ext', 'png']
+    r = subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'Done' in r.stdout and 'TEST LOSS' in r.stdout and 'infer: (2, 4, 4, 2) (2, 4, 4, 1)' in r.stdout
+    snaps = os.listdir(tmp_path / 'examples' / 'unet' / 'snapshots')
+    assert any(f.endswith('-4.npz') for f in snaps), snaps

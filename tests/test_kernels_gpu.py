@@ -154,7 +154,9 @@ def test_conv_with_fused_maxpool(cin, cout, H, W, padding):
 
 
 @pytest.mark.parametrize('dtype', DT)
-@pytest.mark.parametrize('case', [(64, 32, 8, 8, 2), (32, 32, 36, 36, 1), (128, 64, 5, 7, 2), (24, 8, 6, 6, 1)])
+@pytest.mark.parametrize('case', [(64, 32, 8, 8, 2), (32, 32, 36, 36, 1), (128, 64, 5, 7, 2), (24, 8, 6, 6, 1),
+                                  # 44 / 20x44 maps pick the 8x16 stride-2 filter-gradient tile (upconv2 of the 512x512 U-Net): interior AND edge tiles
+                                  (256, 128, 44, 44, 2), (64, 32, 20, 44, 3)])
 def test_upconv_fwd_bwd(dtype, case):
     cin, cout, H, W, B = case
     rng = np.random.default_rng(cin * 1000 + H)
