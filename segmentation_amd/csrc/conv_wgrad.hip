@@ -5,8 +5,8 @@
 //
 // Both MFMA operands need K (= pixel) contiguous per lane while NHWC keeps channels contiguous, so the
 // bf16 path reads its fragments with ds_read_b64_tr_b16 (4 pixels x 16 channels, delivered
-// column-major); the f32 path reads single elements.  A workgroup owns one 32-channel chunk of X and
-// BN channels of dZ for ALL taps, keeps the KH*KW*32*BN partial sums in registers while it walks its
+// column-major); the f32 path reads single elements.  A workgroup owns one CIT-channel chunk of X (32 or 64) and
+// BN channels of dZ for ALL taps, keeps the KH*KW*CIT*BN partial sums in registers while it walks its
 // share of the pixel tiles, and flushes them ONCE, with plain coalesced stores, into its own slab of a
 // workspace; a second small kernel sums the `ksplit` slabs in a fixed order into the TF-layout gradient
 // (deterministic, no atomics: 768 workgroups hammering one 36 KB filter with f32 atomics measured 10-30x
@@ -69,17 +69,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   constexpr int NTF = KH * KW;                // taps of the filter
   constexpr int ES = sizeof(T);
   constexpr int BN = 16 * FCO * WCO;
+  constexpr int CIT = 16 * FCI * WCI;         // X channels per workgroup: 32, or 64 (bf16 register-reuse layouts below)
+  // Wave layout matters more than the tile: every tap needs its own (shifted) X fragment, the dZ fragment is shared by all
+  // taps.  A wave that owns FCI x FCO fragments reads 9*FCI + FCO fragments from LDS per 9*FCI*FCO MFMAs: the 32x32 tile
+  // with one fragment pair per wave (r01 default) reads 1.1 fragments per MFMA = 284 B/clk per CU, MORE than the LDS delivers
+  // (256 B/clk) -- it was LDS-read-bound at 0.06-0.10 of the MFMA peak; 16 ci x 64 co per wave (FCI 1, FCO 4) reads 0.36.
   // LDS row strides.  bf16: +32 B of padding and the pixel<->k permutation below make every ds_read_b64_tr_b16
   // conflict-free (each 32-lane half then reads 8 consecutive pixel rows whose 32-byte chunks fall in 8 distinct
   // bank groups: 96 B and BN*2+32 B strides are 3 resp. odd multiples of 32 B); f32 (parity mode): +16 B.
-  constexpr int RSP = 32 * ES + (ES == 2 ? 32 : 16);   // patch row stride (bytes)
+  constexpr int RSP = CIT * ES + (ES == 2 ? 32 : 16);  // patch row stride (bytes)
   constexpr int RSZ = BN * ES + (ES == 2 ? 32 : 16);   // dZ tile row stride
-  constexpr int PPIECES = 32 * ES / 16, ZPIECES = BN * ES / 16, EPP = 16 / ES;
+  constexpr int PPIECES = CIT * ES / 16, ZPIECES = BN * ES / 16, EPP = 16 / ES;
   constexpr int PATCH_BYTES = ((NPIX * RSP + 15) / 16) * 16;
   constexpr int NPP = (NPIX * PPIECES + 255) / 256;
   constexpr int NZP = (BM * ZPIECES + 255) / 256;
   constexpr int KS = BM / 32;
-  static_assert(WCI * WCO == 4 && 16 * FCI * WCI == 32, "wave layout");
+  static_assert(WCI * WCO == 4 && (CIT == 32 || CIT == 64), "wave layout");
   static_assert(BM % 32 == 0, "tile pixels");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   const int u0 = RS ? blockIdx.z : 0;
   const bool first = chunk < P.nchunks0;
   const seg_view& sv = first ? d.src0 : d.src1;
-  const int cbase = first ? chunk * 32 : (chunk - P.nchunks0) * 32;   // padded channel base inside its source
+  const int cbase = first ? chunk * CIT : (chunk - P.nchunks0) * CIT; // padded channel base inside its source
   const T* srcp = reinterpret_cast<const T*>(sv.ptr);
   const T* dzp = reinterpret_cast<const T*>(d.dz.ptr);
   const int n0 = nb * BN;
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
 
   // ---- flush: D[row = ci][col = co]; lane: co = lr, ci = 4G + r ----
   // ksplit == 1: straight into the TF-layout gradient; else into this split's slab (plain stores).
-  const int kbase = chunk * 32;                                    // padded concat channel base
+  const int kbase = chunk * CIT;                                   // padded concat channel base
   const int k_log_n = d.src0_clog + d.src1_clog;
   float* slab = d.ws + (int64_t)blockIdx.y * P.slab;
 #pragma unroll
@@ -545,12 +550,15 @@ thread_local RedJob* g_job_out = nullptr;      // job-capture mode: describe the
 
 template <typename T, int TH, int TW, int KH, int KW, int S, int WCI, int WCO, int FCI, int FCO>
 int launch_cfg(const WgK& P0, hipStream_t st) {
-  constexpr int BN = 16 * FCO * WCO, ES = sizeof(T);
+  constexpr int BN = 16 * FCO * WCO, ES = sizeof(T), CIT = 16 * FCI * WCI;
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
   constexpr int PADB = ES == 2 ? 32 : 16;
-  constexpr int PATCH_BYTES = ((PH * PW * (32 * ES + PADB) + 15) / 16) * 16;
+  constexpr int PATCH_BYTES = ((PH * PW * (CIT * ES + PADB) + 15) / 16) * 16;
   constexpr int LDS = PATCH_BYTES + TH * TW * (BN * ES + PADB);
   WgK P = P0;
+  if (P.d.src0.c % CIT || (P.d.src1.c && P.d.src1.c % CIT)) { seg_set_error("wgrad: source channels %d,%d not multiples of the %d-channel tile", P.d.src0.c, P.d.src1.c, CIT); return SEG_ERR_ARG; }
+  P.nchunks0 = P.d.src0.c / CIT;
+  P.nchunks = P.nchunks0 + P.d.src1.c / CIT;
   P.tiles_x = cdiv(P.d.Wo, TW); P.tiles_y = cdiv(P.d.Ho, TH);
   P.ntiles = P.d.B * P.tiles_x * P.tiles_y;
   P.nblk = cdiv(P.d.dz.c, BN);
@@ -575,7 +583,7 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
     occ = nb > 4 ? 4 : nb;
   }
   // small filters (<= 64 KB of partial sums per workgroup) are cheap to split: fill every resident slot of the chip
-  const int64_t wg_tile_bytes = (int64_t)KH * KW * 32 * BN * 4;
+  const int64_t wg_tile_bytes = (int64_t)KH * KW * CIT * BN * 4;
   int ks = P.d.ksplit > 0 ? P.d.ksplit : cdiv(target_wgs, wg);
   if (P.d.ksplit <= 0 && wg_tile_bytes <= 64 * 1024 && P.ntiles / ks > 8) {
     // long serial tile walks (first layer: 31 tiles per workgroup): use every resident slot, keep >= 8 tiles each
@@ -593,7 +601,7 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
   if (ks < 1) ks = 1;
   P.ksplit = ks;
   P.direct = ks == 1;
-  P.k_pad = P.nchunks * 32; P.n_pad = P.d.dz.c;
+  P.k_pad = P.nchunks * CIT; P.n_pad = P.d.dz.c;
   const int64_t bias_len = P.k_pad > P.n_pad ? P.k_pad : P.n_pad;
   P.slab = (int64_t)KH * KW * P.k_pad * P.n_pad + bias_len;
   if (g_wname_out) {
@@ -633,13 +641,39 @@ int launch_k(const WgK& P, hipStream_t st) {
   const seg_wgrad_desc& d = P.d;
   int cfg = d.cfg;
   const bool small = (long)cdiv(d.Ho, 8) * 8 * cdiv(d.Wo, 8) * 8 < (long)cdiv(d.Ho, 8) * 8 * cdiv(d.Wo, 16) * 16;
-  if (cfg == 0) {
-    const int bn = (d.dz.c % 128 == 0) ? 128 : (d.dz.c % 64 == 0 ? 64 : 32);
-    static const int bnmax = getenv("SEG_WGRAD_BN") ? atoi(getenv("SEG_WGRAD_BN")) : 32;   // 32-channel tiles: fewest registers -> most co-residency with the dgrads (measured best)
-    const int bne = bn > bnmax ? bnmax : bn;
-    cfg = (bne == 128 ? 1 : bne == 64 ? 2 : 3) + (small ? 3 : 0);
+  if (cfg == 0 && sizeof(T) == 2) {
+    // bf16: layout AND pixel tile by a cost model calibrated on stand-alone runs of every U-Net layer at 256 and 512
+    // (tools/wgrad_micro.py, profiles/r02_wgrad_micro_*.txt).  Layouts: A = 64 ci x 64 co (16 ci x 64 co per wave: 0.36 LDS
+    // fragment reads per MFMA, ~750 TF/s when the chip is full), B = 32 ci x 64 co (0.61, ~620), C = 32 x 32 (1.1: LDS-read
+    // bound, ~480; ~540 with 256-pixel tiles).  Bigger accumulators mean bigger partial-sum slabs per K split (A: 147 KB per
+    // workgroup), so A wins on the big maps (512 x 512: 540-717 TF/s for kernel + reduction) and B / C on the small ones.
+    //   cost [us] = 8 + rounds * ceil(tiles / ksplit) * t_tile + (ksplit > 1 ? 3 + ksplit * slab_bytes / 4.5 TB/s : 0)
+    static const int layout = getenv("SEG_WGRAD_LAYOUT") ? atoi(getenv("SEG_WGRAD_LAYOUT")) : 2;   // 0 = r01 choice (C only), 1 = B and C
+    const bool ci64 = d.src0.c % 64 == 0 && (!d.src1.ptr || d.src1.c % 64 == 0), co64 = d.dz.c % 64 == 0;
+    struct Cand { int cfg, th, tw, cit, bn, occ; double rate; };
+    static const Cand cands[] = {{11, 8, 16, 64, 64, 1, 750.}, {14, 8, 8, 64, 64, 1, 750.}, {12, 8, 16, 32, 64, 2, 620.}, {15, 8, 8, 32, 64, 2, 620.},
+                                 {3, 8, 16, 32, 32, 2, 480.}, {6, 8, 8, 32, 32, 3, 480.}, {9, 16, 16, 32, 32, 1, 540.}};
+    double best = 1e30;
+    const int kin = d.src0.c + (d.src1.ptr ? d.src1.c : 0);
+    for (const Cand& c : cands) {
+      if (c.cit == 64 && (!ci64 || !co64 || S != 1 || layout < 2)) continue;
+      if (c.bn == 64 && c.cit == 32 && (!co64 || layout < 1)) continue;
+      if (c.cfg == 9 && S != 1) continue;
+      const long ntiles = (long)d.B * cdiv(d.Ho, c.th) * cdiv(d.Wo, c.tw);
+      const int base = (kin / c.cit) * (d.dz.c / c.bn);
+      const bool rs = KH > 1 && d.bias_mode != 2 && ntiles <= 64 && base < 192;
+      const int wg = base * (rs ? KH : 1);
+      long ks = cdiv(256, wg); if (ks > ntiles) ks = ntiles; if (ks < 1) ks = 1;
+      const double t_tile = 2.0 * c.th * c.tw * KH * KW * c.cit * c.bn / (rs ? KH : 1) / (c.rate * 1e6 / 256.0);   // us on one CU
+      const double rounds = (double)cdiv((int)(wg * ks), 256 * c.occ);
+      const double slab = (double)KH * KW * c.cit * c.bn * 4.0 * base;           // bytes per K split (all output tiles)
+      const double cost = 8.0 + rounds * (double)((ntiles + ks - 1) / ks) * t_tile + (ks > 1 ? 3.0 + ks * slab / 4.5e6 : 0.0);
+      if (cost < best) { best = cost; cfg = c.cfg; }
+    }
+  } else if (cfg == 0) {
+    cfg = small ? 6 : 3;                                                                 // f32 (parity mode): 32 ci x 32 co
     // large maps: 256-pixel tiles halve the barriers / staging rounds per MFMA (measured +5-8 % at >= 59x59)
-    if (!small && d.Ho >= 48 && d.Wo >= 48 && (cfg == 2 || cfg == 3)) cfg += 6;
+    if (!small && d.Ho >= 48 && d.Wo >= 48 && S == 1) cfg += 6;
   }
   if (S != 1 && (cfg == 8 || cfg == 9)) { seg_set_error("wgrad: 256-pixel tiles are stride-1 only (cfg %d)", cfg); return SEG_ERR_UNSUPPORTED; }
   switch (cfg) {
@@ -651,8 +685,18 @@ int launch_k(const WgK& P, hipStream_t st) {
     case 6: return launch_cfg<T, 8, 8, KH, KW, S, 2, 2, 1, 1>(P, st);
     case 8: return launch_cfg<T, 16, 16, KH, KW, S, 1, 4, 2, 1>(P, st);  // 256 px, 32 ci x 64 co
     case 9: return launch_cfg<T, 16, 16, KH, KW, S, 2, 2, 1, 1>(P, st);  // 256 px, 32 ci x 32 co
-    default: seg_set_error("wgrad: unknown cfg %d", cfg); return SEG_ERR_ARG;
+    default: break;
   }
+  if constexpr (sizeof(T) == 2) {
+    switch (cfg) {      // bf16 register-reuse layouts: a wave owns 16 ci x (16 FCO) co for all taps
+      case 11: if constexpr (S == 1) return launch_cfg<T, 8, 16, KH, KW, S, 4, 1, 1, 4>(P, st); else break;  // 128 px, 64 ci x 64 co
+      case 12: return launch_cfg<T, 8, 16, KH, KW, S, 2, 2, 1, 2>(P, st);  // 128 px, 32 ci x 64 co
+      case 14: if constexpr (S == 1) return launch_cfg<T, 8, 8, KH, KW, S, 4, 1, 1, 4>(P, st); else break;   //  64 px, 64 ci x 64 co
+      case 15: return launch_cfg<T, 8, 8, KH, KW, S, 2, 2, 1, 2>(P, st);   //  64 px, 32 ci x 64 co
+      default: break;
+    }
+  }
+  seg_set_error("wgrad: unknown cfg %d", cfg); return SEG_ERR_ARG;
 }
 
 template <typename T>
@@ -706,8 +750,7 @@ extern "C" int seg_conv2d_wgrad(const seg_wgrad_desc* dp, void* stream) {
   WgK P;
   P.d = d;
   if (!d.src1.ptr) { P.d.src1 = d.src0; P.d.src1.c = 0; P.d.src1_clog = 0; }
-  P.nchunks0 = d.src0.c / 32;
-  P.nchunks = P.nchunks0 + (d.src1.ptr ? d.src1.c / 32 : 0);
+  P.nchunks0 = P.nchunks = 0;                     // set by launch_cfg from its channel tile
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d.dtype == SEG_F32) return launch_t<float>(P, st);
   if (d.dtype == SEG_BF16) return launch_t<bf16_t>(P, st);

@@ -128,6 +128,58 @@ def test_conv_fwd_bwd(dtype, case):
         c0 += c
 
 
+@pytest.mark.parametrize('case', [
+    # k, padding, segs, cout, H, W, B, wcfg            filter-gradient layouts (bf16): 11/14 = 64 ci x 64 co, 12/15 = 32 ci x 64 co
+    (3, 'VALID', [64], 64, 37, 35, 3, 11),
+    (3, 'VALID', [64], 64, 37, 35, 3, 14),
+    (3, 'SAME', [128], 64, 20, 44, 2, 11),              # two X chunks, edge tiles on both axes
+    (3, 'VALID', [64, 64], 128, 26, 26, 2, 11),         # channel-concat input, two dZ blocks
+    (3, 'VALID', [64], 64, 61, 59, 4, 11),              # long tile walk + K split + slab reduction
+    (3, 'VALID', [256], 256, 10, 10, 2, 14),            # deep layer: filter rows split over blockIdx.z (no K split)
+    (3, 'VALID', [32], 64, 37, 35, 3, 12),
+    (3, 'VALID', [96], 64, 19, 23, 2, 15),
+    (3, 'SAME', [32, 32], 64, 33, 17, 2, 12),
+    (1, 'SAME', [128], 192, 16, 16, 2, 11),             # 1x1 (FCN conv6/conv7)
+    (1, 'SAME', [64], 64, 9, 9, 1, 14),
+    (3, 'VALID', [64], 64, 37, 35, 3, 0),               # automatic choice = the 64 x 64 layout
+    (3, 'VALID', [48, 16], 40, 21, 19, 2, 0),           # unpadded channel counts -> 64 / 32 padded: automatic choice
+])
+def test_wgrad_layouts(case):
+    k, padding, segs, cout, H, W, B, wcfg = case
+    dtype = L.SEG_BF16
+    rng = np.random.default_rng(k * 131 + sum(segs) * 7 + cout * 3 + H + W + wcfg)
+    layer = E.Layer('c', 'conv', k, segs, cout, padding, True)
+    p = {'c': _rand_params(layer, rng, dtype)}
+    store = U.make_store([layer], dtype, p)
+    net = E.Net(store, B, dtype, U.dev())
+    srcs, xs = [], []
+    for i, c in enumerate(segs):
+        a = net.act(H + 2, W + 3, c)
+        full = U.round_dtype(rng.standard_normal((B, a.H, a.W, c)), dtype)
+        U.fill_act(a, full)
+        srcs.append((a, 1, 2 - i)); xs.append(full[:, 1:1 + H, 2 - i:2 - i + W, :])
+    x = np.concatenate(xs, -1)
+    Ho, Wo = H + 2 * layer.pad - k + 1, W + 2 * layer.pad - k + 1
+    dzv = U.round_dtype(rng.standard_normal((B, Ho, Wo, cout)) * 0.5, dtype)
+    dz = net.act(Ho, Wo, cout); U.fill_act(dz, dzv)
+    store.g.fill_(float('nan'))
+    bplan = E.Plan('b')
+    net.conv_bwd(bplan, layer, srcs, H, W, dz, [None] * len(segs), wcfg=wcfg)
+    net.flush_reduce(bplan)
+    name = bplan.kernel_name(0)
+    if wcfg in (11, 14) or (wcfg == 0 and all(c_ % 64 == 0 for c_ in layer.cin_p) and layer.cout_p % 64 == 0):
+        assert ',4,1,1,4,' in name, name
+    bplan.run(U.stream()); U.sync()
+    dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (k, k), padding, 1)
+    g = store.get_grads()['c']
+    assert np.isfinite(g['weights']).all() and np.isfinite(g['biases']).all()
+    assert U.rel_err(g['weights'], dw_ref) < 1e-2, 'wgrad ' + name
+    assert U.rel_err(g['biases'], db_ref) < 1e-2, 'bias grad ' + name
+    # same bits on a second run (fixed reduction order)
+    g1 = store.g.clone(); store.g.fill_(0); bplan.run(U.stream()); U.sync()
+    assert torch.equal(g1, store.g)
+
+
 @pytest.mark.parametrize('cin,cout,H,W,padding', [(64, 64, 23, 37, 'VALID'), (32, 32, 34, 34, 'SAME'), (128, 96, 19, 50, 'VALID')])
 def test_conv_with_fused_maxpool(cin, cout, H, W, padding):
     """seg_conv_desc.pool: same activation bits as the plain launch, pooled map == 2x2 max-pool of those bits."""
