@@ -253,6 +253,71 @@ int seg_relu_grad(const seg_view* dy, const seg_view* y_act, const seg_view* dz,
 int seg_dropout(const seg_view* x, const seg_view* y, int32_t B, int32_t H, int32_t W, int32_t C,
                 float keep, uint64_t seed, uint64_t offset, int32_t dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * DeconvModel (models/deconvolution.py:101-178): the ops its graph needs beyond the U-Net / FCN set.
+ * ------------------------------------------------------------------------------------------------------------------- */
+
+/* Direct correlation for the layers the MFMA tiles do not cover (5x5 stride-2 conv, 5x5 stride-2 transposed conv:
+ * models/deconvolution.py:109-116,147-157).  One descriptor, three launches:
+ *   seg_dconv_fwd       y[b,oy,ox,n] = act( bias[n] + sum_{u,v,k} x[b, oy*s+u-pad_t, ox*s+v-pad_l, k] * W(u,v,k,n) )
+ *   seg_dconv_bwd_data  x[b,iy,ix,k] = act( bias[k] + sum_{u,v,n : (iy+pad_t-u) % s == 0, (ix+pad_l-v) % s == 0}
+ *                                                      y[b, (iy+pad_t-u)/s, (ix+pad_l-v)/s, n] * W(u,v,k,n) )
+ *   seg_dconv_wgrad     dW(u,v,k,n) = sum_{b,oy,ox} x[b, oy*s+u-pad_t, ox*s+v-pad_l, k] * y[b,oy,ox,n]   (f32, overwritten;
+ *                       fixed summation order); db_mode 1: db[n] = sum y, 2: db[k] = sum x over its full extent
+ * with W(u,v,k,n) = w[u*w_su + v*w_sv + k*w_sk + n] read from the fp32 master copy (n contiguous).
+ * slim.convolution2d (HWIO, k = Cin, n = Cout): forward = _fwd, input gradient = _bwd_data, filter gradient = _wgrad.
+ * slim.convolution2d_transpose (filter [kh,kw,Cout,Cin]; x := the LARGE output map, y := the small input map, k = Cout,
+ * n = Cin): forward = _bwd_data (with bias / ReLU), input gradient = _fwd, filter gradient = _wgrad (db_mode 2).
+ * `mask` (nullable): ReLU-grad mask on the written tensor (out = 0 where mask <= 0), same extent as the written tensor. */
+typedef struct seg_dconv_desc {
+  seg_view x; int32_t xc;            /* xc / yc: logical channels (loops stop there; pad channels are written as 0) */
+  seg_view y; int32_t yc;
+  int32_t B, Hx, Wx, Hy, Wy;
+  int32_t KH, KW, stride, pad_t, pad_l;
+  const float* w; int64_t w_su, w_sv, w_sk;
+  const float* bias; int32_t bias_n;
+  int32_t relu;
+  seg_view mask;
+  int32_t dtype;
+} seg_dconv_desc;
+int seg_dconv_fwd(const seg_dconv_desc* d, void* stream);
+int seg_dconv_bwd_data(const seg_dconv_desc* d, void* stream);
+int seg_dconv_wgrad(const seg_dconv_desc* d, float* dw, float* db, int32_t db_mode, void* stream);
+
+/* slim.max_pool2d(x, k, k) (kernel k, stride k, VALID; models/deconvolution.py:118,131,140: k = 2, 3, 3) on a tensor that is
+ * NOT a ReLU output (it follows a batch norm): no mask fusion.  bwd routes to the first maximum in row-major window order. */
+int seg_maxpool_k_fwd(const seg_view* src, const seg_view* dst, int32_t k, int32_t B, int32_t Ho, int32_t Wo, int32_t C,
+                      int32_t dtype, void* stream);
+int seg_maxpool_k_bwd(const seg_view* src, const seg_view* dpool, const seg_view* dsrc, int32_t k, int32_t B, int32_t H, int32_t W,
+                      int32_t C, int32_t dtype, void* stream);
+
+/* slim.batch_norm with its defaults (decay 0.999, center=True -> beta, scale=False -> no gamma, epsilon 0.001) behind a
+ * ReLU'd convolution: models/deconvolution.py:116,124,138,146,150,155,158,165; updates ride on UPDATE_OPS
+ * (models/basemodel.py:364-365).  a = the ReLU output [B,H,W,C]; statistics over B*H*W per channel (population variance).
+ *   seg_bn_fwd  training != 0: batch mean / variance -> stats[0:C] = mean, stats[C:2C] = 1/sqrt(var + eps); when moving != NULL
+ *               also moving[0:C] = decay*moving + (1-decay)*mean, moving[C:2C] likewise with var.
+ *               training == 0: mean / variance come from moving[] (the test() path).
+ *               y = (a - mean) * rstd + beta.   ws: >= seg_bn_ws_bytes(C) bytes of scratch (partial sums, fixed order).
+ *   seg_bn_relu_bwd  (training statistics)  dbeta[c] = sum dy;  da = rstd * (dy - mean(dy) - xhat * mean(dy * xhat));
+ *               dz = da where a > 0 else 0  (the ReLU-grad of the producing convolution, fused: dz feeds its wgrad / dgrad). */
+int64_t seg_bn_ws_bytes(int32_t C);
+int seg_bn_fwd(const seg_view* a, const seg_view* y, const float* beta, float* moving, float* stats, int32_t training, float decay,
+               float eps, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype, void* stream);
+int seg_bn_relu_bwd(const seg_view* a, const seg_view* dy, const seg_view* dz, const float* stats, float* dbeta, int32_t B,
+                    int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype, void* stream);
+
+/* tf.image.resize_bilinear(x, [Hd, Wd]) with align_corners=False (models/deconvolution.py:160): source coordinate =
+ * dst * (Hs/Hd), lerp of the 2x2 neighbours (upper index clamped).  bwd is the adjoint, in gather form (fixed order). */
+int seg_resize_bilinear_fwd(const seg_view* src, int32_t Hs, int32_t Ws, const seg_view* dst, int32_t Hd, int32_t Wd, int32_t B,
+                            int32_t C, int32_t dtype, void* stream);
+int seg_resize_bilinear_bwd(const seg_view* ddst, int32_t Hd, int32_t Wd, const seg_view* dsrc, int32_t Hs, int32_t Ws, int32_t B,
+                            int32_t C, int32_t dtype, void* stream);
+
+/* seg_dropout whose counter offset is offset + (*step_dev << 40), read on the device: a training step captured in a hipGraph
+ * draws a fresh mask at every replay; the backward launch (dy -> dz with the same arguments) regenerates the forward mask. */
+int seg_dropout_step(const seg_view* x, const seg_view* y, int32_t B, int32_t H, int32_t W, int32_t C, float keep, uint64_t seed,
+                     uint64_t offset, const int64_t* step_dev, int32_t dtype, void* stream);
+
 /* float32 NHWC -> dtype NHWC with channel padding (feeding placeholder inputs). */
 int seg_cast_pad(const float* x, int64_t npix, int32_t c, const seg_view* dst_dense, int32_t dtype, void* stream);
 

@@ -133,6 +133,88 @@ def max_pool2x2_bwd(dy, idx, in_hw):
     return dx
 
 
+def max_pool_k(x, k):
+    """slim.max_pool2d(x, k, k): kernel k, stride k, VALID (models/deconvolution.py:118,131,140).  Returns (y, idx) with idx the
+    FIRST maximum in row-major window order (MaxPoolGrad routing)."""
+    B, H, W, C = x.shape
+    Ho, Wo = H // k, W // k
+    xs = x[:, :Ho * k, :Wo * k, :].reshape(B, Ho, k, Wo, k, C).transpose(0, 1, 3, 5, 2, 4).reshape(B, Ho, Wo, C, k * k)
+    idx = np.argmax(xs, axis=-1)
+    y = np.take_along_axis(xs, idx[..., None], axis=-1)[..., 0]
+    return y, idx.astype(np.uint8)
+
+
+def max_pool_k_bwd(dy, idx, in_hw, k):
+    B, Ho, Wo, C = dy.shape
+    H, W = in_hw
+    g = np.zeros((B, Ho, Wo, C, k * k), dy.dtype)
+    np.put_along_axis(g, idx[..., None].astype(np.int64), dy[..., None], axis=-1)
+    g = g.reshape(B, Ho, Wo, C, k, k).transpose(0, 1, 4, 2, 5, 3).reshape(B, Ho * k, Wo * k, C)
+    dx = np.zeros((B, H, W, C), dy.dtype)
+    dx[:, :Ho * k, :Wo * k, :] = g
+    return dx
+
+
+# ----------------------------------------------------------------------------
+# slim.batch_norm with its defaults: decay 0.999, center=True (beta), scale=False (no gamma), epsilon 0.001,
+# statistics over (B,H,W), population variance (tf.nn.moments); moving averages updated through UPDATE_OPS
+# (models/deconvolution.py:116-165, models/basemodel.py:364-365)
+# ----------------------------------------------------------------------------
+def batch_norm(x, beta, moving_mean=None, moving_var=None, training=True, decay=0.999, eps=1e-3, dt=np.float64):
+    """Returns (y, cache, new_moving_mean, new_moving_var)."""
+    x = np.asarray(x, dt)
+    if training:
+        mean = x.mean((0, 1, 2)); var = x.var((0, 1, 2))
+        nm = None if moving_mean is None else decay * np.asarray(moving_mean, dt) + (1 - decay) * mean
+        nv = None if moving_var is None else decay * np.asarray(moving_var, dt) + (1 - decay) * var
+    else:
+        mean, var = np.asarray(moving_mean, dt), np.asarray(moving_var, dt)
+        nm, nv = moving_mean, moving_var
+    rstd = 1.0 / np.sqrt(var + eps)
+    xhat = (x - mean) * rstd
+    return xhat + np.asarray(beta, dt), (xhat, rstd), nm, nv
+
+
+def batch_norm_bwd(dy, cache):
+    """Training-mode gradient wrt the input and beta (no gamma)."""
+    xhat, rstd = cache
+    dbeta = dy.sum((0, 1, 2))
+    dx = rstd * (dy - dy.mean((0, 1, 2)) - xhat * (dy * xhat).mean((0, 1, 2)))
+    return dx, dbeta
+
+
+# ----------------------------------------------------------------------------
+# tf.image.resize_bilinear(x, [Hd, Wd]) with align_corners=False (models/deconvolution.py:160): in = out * (Hs / Hd) (the scale
+# and the source coordinate are float32 in TF's kernel), lower = floor(in), upper = min(lower + 1, Hs - 1), lerp = in - lower
+# ----------------------------------------------------------------------------
+def _resize_axis(n_in, n_out):
+    scale = np.float32(n_in) / np.float32(n_out)
+    f = (np.arange(n_out, dtype=np.float32) * scale).astype(np.float32)
+    lo = np.minimum(np.floor(f).astype(np.int64), n_in - 1)
+    hi = np.minimum(lo + 1, n_in - 1)
+    return lo, hi, (f - np.floor(f)).astype(np.float64)
+
+
+def resize_bilinear(x, out_hw, dt=np.float64):
+    x = np.asarray(x, dt)
+    B, H, W, C = x.shape
+    y0, y1, ly = _resize_axis(H, out_hw[0]); x0, x1, lx = _resize_axis(W, out_hw[1])
+    ly = ly[None, :, None, None]; lx = lx[None, None, :, None]
+    top = x[:, y0][:, :, x0] + (x[:, y0][:, :, x1] - x[:, y0][:, :, x0]) * lx
+    bot = x[:, y1][:, :, x0] + (x[:, y1][:, :, x1] - x[:, y1][:, :, x0]) * lx
+    return top + (bot - top) * ly
+
+
+def resize_bilinear_bwd(dy, in_hw, dt=np.float64):
+    dy = np.asarray(dy, dt)
+    B, Hd, Wd, C = dy.shape
+    H, W = in_hw
+    y0, y1, ly = _resize_axis(H, Hd); x0, x1, lx = _resize_axis(W, Wd)
+    My = np.zeros((Hd, H), dt); My[np.arange(Hd), y0] += 1 - ly; My[np.arange(Hd), y1] += ly
+    Mx = np.zeros((Wd, W), dt); Mx[np.arange(Wd), x0] += 1 - lx; Mx[np.arange(Wd), x1] += lx
+    return np.einsum('byxc,yi,xj->bijc', dy, My, Mx, optimize=True)
+
+
 # ----------------------------------------------------------------------------
 # transposed conv.  w is [kh,kw,Cout,Cin] (TF conv2d_transpose filter layout)
 # ----------------------------------------------------------------------------

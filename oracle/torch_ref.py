@@ -199,3 +199,84 @@ def fcn_loss_and_grads(p, x, y, fcn_type='8s', dtype=torch.float64):
     g = {n: {k: (tp[n][k].grad.numpy() if tp[n][k].grad is not None else np.zeros_like(np.asarray(p[n][k]), dtype=np.float64))
              for k in ('weights', 'biases')} for n in tp}
     return float(loss.detach()), g, logits.detach().numpy()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DeconvModel (models/deconvolution.py:101-178): independent torch-autograd composition of the graph in oracle/deconv.py
+# ---------------------------------------------------------------------------------------------------------------------
+def _conv_s(x, w_hwio, b, stride, same, relu=True):
+    """NHWC conv with TF padding rules (SAME pads more at the bottom / right when the total is odd)"""
+    k = w_hwio.shape[0]
+    xc = x.permute(0, 3, 1, 2)
+    if same:
+        H, W = xc.shape[2:]
+        oh, ow = -(-H // stride), -(-W // stride)
+        ph, pw = max((oh - 1) * stride + k - H, 0), max((ow - 1) * stride + k - W, 0)
+        xc = F.pad(xc, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+    y = F.conv2d(xc, w_hwio.permute(3, 2, 0, 1), b, stride=stride)
+    y = y.permute(0, 2, 3, 1)
+    return torch.relu(y) if relu else y
+
+
+def _deconv_s(x, w_hwoi, b, stride):
+    """slim.convolution2d_transpose VALID + bias + ReLU; filter [kh,kw,Cout,Cin]"""
+    y = F.conv_transpose2d(x.permute(0, 3, 1, 2), w_hwoi.permute(3, 2, 0, 1), b, stride=stride)
+    return torch.relu(y.permute(0, 2, 3, 1))
+
+
+def _bn_train(a, beta, eps=1e-3):
+    mean = a.mean((0, 1, 2)); var = a.var((0, 1, 2), unbiased=False)
+    return (a - mean) / torch.sqrt(var + eps) + beta, mean, var
+
+
+def _resize_tf(x, out_hw):
+    """tf.image.resize_bilinear, align_corners=False (source = dst * in/out, no half-pixel shift), gather formulation"""
+    def axis(n_in, n_out):
+        scale = np.float32(n_in) / np.float32(n_out)
+        f = (np.arange(n_out, dtype=np.float32) * scale).astype(np.float32)
+        lo = np.minimum(np.floor(f).astype(np.int64), n_in - 1); hi = np.minimum(lo + 1, n_in - 1)
+        return torch.from_numpy(lo), torch.from_numpy(hi), torch.from_numpy((f - np.floor(f)).astype(np.float64)).to(x.dtype)
+    y0, y1, ly = axis(x.shape[1], out_hw[0]); x0, x1, lx = axis(x.shape[2], out_hw[1])
+    r0, r1 = x.index_select(1, y0), x.index_select(1, y1)
+    lx_ = lx[None, None, :, None]; ly_ = ly[None, :, None, None]
+    top = r0.index_select(2, x0) * (1 - lx_) + r0.index_select(2, x1) * lx_
+    bot = r1.index_select(2, x0) * (1 - lx_) + r1.index_select(2, x1) * lx_
+    return top * (1 - ly_) + bot * ly_
+
+
+def deconv_forward(tp, x, masks=None, keep=0.5):
+    """tp: {layer: {weights, biases}, bn: {beta}} torch tensors; masks: {bn: bool ndarray} dropout keep-masks (bayesian)"""
+    H, W = x.shape[1:3]
+    stats = {}
+
+    def bn(name, a):
+        y, mean, var = _bn_train(a, tp[name]['beta'])
+        stats[name] = (mean.detach(), var.detach())
+        if masks is not None and name in masks:
+            y = y * torch.from_numpy(masks[name]).to(y.dtype) * float(np.float32(1.0) / np.float32(keep))
+        return y
+    net = bn('bn1', _conv_s(x, tp['conv1_0']['weights'], tp['conv1_0']['biases'], 2, True))
+    net = F.max_pool2d(net.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    net = bn('bn2', _conv_s(net, tp['conv2_0']['weights'], tp['conv2_0']['biases'], 1, False))
+    net = F.max_pool2d(net.permute(0, 3, 1, 2), 3, 3).permute(0, 2, 3, 1)
+    net = bn('bn3', _conv_s(net, tp['conv3_0']['weights'], tp['conv3_0']['biases'], 1, False))
+    net = F.max_pool2d(net.permute(0, 3, 1, 2), 3, 3).permute(0, 2, 3, 1)
+    net = bn('bn4', _conv_s(net, tp['conv4_0']['weights'], tp['conv4_0']['biases'], 1, False))
+    net = bn('bn5', _deconv_s(net, tp['deconv1_0']['weights'], tp['deconv1_0']['biases'], 2))
+    net = bn('bn6', _deconv_s(net, tp['deconv2_0']['weights'], tp['deconv2_0']['biases'], 2))
+    net = bn('bn7', _deconv_s(net, tp['deconv2_1']['weights'], tp['deconv2_1']['biases'], 2))
+    net = _resize_tf(net, (H // 2, W // 2))
+    net = bn('bn8', _deconv_s(net, tp['deconv3_0']['weights'], tp['deconv3_0']['biases'], 2))
+    net = _crop_or_pad(net.permute(0, 3, 1, 2), H, W).permute(0, 2, 3, 1)      # (that helper is NCHW)
+    return _conv_s(net, tp['conv_out']['weights'], tp['conv_out']['biases'], 1, True, relu=False), stats
+
+
+def deconv_loss_and_grads(p, x, y, masks=None, keep=0.5, dtype=torch.float64):
+    tp = {}
+    for n, t in p.items():
+        tp[n] = {k: torch.tensor(np.asarray(a), dtype=dtype, requires_grad=True) for k, a in t.items() if k in ('weights', 'biases', 'beta')}
+    logits, stats = deconv_forward(tp, torch.as_tensor(np.asarray(x), dtype=dtype), masks, keep)
+    loss = xent_mean(logits, torch.as_tensor(np.asarray(y)[..., 0].astype(np.int64)))
+    loss.backward()
+    g = {n: {k: a.grad.numpy() for k, a in t.items()} for n, t in tp.items()}
+    return float(loss.detach()), g, logits.detach().numpy(), {n: (m.numpy(), v.numpy()) for n, (m, v) in stats.items()}

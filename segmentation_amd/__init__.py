@@ -10,6 +10,9 @@ def __getattr__(name):
     if name == 'FCNModel':
         from .fcn import FCNModel
         return FCNModel
+    if name == 'DeconvModel':
+        from .deconvolution import DeconvModel
+        return DeconvModel
     if name == 'BaseModel':
         from .basemodel import BaseModel
         return BaseModel

@@ -40,6 +40,13 @@ class WgradDesc(C.Structure):
                 ('db', C.c_void_p), ('bias_n', C.c_int32), ('phase', C.c_int32)]
 
 
+class DconvDesc(C.Structure):
+    _fields_ = [('x', View), ('xc', C.c_int32), ('y', View), ('yc', C.c_int32), ('B', C.c_int32), ('Hx', C.c_int32), ('Wx', C.c_int32),
+                ('Hy', C.c_int32), ('Wy', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32), ('stride', C.c_int32), ('pad_t', C.c_int32),
+                ('pad_l', C.c_int32), ('w', C.c_void_p), ('w_su', C.c_int64), ('w_sv', C.c_int64), ('w_sk', C.c_int64),
+                ('bias', C.c_void_p), ('bias_n', C.c_int32), ('relu', C.c_int32), ('mask', View), ('dtype', C.c_int32)]
+
+
 class PackEntry(C.Structure):
     _fields_ = [('src_off', C.c_int64), ('dst_off', C.c_int64), ('mode', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32),
                 ('cin', C.c_int32), ('cout', C.c_int32), ('seg0_c', C.c_int32), ('seg0_cp', C.c_int32),
@@ -79,6 +86,16 @@ SIGNATURES = {
     'seg_relu_grad': [PV, PV, PV, i32, i32, i32, i32, i32, vp],
     'seg_dropout': [PV, PV, i32, i32, i32, i32, f32, u64, u64, i32, vp],
     'seg_cast_pad': [vp, i64, i32, PV, i32, vp],
+    'seg_dconv_fwd': [C.POINTER(DconvDesc), vp],
+    'seg_dconv_bwd_data': [C.POINTER(DconvDesc), vp],
+    'seg_dconv_wgrad': [C.POINTER(DconvDesc), vp, vp, i32, vp],
+    'seg_maxpool_k_fwd': [PV, PV, i32, i32, i32, i32, i32, i32, vp],
+    'seg_maxpool_k_bwd': [PV, PV, PV, i32, i32, i32, i32, i32, i32, vp],
+    'seg_bn_fwd': [PV, PV, vp, vp, vp, i32, f32, f32, i32, i32, i32, i32, i32, vp, i32, vp],
+    'seg_bn_relu_bwd': [PV, PV, PV, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp],
+    'seg_resize_bilinear_fwd': [PV, i32, i32, PV, i32, i32, i32, i32, i32, vp],
+    'seg_resize_bilinear_bwd': [PV, i32, i32, PV, i32, i32, i32, i32, i32, vp],
+    'seg_dropout_step': [PV, PV, i32, i32, i32, i32, f32, u64, u64, vp, i32, vp],
 }
 
 _lib = None
@@ -107,6 +124,8 @@ def load():
     lib.seg_last_error.argtypes = []
     lib.seg_version.restype = C.c_int
     lib.seg_version.argtypes = []
+    lib.seg_bn_ws_bytes.restype = C.c_int64
+    lib.seg_bn_ws_bytes.argtypes = [C.c_int32]
     _lib = lib
     return lib
 

@@ -442,9 +442,11 @@ class BaseModel(object):
             return
         blob = {'global_step': np.int64(gs), 'p': self.store.p.cpu().numpy(), 'm': self.store.m.cpu().numpy(),
                 'v': self.store.v.cpu().numpy()}
-        for name, l in self.store.layers.items():     # named views for interchange: <scope>/weights, <scope>/biases
-            blob[name + '/weights'] = blob['p'][l.w_off:l.w_off + l.wsize].reshape(l.wshape)
-            blob[name + '/biases'] = blob['p'][l.b_off:l.b_off + l.cout]
+        for name, l in self.store.layers.items():     # named views for interchange: <scope>/weights, <scope>/biases (bn: <scope>/beta)
+            blob[name + '/' + l.wname] = blob['p'][l.w_off:l.w_off + l.wsize].reshape(l.wshape)
+            if l.nbias:
+                blob[name + '/' + l.bname] = blob['p'][l.b_off:l.b_off + l.nbias]
+        blob.update(self._state_blob())               # non-trainable state (batch-norm moving averages)
         np.savez(path, **blob)
         for old in glob.glob(self.save_path + '-*.npz'):      # tf.train.Saver(max_to_keep=1)
             if old != path:
@@ -452,8 +454,9 @@ class BaseModel(object):
 
     def restore(self, path):
         z = np.load(path)
-        params = {n: {'weights': z[n + '/weights'], 'biases': z[n + '/biases']} for n in self.store.layers}
+        params = {n: {k: z[n + '/' + k] for k in ((l.wname, l.bname) if l.nbias else (l.wname,))} for n, l in self.store.layers.items()}
         self.store.set_params(params)
+        self._load_state(z)
         if self.store.training and 'm' in z and z['m'].shape[0] == self.store.n:
             self.store.m.copy_(torch.from_numpy(z['m']))
             self.store.v.copy_(torch.from_numpy(z['v']))
@@ -461,6 +464,13 @@ class BaseModel(object):
         self.store.step.fill_(self._gs_host)          # both counters: nothing is in flight here
         self.weights_restored = True
         self._repack()
+
+    def _state_blob(self):
+        """non-trainable tensors to snapshot ({name: ndarray}); models with batch norm override"""
+        return {}
+
+    def _load_state(self, z):
+        pass
 
     def _repack(self):
         self._packed_dirty = False
@@ -476,6 +486,9 @@ class BaseModel(object):
         params = {}
         for name in order:
             l = self.store.layers[name]
+            if l.kind == 'bn':                       # slim.batch_norm: beta = zeros
+                params[name] = {'beta': np.zeros(l.wshape, np.float32)}
+                continue
             k2 = l.wshape[0] * l.wshape[1]
             lim = (6.0 / (k2 * l.wshape[2] + k2 * l.wshape[3])) ** 0.5
             params[name] = {'weights': rng.uniform(-lim, lim, size=l.wshape).astype(np.float32),

@@ -462,7 +462,7 @@ SEG_DEV void glds16(const void* gsrc, char* lds_wave_base) {
 // NBUF = 2: double-buffered (chunk c+1 in flight during chunk c, ~1 workgroup/CU); NBUF = 1: single LDS buffer, loads are
 // not overlapped inside a workgroup but 4-5 small workgroups per CU overlap each other (no staging VGPRs -> 4+ waves/SIMD).
 template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, int NBUF>
-__global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_fwd_glds_kernel(const ConvK P) {
   using T = bf16_t;
   using TT = Tr<T>;
   constexpr int BM = TH * TW;
@@ -471,11 +471,12 @@ __global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
   constexpr int RSTR = TT::RSTR;
   constexpr int PINST = (NPIX * 4 + 63) / 64;             // wave-instructions (1 KiB each) for the patch
   constexpr int WINST = NT * BN * 4 / 64;                 // ... for the filter rows
-  constexpr int PPW = (PINST + 3) / 4, WPW = (WINST + 3) / 4;   // per wave
+  constexpr int NW = WM * WN;                                 // waves per workgroup: 4, or 8 for the 512-pixel tile
+  constexpr int PPW = (PINST + NW - 1) / NW, WPW = (WINST + NW - 1) / NW;   // per wave
   constexpr int PATCH_BYTES = PINST * 1024;
   constexpr int BUF = PATCH_BYTES + WINST * 1024;
   constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
-  static_assert(WM * WN == 4 && FN % 2 == 0, "wave layout");
+  static_assert((NW == 4 || NW == 8) && FN % 2 == 0, "wave layout");
   static_assert((NT * BN * 4) % 64 == 0, "filter rows fill whole wave-instructions");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
   int p_off0[PPW], p_off1[PPW];                 // element offsets inside image b; -1 = zero word
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
-    const int piece = (i * 4 + wave) * 64 + lane;
+    const int piece = (i * NW + wave) * 64 + lane;
     const int q = piece >> 2, h = (piece & 3) ^ ((q >> 1) & 2);          // un-swizzle: which 8 channels land here
     p_off0[i] = -1; p_off1[i] = -1;
     if (q < NPIX) {
@@ -515,10 +516,10 @@ __global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
   int w_off[WPW];                               // element offset inside one (tap-major) chunk slab of the packed filters
 #pragma unroll
   for (int i = 0; i < WPW; ++i) {
-    const int piece = (i * 4 + wave) * 64 + lane;
+    const int piece = (i * NW + wave) * 64 + lane;
     const int rowg = piece >> 2, h = (piece & 3) ^ ((rowg >> 1) & 2);    // rowg = tap*BN + row
     const int tap = rowg / BN, row = rowg % BN;
-    w_off[i] = (i * 4 + wave < WINST) ? ((tap * P.nchunks) * d.n_total + d.n_off + n0 + row) * 32 + h * 8 : -1;
+    w_off[i] = (i * NW + wave < WINST) ? ((tap * P.nchunks) * d.n_total + d.n_off + n0 + row) * 32 + h * 8 : -1;
   }
   const T* src0 = reinterpret_cast<const T*>(d.src0.ptr) + (int64_t)b * d.src0.H * d.src0.W * d.src0.cs;
   const T* src1 = reinterpret_cast<const T*>(d.src1.ptr) + (int64_t)b * d.src1.H * d.src1.W * d.src1.cs;
@@ -529,16 +530,16 @@ __global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
     const T* sb = first ? src0 + c * 32 : src1 + (c - P.nchunks0) * 32;
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      if (i * 4 + wave < PINST) {
+      if (i * NW + wave < PINST) {
         const int off = first ? p_off0[i] : p_off1[i];
         const void* gp = off >= 0 ? (const void*)(sb + off) : (const void*)g_zero16;
-        glds16(gp, buf + (i * 4 + wave) * 1024);
+        glds16(gp, buf + (i * NW + wave) * 1024);
       }
     }
     const T* wc = wp + (int64_t)c * d.n_total * 32;
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
-      if (i * 4 + wave < WINST) glds16(wc + w_off[i], buf + PATCH_BYTES + (i * 4 + wave) * 1024);
+      if (i * NW + wave < WINST) glds16(wc + w_off[i], buf + PATCH_BYTES + (i * NW + wave) * 1024);
     }
   };
 
@@ -567,9 +568,9 @@ __global__ __launch_bounds__(256) void conv_fwd_glds_kernel(const ConvK P) {
   constexpr int PD = NBUF - 1;
   int lpw = 0;                                             // glds instructions this wave issues per chunk
 #pragma unroll
-  for (int i = 0; i < PPW; ++i) lpw += (i * 4 + wave < PINST) ? 1 : 0;
+  for (int i = 0; i < PPW; ++i) lpw += (i * NW + wave < PINST) ? 1 : 0;
 #pragma unroll
-  for (int i = 0; i < WPW; ++i) lpw += (i * 4 + wave < WINST) ? 1 : 0;
+  for (int i = 0; i < WPW; ++i) lpw += (i * NW + wave < WINST) ? 1 : 0;
   if (NBUF >= 2) {
 #pragma unroll
     for (int i = 0; i < PD; ++i) if (i < P.nchunks) issue(i, smem + i * BUF);
@@ -947,7 +948,7 @@ int launch_glds(const ConvK& P0, hipStream_t st) {
     attr_done = true;
   }
   dim3 grid(P.d.B * P.tiles_y * P.tiles_x, P.d.n_count / BN);
-  SEG_LAUNCH(kern, grid, dim3(256), LDS, st, P);
+  SEG_LAUNCH(kern, grid, dim3(64 * WM * WN), LDS, st, P);
   return seg_check_launch("conv_fwd_glds");
 }
 
@@ -1079,6 +1080,8 @@ int launch_k(const ConvK& P, hipStream_t st) {
       case 13: return launch_glds<8, 8, 64, 2, 2, KH, KW, S>(P, st);
       case 14: return launch_glds<8, 8, 32, 4, 1, KH, KW, S>(P, st);
       case 15: return launch_glds<16, 16, 64, 4, 1, KH, KW, S>(P, st);  // 256 px x 64 ch
+      case 16: if constexpr (S == 1) return launch_glds<16, 32, 64, 8, 1, KH, KW, S>(P, st); else break;   // 512 px x 64 ch, 8 waves (64 px x 64 ch each), 150 KB of LDS
+      case 17: if constexpr (S == 1) return launch_glds<16, 32, 32, 8, 1, KH, KW, S>(P, st); else break;   // 512 px x 32 ch
       case 21: return launch_glds<8, 16, 64, 4, 1, KH, KW, S, 1>(P, st);  // single-buffered variants
       case 22: return launch_glds<8, 16, 32, 4, 1, KH, KW, S, 1>(P, st);
       case 23: return launch_glds<8, 8, 64, 2, 2, KH, KW, S, 1>(P, st);

@@ -1,0 +1,616 @@
+// deconv_ops.hip -- the ops DeconvModel needs beyond the U-Net / FCN set (/root/reference/models/deconvolution.py:101-178):
+// 5x5 stride-2 convolution and transposed convolution (direct correlation on the vector ALU: these layers carry < 15 % of
+// the model's 1.5 GMAC per 512x512 image; its 3x3 / 2x2 layers run on the MFMA tiles of conv_fwd.hip / conv_wgrad.hip),
+// k x k max-pool, batch norm fused with the ReLU-grad of the convolution in front of it (wavefront reductions, fixed
+// summation order), bilinear resize.  NHWC, channels padded to 32, 16-byte vector access over channels.
+#include "common.h"
+
+namespace {
+
+inline int grid_for(int64_t n, int per_block = 256, int cap = 16384) {
+  int64_t g = (n + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+inline bool view_ok(const seg_view& v, int H, int W, int C) {
+  return v.ptr && v.oy >= 0 && v.ox >= 0 && v.oy + H <= v.H && v.ox + W <= v.W && v.coff >= 0 && v.coff + C <= v.cs &&
+         (v.cs % 8) == 0 && (v.coff % 8) == 0;
+}
+
+// 8 consecutive n-weights of row (u,v,k); entries at or beyond n_log read as 0 (the row is only n_log long)
+SEG_DEV void wrow8(const float* wr, int n0, int n_log, float (&o)[8]) {
+  if (n0 + 8 <= n_log && ((reinterpret_cast<uintptr_t>(wr + n0) & 15) == 0)) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(wr + n0), b = *reinterpret_cast<const f32x4*>(wr + n0 + 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = n0 + e < n_log ? wr[n0 + e] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// direct correlation: forward form (one thread = one y pixel x 8 n-channels)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dconv_fwd_kernel(const seg_dconv_desc d) {
+  const int N8 = d.y.c / 8, K8 = (d.xc + 7) / 8;
+  const int64_t npix = (int64_t)d.B * d.Hy * d.Wy, total = npix * N8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n8 = (int)(i / npix);                       // slowest: a wave shares its weight rows
+    int64_t t = i - (int64_t)n8 * npix;
+    const int ox = t % d.Wy; t /= d.Wy;
+    const int oy = t % d.Hy; const int b = t / d.Hy;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = (d.bias != nullptr && n8 * 8 + e < d.bias_n) ? d.bias[n8 * 8 + e] : 0.f;
+    if (n8 * 8 < d.yc) {
+      for (int u = 0; u < d.KH; ++u) {
+        const int iy = oy * d.stride + u - d.pad_t;
+        if (iy < 0 || iy >= d.Hx) continue;
+        for (int v = 0; v < d.KW; ++v) {
+          const int ix = ox * d.stride + v - d.pad_l;
+          if (ix < 0 || ix >= d.Wx) continue;
+          const T* xp = reinterpret_cast<const T*>(d.x.ptr) + view_off(d.x, b, iy, ix);
+          const float* wt = d.w + u * d.w_su + v * d.w_sv;
+          for (int k8 = 0; k8 < K8; ++k8) {
+            Vec8<T> xv; xv.load(xp + k8 * 8);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+              const int k = k8 * 8 + kk;
+              if (k >= d.xc) break;
+              float wr[8];
+              wrow8(wt + (int64_t)k * d.w_sk, n8 * 8, d.yc, wr);
+              const float xs = xv.get(kk);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[e] = fmaf(xs, wr[e], acc[e]);
+            }
+          }
+        }
+      }
+    }
+    Vec8<T> mk; mk.zero();
+    if (d.mask.ptr) mk.load(reinterpret_cast<const T*>(d.mask.ptr) + view_off(d.mask, b, oy, ox) + n8 * 8);
+    Vec8<T> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float r = n8 * 8 + e < d.yc ? acc[e] : 0.f;
+      if (d.relu) r = fmaxf(r, 0.f);
+      if (d.mask.ptr && !(mk.get(e) > 0.f)) r = 0.f;
+      o.set(e, r);
+    }
+    o.store(reinterpret_cast<T*>(d.y.ptr) + view_off(d.y, b, oy, ox) + n8 * 8);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// direct correlation: data-gradient / transposed-forward form (one thread = one x pixel x 8 k-channels)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dconv_bwd_data_kernel(const seg_dconv_desc d) {
+  const int K8 = d.x.c / 8, N8 = (d.yc + 7) / 8;
+  const int64_t npix = (int64_t)d.B * d.Hx * d.Wx, total = npix * K8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k8 = (int)(i / npix);
+    int64_t t = i - (int64_t)k8 * npix;
+    const int ix = t % d.Wx; t /= d.Wx;
+    const int iy = t % d.Hx; const int b = t / d.Hx;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = (d.bias != nullptr && k8 * 8 + e < d.bias_n) ? d.bias[k8 * 8 + e] : 0.f;
+    if (k8 * 8 < d.xc) {
+      for (int u = 0; u < d.KH; ++u) {
+        const int ty = iy + d.pad_t - u;
+        if (ty < 0 || ty % d.stride) continue;
+        const int oy = ty / d.stride;
+        if (oy >= d.Hy) continue;
+        for (int v = 0; v < d.KW; ++v) {
+          const int tx = ix + d.pad_l - v;
+          if (tx < 0 || tx % d.stride) continue;
+          const int ox = tx / d.stride;
+          if (ox >= d.Wy) continue;
+          const T* yp = reinterpret_cast<const T*>(d.y.ptr) + view_off(d.y, b, oy, ox);
+          const float* wt = d.w + u * d.w_su + v * d.w_sv;
+          for (int n8 = 0; n8 < N8; ++n8) {
+            Vec8<T> yv; yv.load(yp + n8 * 8);
+            float ys[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ys[e] = yv.get(e);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+              const int k = k8 * 8 + kk;
+              if (k >= d.xc) break;
+              float wr[8];
+              wrow8(wt + (int64_t)k * d.w_sk, n8 * 8, d.yc, wr);
+              float s = acc[kk];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) s = fmaf(ys[e], wr[e], s);
+              acc[kk] = s;
+            }
+          }
+        }
+      }
+    }
+    Vec8<T> mk; mk.zero();
+    if (d.mask.ptr) mk.load(reinterpret_cast<const T*>(d.mask.ptr) + view_off(d.mask, b, iy, ix) + k8 * 8);
+    Vec8<T> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float r = k8 * 8 + e < d.xc ? acc[e] : 0.f;
+      if (d.relu) r = fmaxf(r, 0.f);
+      if (d.mask.ptr && !(mk.get(e) > 0.f)) r = 0.f;
+      o.set(e, r);
+    }
+    o.store(reinterpret_cast<T*>(d.x.ptr) + view_off(d.x, b, iy, ix) + k8 * 8);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// filter gradient: one workgroup per (tap, 8 k, 8 n); threads stride over the y pixels with an 8x8 partial sum each, then
+// a fixed-order reduction (butterfly inside a wave, the four waves through LDS in wave order) -> bitwise reproducible
+// ------------------------------------------------------------------------------------------
+SEG_DEV float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dconv_wgrad_kernel(const seg_dconv_desc d, float* dw, float* db, int db_mode) {
+  __shared__ float red[4][72];
+  const int tap = blockIdx.x, u = tap / d.KW, v = tap % d.KW;
+  const int k8 = blockIdx.y, n8 = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float acc[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[a][e] = 0.f;
+  float accb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) accb[e] = 0.f;
+  const bool bias1 = db_mode == 1 && tap == 0 && k8 == 0, bias2 = db_mode == 2 && tap == 0 && n8 == 0;
+  const int64_t npix = (int64_t)d.B * d.Hy * d.Wy;
+  for (int64_t p = tid; p < npix; p += 256) {
+    int64_t t = p;
+    const int ox = t % d.Wy; t /= d.Wy;
+    const int oy = t % d.Hy; const int b = t / d.Hy;
+    Vec8<T> yv; yv.load(reinterpret_cast<const T*>(d.y.ptr) + view_off(d.y, b, oy, ox) + n8 * 8);
+    if (bias1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) accb[e] += yv.get(e);
+    }
+    const int iy = oy * d.stride + u - d.pad_t, ix = ox * d.stride + v - d.pad_l;
+    if (iy < 0 || iy >= d.Hx || ix < 0 || ix >= d.Wx) continue;
+    Vec8<T> xv; xv.load(reinterpret_cast<const T*>(d.x.ptr) + view_off(d.x, b, iy, ix) + k8 * 8);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const float xs = xv.get(a);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[a][e] = fmaf(xs, yv.get(e), acc[a][e]);
+    }
+  }
+  if (bias2) {                                       // sum of x over its FULL extent (bias of a transposed convolution)
+    const int64_t nx = (int64_t)d.B * d.Hx * d.Wx;
+    for (int64_t p = tid; p < nx; p += 256) {
+      int64_t t = p;
+      const int ix = t % d.Wx; t /= d.Wx;
+      const int iy = t % d.Hx; const int b = t / d.Hx;
+      Vec8<T> xv; xv.load(reinterpret_cast<const T*>(d.x.ptr) + view_off(d.x, b, iy, ix) + k8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) accb[e] += xv.get(e);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float s = wave_sum64(acc[a][e]);
+      if (lane == 0) red[wave][a * 8 + e] = s;
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float s = wave_sum64(accb[e]);
+    if (lane == 0) red[wave][64 + e] = s;
+  }
+  __syncthreads();
+  if (tid < 72) {
+    const float s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    if (tid < 64) {
+      const int k = k8 * 8 + tid / 8, n = n8 * 8 + tid % 8;
+      if (k < d.xc && n < d.yc) dw[u * d.w_su + v * d.w_sv + (int64_t)k * d.w_sk + n] = s;
+    } else {
+      const int e = tid - 64;
+      if (bias1 && n8 * 8 + e < d.bias_n) db[n8 * 8 + e] = s;
+      if (bias2 && k8 * 8 + e < d.bias_n) db[k8 * 8 + e] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k x k / stride k / VALID max-pool (no ReLU-mask fusion: the input is a batch-norm output)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool_k_fwd_kernel(seg_view src, seg_view dst, int k, int B, int Ho, int Wo, int C8) {
+  const int64_t total = (int64_t)B * Ho * Wo * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int c8 = t % C8; t /= C8;
+    const int ox = t % Wo; t /= Wo;
+    const int oy = t % Ho; const int b = t / Ho;
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+    for (int u = 0; u < k; ++u)
+      for (int v = 0; v < k; ++v) {
+        Vec8<T> x; x.load(reinterpret_cast<const T*>(src.ptr) + view_off(src, b, oy * k + u, ox * k + v) + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], x.get(e));
+      }
+    Vec8<T> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.set(e, m[e]);
+    o.store(reinterpret_cast<T*>(dst.ptr) + view_off(dst, b, oy, ox) + c8 * 8);
+  }
+}
+
+// one thread per window position of the ceil grid: routes dpool to the FIRST maximum (row-major), zeroes the rest of the
+// window and the trailing rows / columns no window covers
+template <typename T>
+__global__ void maxpool_k_bwd_kernel(seg_view src, seg_view dpool, seg_view dsrc, int k, int B, int H, int W, int C8) {
+  const int Ho = H / k, Wo = W / k, Hw = (H + k - 1) / k, Ww = (W + k - 1) / k;
+  const int64_t total = (int64_t)B * Hw * Ww * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int c8 = t % C8; t /= C8;
+    const int wx = t % Ww; t /= Ww;
+    const int wy = t % Hw; const int b = t / Hw;
+    const bool full = wy < Ho && wx < Wo;
+    float m[8]; int mi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; mi[e] = -1; }
+    Vec8<T> dp; dp.zero();
+    if (full) {
+      dp.load(reinterpret_cast<const T*>(dpool.ptr) + view_off(dpool, b, wy, wx) + c8 * 8);
+      for (int u = 0; u < k; ++u)
+        for (int v = 0; v < k; ++v) {
+          Vec8<T> x; x.load(reinterpret_cast<const T*>(src.ptr) + view_off(src, b, wy * k + u, wx * k + v) + c8 * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float xv = x.get(e); if (xv > m[e] || mi[e] < 0) { m[e] = xv; mi[e] = u * k + v; } }
+        }
+    }
+    for (int u = 0; u < k; ++u)
+      for (int v = 0; v < k; ++v) {
+        const int yy = wy * k + u, xx = wx * k + v;
+        if (yy >= H || xx >= W) continue;
+        Vec8<T> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, (full && mi[e] == u * k + v) ? dp.get(e) : 0.f);
+        o.store(reinterpret_cast<T*>(dsrc.ptr) + view_off(dsrc, b, yy, xx) + c8 * 8);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// batch norm (beta only) behind a ReLU: statistics in three fixed-order stages
+//   partial  : NB workgroups, each a contiguous pixel range; thread (pixel lane, 8 channels) -> per-workgroup sums in ws
+//   final    : one thread per channel adds the NB partials in order (double), derives mean / rstd (fwd) or the two means (bwd)
+//   apply    : elementwise
+// MODE 0: s1 = sum a, s2 = sum a^2.  MODE 1: s1 = sum dy, s2 = sum dy * xhat.
+// ------------------------------------------------------------------------------------------
+constexpr int BN_NB = 256;
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(seg_view a, seg_view dy, const float* stats, int B, int H, int W, int C, float* ws) {
+  __shared__ float red[256][17];
+  const int C8 = C / 8, PL = 256 / C8;                  // pixel lanes per workgroup
+  const int tid = threadIdx.x, c8 = tid % C8, pl = tid / C8;
+  const int64_t npix = (int64_t)B * H * W;
+  const int64_t chunk = (npix + gridDim.x - 1) / gridDim.x;
+  const int64_t p0 = (int64_t)blockIdx.x * chunk, p1 = p0 + chunk < npix ? p0 + chunk : npix;
+  float s1[8], s2[8], mean[8], rstd[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = s2[e] = 0.f; mean[e] = 0.f; rstd[e] = 1.f; }
+  if (MODE == 1 && pl < PL) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { mean[e] = stats[c8 * 8 + e]; rstd[e] = stats[C + c8 * 8 + e]; }
+  }
+  if (pl < PL) {
+    for (int64_t p = p0 + pl; p < p1; p += PL) {
+      int64_t t = p;
+      const int x = t % W; t /= W;
+      const int y = t % H; const int b = t / H;
+      Vec8<T> av; av.load(reinterpret_cast<const T*>(a.ptr) + view_off(a, b, y, x) + c8 * 8);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float v = av.get(e); s1[e] += v; s2[e] = fmaf(v, v, s2[e]); }
+      } else {
+        Vec8<T> gv; gv.load(reinterpret_cast<const T*>(dy.ptr) + view_off(dy, b, y, x) + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float g = gv.get(e); s1[e] += g; s2[e] = fmaf(g, (av.get(e) - mean[e]) * rstd[e], s2[e]); }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[tid][e] = s1[e]; red[tid][8 + e] = s2[e]; }
+  __syncthreads();
+  for (int idx = tid; idx < C8 * 16; idx += 256) {     // one (channel group, which of its 16 sums) each: pixel lanes added in order
+    const int cc = idx / 16, j = idx % 16;
+    float s = 0.f;
+    for (int q = 0; q < PL; ++q) s += red[q * C8 + cc][j];
+    ws[((int64_t)blockIdx.x * C + cc * 8 + (j & 7)) * 2 + (j >> 3)] = s;
+  }
+}
+
+template <int MODE>
+__global__ void bn_final_kernel(const float* ws, int nb, int C, int c_log, double inv_n, float eps, float decay, int training,
+                                float* moving, float* stats, float* out2, float* dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nb; ++b) { s1 += (double)ws[((int64_t)b * C + c) * 2]; s2 += (double)ws[((int64_t)b * C + c) * 2 + 1]; }
+  if (MODE == 0) {
+    float mean, var;
+    if (training) {
+      const double m = s1 * inv_n;
+      double vv = s2 * inv_n - m * m; if (vv < 0.0) vv = 0.0;
+      mean = (float)m; var = (float)vv;
+      if (moving != nullptr && c < c_log) {
+        moving[c] = decay * moving[c] + (1.f - decay) * mean;
+        moving[C + c] = decay * moving[C + c] + (1.f - decay) * var;
+      }
+    } else {
+      mean = moving[c]; var = moving[C + c];
+    }
+    if (c >= c_log) { mean = 0.f; var = 1.f; }          // pad channels: y = 0 * rstd + 0
+    stats[c] = mean;
+    stats[C + c] = 1.f / sqrtf(var + eps);
+  } else {
+    out2[c] = (float)(s1 * inv_n);
+    out2[C + c] = (float)(s2 * inv_n);
+    if (c < c_log) dbeta[c] = (float)s1;
+  }
+}
+
+template <typename T, int MODE>
+__global__ void bn_apply_kernel(seg_view a, seg_view in2, seg_view out, const float* stats, const float* aux, int B, int H, int W, int C8, int C, int c_log) {
+  const int64_t total = (int64_t)B * H * W * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int c8 = t % C8; t /= C8;
+    const int x = t % W; t /= W;
+    const int y = t % H; const int b = t / H;
+    Vec8<T> av; av.load(reinterpret_cast<const T*>(a.ptr) + view_off(a, b, y, x) + c8 * 8);
+    Vec8<T> o;
+    if (MODE == 0) {                                     // aux = beta (c_log entries: pad channels stay 0)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const int c = c8 * 8 + e; o.set(e, c < c_log ? (av.get(e) - stats[c]) * stats[C + c] + aux[c] : 0.f); }
+    } else {                                             // aux = {mean(dy), mean(dy * xhat)}
+      Vec8<T> gv; gv.load(reinterpret_cast<const T*>(in2.ptr) + view_off(in2, b, y, x) + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = c8 * 8 + e;
+        const float xh = (av.get(e) - stats[c]) * stats[C + c];
+        const float da = stats[C + c] * (gv.get(e) - aux[c] - xh * aux[C + c]);
+        o.set(e, av.get(e) > 0.f ? da : 0.f);
+      }
+    }
+    o.store(reinterpret_cast<T*>(out.ptr) + view_off(out, b, y, x) + c8 * 8);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// tf.image.resize_bilinear, align_corners=False
+// ------------------------------------------------------------------------------------------
+SEG_DEV void lerp_coord(int o, float scale, int n_in, int& i0, int& i1, float& l) {
+  const float f = (float)o * scale;
+  i0 = (int)floorf(f);
+  if (i0 > n_in - 1) i0 = n_in - 1;
+  i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
+  l = f - floorf(f);
+}
+
+template <typename T>
+__global__ void resize_fwd_kernel(seg_view src, int Hs, int Ws, seg_view dst, int Hd, int Wd, int B, int C8) {
+  const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
+  const int64_t total = (int64_t)B * Hd * Wd * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int c8 = t % C8; t /= C8;
+    const int x = t % Wd; t /= Wd;
+    const int y = t % Hd; const int b = t / Hd;
+    int y0, y1, x0, x1; float ly, lx;
+    lerp_coord(y, sy, Hs, y0, y1, ly); lerp_coord(x, sx, Ws, x0, x1, lx);
+    const T* sp = reinterpret_cast<const T*>(src.ptr);
+    Vec8<T> tl, tr, bl, br;
+    tl.load(sp + view_off(src, b, y0, x0) + c8 * 8); tr.load(sp + view_off(src, b, y0, x1) + c8 * 8);
+    bl.load(sp + view_off(src, b, y1, x0) + c8 * 8); br.load(sp + view_off(src, b, y1, x1) + c8 * 8);
+    Vec8<T> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float top = tl.get(e) + (tr.get(e) - tl.get(e)) * lx, bot = bl.get(e) + (br.get(e) - bl.get(e)) * lx;
+      o.set(e, top + (bot - top) * ly);
+    }
+    o.store(reinterpret_cast<T*>(dst.ptr) + view_off(dst, b, y, x) + c8 * 8);
+  }
+}
+
+// adjoint in gather form: source pixel (iy, ix) collects every destination pixel whose 2x2 neighbourhood contains it
+template <typename T>
+__global__ void resize_bwd_kernel(seg_view dd, int Hd, int Wd, seg_view ds, int Hs, int Ws, int B, int C8) {
+  const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
+  const int64_t total = (int64_t)B * Hs * Ws * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int c8 = t % C8; t /= C8;
+    const int ix = t % Ws; t /= Ws;
+    const int iy = t % Hs; const int b = t / Hs;
+    int ya = (int)floorf((float)(iy - 1) / sy) - 1, yb = (int)ceilf((float)(iy + 1) / sy) + 1;
+    int xa = (int)floorf((float)(ix - 1) / sx) - 1, xb = (int)ceilf((float)(ix + 1) / sx) + 1;
+    if (ya < 0) ya = 0; if (xa < 0) xa = 0; if (yb > Hd - 1) yb = Hd - 1; if (xb > Wd - 1) xb = Wd - 1;
+    if (iy == Hs - 1) yb = Hd - 1;                       // clamped upper neighbours all land on the last row / column
+    if (ix == Ws - 1) xb = Wd - 1;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int y = ya; y <= yb; ++y) {
+      int y0, y1; float ly;
+      lerp_coord(y, sy, Hs, y0, y1, ly);
+      const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int x = xa; x <= xb; ++x) {
+        int x0, x1; float lx;
+        lerp_coord(x, sx, Ws, x0, x1, lx);
+        const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+        if (wx == 0.f) continue;
+        Vec8<T> g; g.load(reinterpret_cast<const T*>(dd.ptr) + view_off(dd, b, y, x) + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(g.get(e), wy * wx, acc[e]);
+      }
+    }
+    Vec8<T> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.set(e, acc[e]);
+    o.store(reinterpret_cast<T*>(ds.ptr) + view_off(ds, b, iy, ix) + c8 * 8);
+  }
+}
+
+int check_dconv(const seg_dconv_desc* dp, const char* what) {
+  if (!dp) { seg_set_error("%s: null descriptor", what); return SEG_ERR_ARG; }
+  const seg_dconv_desc& d = *dp;
+  if (d.B <= 0 || d.Hx <= 0 || d.Wx <= 0 || d.Hy <= 0 || d.Wy <= 0 || d.KH <= 0 || d.KW <= 0 || d.stride <= 0) { seg_set_error("%s: empty extent", what); return SEG_ERR_ARG; }
+  if (!view_ok(d.x, d.Hx, d.Wx, d.x.c) || !view_ok(d.y, d.Hy, d.Wy, d.y.c) || d.x.c <= 0 || d.x.c % 8 || d.y.c <= 0 || d.y.c % 8) { seg_set_error("%s: bad x / y view", what); return SEG_ERR_ARG; }
+  if (d.xc <= 0 || d.xc > d.x.c || d.yc <= 0 || d.yc > d.y.c || !d.w) { seg_set_error("%s: bad channel counts / null weights", what); return SEG_ERR_ARG; }
+  if (d.dtype != SEG_F32 && d.dtype != SEG_BF16) { seg_set_error("%s: bad dtype %d", what, d.dtype); return SEG_ERR_ARG; }
+  // every y pixel must read only taps that the stride / padding arithmetic places (partly) inside x or in its zero padding
+  if ((d.Hy - 1) * d.stride - d.pad_t >= d.Hx || (d.Wy - 1) * d.stride - d.pad_l >= d.Wx) { seg_set_error("%s: y extent %dx%d does not fit x %dx%d at stride %d", what, d.Hy, d.Wy, d.Hx, d.Wx, d.stride); return SEG_ERR_ARG; }
+  return SEG_OK;
+}
+
+}  // namespace
+
+extern "C" int seg_dconv_fwd(const seg_dconv_desc* dp, void* stream) {
+  if (int rc = check_dconv(dp, "dconv_fwd")) return rc;
+  const seg_dconv_desc& d = *dp;
+  if (d.mask.ptr && !view_ok(d.mask, d.Hy, d.Wy, d.y.c)) { seg_set_error("dconv_fwd: bad mask view"); return SEG_ERR_ARG; }
+  const int g = grid_for((int64_t)d.B * d.Hy * d.Wy * (d.y.c / 8));
+  if (d.dtype == SEG_F32) SEG_LAUNCH(dconv_fwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, d);
+  else SEG_LAUNCH(dconv_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, d);
+  return seg_check_launch("dconv_fwd");
+}
+
+extern "C" int seg_dconv_bwd_data(const seg_dconv_desc* dp, void* stream) {
+  if (int rc = check_dconv(dp, "dconv_bwd_data")) return rc;
+  const seg_dconv_desc& d = *dp;
+  if (d.mask.ptr && !view_ok(d.mask, d.Hx, d.Wx, d.x.c)) { seg_set_error("dconv_bwd_data: bad mask view"); return SEG_ERR_ARG; }
+  const int g = grid_for((int64_t)d.B * d.Hx * d.Wx * (d.x.c / 8));
+  if (d.dtype == SEG_F32) SEG_LAUNCH(dconv_bwd_data_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, d);
+  else SEG_LAUNCH(dconv_bwd_data_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, d);
+  return seg_check_launch("dconv_bwd_data");
+}
+
+extern "C" int seg_dconv_wgrad(const seg_dconv_desc* dp, float* dw, float* db, int32_t db_mode, void* stream) {
+  if (int rc = check_dconv(dp, "dconv_wgrad")) return rc;
+  const seg_dconv_desc& d = *dp;
+  if (!dw || db_mode < 0 || db_mode > 2 || (db_mode && (!db || d.bias_n <= 0))) { seg_set_error("dconv_wgrad: bad output / bias request"); return SEG_ERR_ARG; }
+  if ((db_mode == 1 && d.bias_n > d.yc) || (db_mode == 2 && d.bias_n > d.xc)) { seg_set_error("dconv_wgrad: bias_n exceeds channels"); return SEG_ERR_ARG; }
+  const dim3 grid(d.KH * d.KW, (d.xc + 7) / 8, (d.yc + 7) / 8);
+  if (d.dtype == SEG_F32) SEG_LAUNCH(dconv_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, d, dw, db, db_mode);
+  else SEG_LAUNCH(dconv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, d, dw, db, db_mode);
+  return seg_check_launch("dconv_wgrad");
+}
+
+extern "C" int seg_maxpool_k_fwd(const seg_view* src, const seg_view* dst, int32_t k, int32_t B, int32_t Ho, int32_t Wo, int32_t C,
+                                 int32_t dtype, void* stream) {
+  if (!src || !dst || k < 1 || k > 8 || C <= 0 || C % 8 || !view_ok(*src, Ho * k, Wo * k, C) || !view_ok(*dst, Ho, Wo, C)) { seg_set_error("maxpool_k_fwd: bad arguments"); return SEG_ERR_ARG; }
+  const int g = grid_for((int64_t)B * Ho * Wo * (C / 8));
+  if (dtype == SEG_F32) SEG_LAUNCH(maxpool_k_fwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, *src, *dst, k, B, Ho, Wo, C / 8);
+  else if (dtype == SEG_BF16) SEG_LAUNCH(maxpool_k_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, *src, *dst, k, B, Ho, Wo, C / 8);
+  else { seg_set_error("maxpool_k_fwd: bad dtype"); return SEG_ERR_ARG; }
+  return seg_check_launch("maxpool_k_fwd");
+}
+
+extern "C" int seg_maxpool_k_bwd(const seg_view* src, const seg_view* dpool, const seg_view* dsrc, int32_t k, int32_t B, int32_t H,
+                                 int32_t W, int32_t C, int32_t dtype, void* stream) {
+  if (!src || !dpool || !dsrc || k < 1 || k > 8 || C <= 0 || C % 8 || H < k || W < k || !view_ok(*src, H, W, C) || !view_ok(*dsrc, H, W, C) ||
+      !view_ok(*dpool, H / k, W / k, C)) { seg_set_error("maxpool_k_bwd: bad arguments"); return SEG_ERR_ARG; }
+  const int g = grid_for((int64_t)B * ((H + k - 1) / k) * ((W + k - 1) / k) * (C / 8));
+  if (dtype == SEG_F32) SEG_LAUNCH(maxpool_k_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, *src, *dpool, *dsrc, k, B, H, W, C / 8);
+  else if (dtype == SEG_BF16) SEG_LAUNCH(maxpool_k_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, *src, *dpool, *dsrc, k, B, H, W, C / 8);
+  else { seg_set_error("maxpool_k_bwd: bad dtype"); return SEG_ERR_ARG; }
+  return seg_check_launch("maxpool_k_bwd");
+}
+
+extern "C" int64_t seg_bn_ws_bytes(int32_t C) { return ((int64_t)BN_NB * C * 2 + 2 * C) * 4; }
+
+static int bn_nb(int64_t npix, int C8) {
+  const int pl = 256 / C8;
+  int64_t nb = (npix + (int64_t)pl * 16 - 1) / ((int64_t)pl * 16);      // >= 16 pixels per thread before another workgroup pays
+  if (nb > BN_NB) nb = BN_NB;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+extern "C" int seg_bn_fwd(const seg_view* a, const seg_view* y, const float* beta, float* moving, float* stats, int32_t training,
+                          float decay, float eps, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype,
+                          void* stream) {
+  if (!a || !y || !beta || !stats || !ws || C <= 0 || C % 8 || C > 2048 || c_log <= 0 || c_log > C || !view_ok(*a, H, W, C) || !view_ok(*y, H, W, C) ||
+      (!training && !moving) || (dtype != SEG_F32 && dtype != SEG_BF16)) { seg_set_error("bn_fwd: bad arguments"); return SEG_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t npix = (int64_t)B * H * W;
+  const int nb = bn_nb(npix, C / 8);
+  seg_view none = *a;
+  if (training) {
+    if (dtype == SEG_F32) SEG_LAUNCH((bn_partial_kernel<float, 0>), dim3(nb), dim3(256), 0, st, *a, none, (const float*)nullptr, B, H, W, C, ws);
+    else SEG_LAUNCH((bn_partial_kernel<bf16_t, 0>), dim3(nb), dim3(256), 0, st, *a, none, (const float*)nullptr, B, H, W, C, ws);
+    if (int rc = seg_check_launch("bn_partial")) return rc;
+  }
+  SEG_LAUNCH(bn_final_kernel<0>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, training ? nb : 0, C, c_log, 1.0 / (double)npix, eps, decay,
+             training, moving, stats, (float*)nullptr, (float*)nullptr);
+  if (int rc = seg_check_launch("bn_final")) return rc;
+  const int g = grid_for(npix * (C / 8));
+  if (dtype == SEG_F32) SEG_LAUNCH((bn_apply_kernel<float, 0>), dim3(g), dim3(256), 0, st, *a, none, *y, (const float*)stats, beta, B, H, W, C / 8, C, c_log);
+  else SEG_LAUNCH((bn_apply_kernel<bf16_t, 0>), dim3(g), dim3(256), 0, st, *a, none, *y, (const float*)stats, beta, B, H, W, C / 8, C, c_log);
+  return seg_check_launch("bn_apply");
+}
+
+extern "C" int seg_bn_relu_bwd(const seg_view* a, const seg_view* dy, const seg_view* dz, const float* stats, float* dbeta, int32_t B,
+                               int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype, void* stream) {
+  if (!a || !dy || !dz || !stats || !dbeta || !ws || C <= 0 || C % 8 || C > 2048 || c_log <= 0 || c_log > C || !view_ok(*a, H, W, C) ||
+      !view_ok(*dy, H, W, C) || !view_ok(*dz, H, W, C) || (dtype != SEG_F32 && dtype != SEG_BF16)) { seg_set_error("bn_relu_bwd: bad arguments"); return SEG_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t npix = (int64_t)B * H * W;
+  const int nb = bn_nb(npix, C / 8);
+  float* means = ws + (int64_t)BN_NB * C * 2;
+  if (dtype == SEG_F32) SEG_LAUNCH((bn_partial_kernel<float, 1>), dim3(nb), dim3(256), 0, st, *a, *dy, stats, B, H, W, C, ws);
+  else SEG_LAUNCH((bn_partial_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, st, *a, *dy, stats, B, H, W, C, ws);
+  if (int rc = seg_check_launch("bn_partial_bwd")) return rc;
+  SEG_LAUNCH(bn_final_kernel<1>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, nb, C, c_log, 1.0 / (double)npix, 0.f, 0.f, 1,
+             (float*)nullptr, (float*)nullptr, means, dbeta);
+  if (int rc = seg_check_launch("bn_final_bwd")) return rc;
+  const int g = grid_for(npix * (C / 8));
+  if (dtype == SEG_F32) SEG_LAUNCH((bn_apply_kernel<float, 1>), dim3(g), dim3(256), 0, st, *a, *dy, *dz, stats, (const float*)means, B, H, W, C / 8, C, c_log);
+  else SEG_LAUNCH((bn_apply_kernel<bf16_t, 1>), dim3(g), dim3(256), 0, st, *a, *dy, *dz, stats, (const float*)means, B, H, W, C / 8, C, c_log);
+  return seg_check_launch("bn_apply_bwd");
+}
+
+extern "C" int seg_resize_bilinear_fwd(const seg_view* src, int32_t Hs, int32_t Ws, const seg_view* dst, int32_t Hd, int32_t Wd, int32_t B,
+                                       int32_t C, int32_t dtype, void* stream) {
+  if (!src || !dst || C <= 0 || C % 8 || Hs < 1 || Ws < 1 || Hd < 1 || Wd < 1 || !view_ok(*src, Hs, Ws, C) || !view_ok(*dst, Hd, Wd, C)) { seg_set_error("resize_bilinear_fwd: bad arguments"); return SEG_ERR_ARG; }
+  const int g = grid_for((int64_t)B * Hd * Wd * (C / 8));
+  if (dtype == SEG_F32) SEG_LAUNCH(resize_fwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, *src, Hs, Ws, *dst, Hd, Wd, B, C / 8);
+  else if (dtype == SEG_BF16) SEG_LAUNCH(resize_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, *src, Hs, Ws, *dst, Hd, Wd, B, C / 8);
+  else { seg_set_error("resize_bilinear_fwd: bad dtype"); return SEG_ERR_ARG; }
+  return seg_check_launch("resize_bilinear_fwd");
+}
+
+extern "C" int seg_resize_bilinear_bwd(const seg_view* ddst, int32_t Hd, int32_t Wd, const seg_view* dsrc, int32_t Hs, int32_t Ws, int32_t B,
+                                       int32_t C, int32_t dtype, void* stream) {
+  if (!ddst || !dsrc || C <= 0 || C % 8 || Hs < 1 || Ws < 1 || Hd < 1 || Wd < 1 || !view_ok(*dsrc, Hs, Ws, C) || !view_ok(*ddst, Hd, Wd, C)) { seg_set_error("resize_bilinear_bwd: bad arguments"); return SEG_ERR_ARG; }
+  const int g = grid_for((int64_t)B * Hs * Ws * (C / 8));
+  if (dtype == SEG_F32) SEG_LAUNCH(resize_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, *ddst, Hd, Wd, *dsrc, Hs, Ws, B, C / 8);
+  else if (dtype == SEG_BF16) SEG_LAUNCH(resize_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, *ddst, Hd, Wd, *dsrc, Hs, Ws, B, C / 8);
+  else { seg_set_error("resize_bilinear_bwd: bad dtype"); return SEG_ERR_ARG; }
+  return seg_check_launch("resize_bilinear_bwd");
+}

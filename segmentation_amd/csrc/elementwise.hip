@@ -172,7 +172,9 @@ SEG_DEV uint64_t splitmix64(uint64_t k) {
   return k ^ (k >> 31);
 }
 template <typename T>
-__global__ void dropout_kernel(seg_view xin, seg_view yout, int B, int H, int W, int C8, float keep, uint64_t seed, uint64_t offset) {
+__global__ void dropout_kernel(seg_view xin, seg_view yout, int B, int H, int W, int C8, float keep, uint64_t seed, uint64_t offset,
+                               const int64_t* step_dev) {
+  if (step_dev != nullptr) offset += (uint64_t)(*step_dev) << 40;     // (seg_dropout_step: a fresh mask per replayed training step)
   const int64_t total = (int64_t)B * H * W * C8;
   const float inv = 1.f / keep;
   const uint32_t thr = (uint32_t)(keep * 4294967295.0);
@@ -803,14 +805,25 @@ extern "C" int seg_cast_pad(const float* x, int64_t npix, int32_t c, const seg_v
   return seg_check_launch("cast_pad");
 }
 
-extern "C" int seg_dropout(const seg_view* x, const seg_view* y, int32_t B, int32_t H, int32_t W, int32_t C, float keep,
-                           uint64_t seed, uint64_t offset, int32_t dtype, void* stream) {
+static int dropout_launch(const seg_view* x, const seg_view* y, int32_t B, int32_t H, int32_t W, int32_t C, float keep, uint64_t seed,
+                          uint64_t offset, const int64_t* step_dev, int32_t dtype, void* stream) {
   if (!view_ok(x, H, W, C) || !view_ok(y, H, W, C) || C % 8 || !(keep > 0.f && keep <= 1.f)) { seg_set_error("dropout: bad args"); return SEG_ERR_ARG; }
   const int64_t n = (int64_t)B * H * W * (C / 8);
   DISPATCH(dtype,
-           SEG_LAUNCH(dropout_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *x, *y, B, H, W, C / 8, keep, seed, offset),
-           SEG_LAUNCH(dropout_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *x, *y, B, H, W, C / 8, keep, seed, offset));
+           SEG_LAUNCH(dropout_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *x, *y, B, H, W, C / 8, keep, seed, offset, step_dev),
+           SEG_LAUNCH(dropout_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *x, *y, B, H, W, C / 8, keep, seed, offset, step_dev));
   return seg_check_launch("dropout");
+}
+
+extern "C" int seg_dropout(const seg_view* x, const seg_view* y, int32_t B, int32_t H, int32_t W, int32_t C, float keep,
+                           uint64_t seed, uint64_t offset, int32_t dtype, void* stream) {
+  return dropout_launch(x, y, B, H, W, C, keep, seed, offset, nullptr, dtype, stream);
+}
+
+extern "C" int seg_dropout_step(const seg_view* x, const seg_view* y, int32_t B, int32_t H, int32_t W, int32_t C, float keep,
+                                uint64_t seed, uint64_t offset, const int64_t* step_dev, int32_t dtype, void* stream) {
+  if (!step_dev) { seg_set_error("dropout_step: null step pointer"); return SEG_ERR_ARG; }
+  return dropout_launch(x, y, B, H, W, C, keep, seed, offset, step_dev, dtype, stream);
 }
 
 extern "C" int seg_softmax_xent(const seg_view* logits, const uint8_t* labels, int32_t LH, int32_t LW, int32_t ly0, int32_t lx0,

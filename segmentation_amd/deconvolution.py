@@ -1,0 +1,330 @@
+"""DeconvModel: the reference's convolution / deconvolution net (/root/reference/models/deconvolution.py:26-178) compiled to
+HIP launch plans -- the one segmentation model of the reference with BatchNorm and `bayesian` dropout.
+
+Graph (slim defaults: bias + ReLU on every conv / transposed conv except conv_out; batch_norm decay 0.999, eps 1e-3, beta
+only, applied to the ReLU OUTPUT of the layer in front of it):
+  conv1_0 5x5/s2 SAME -> bn1 -> pool 2x2 -> conv2_0 3x3 VALID -> bn2 [-> dropout] -> pool 3x3 -> conv3_0 -> bn3 -> pool 3x3
+  -> conv4_0 -> bn4 [-> dropout] -> deconv1_0 5x5/s2 VALID -> bn5 [-> dropout] -> deconv2_0 -> bn6 -> deconv2_1 -> bn7
+  -> resize_bilinear(H/2, W/2) -> deconv3_0 2x2/s2 -> bn8 -> crop_or_pad(H, W) -> conv_out 3x3 SAME (no activation)
+Kernels: the 3x3 and 2x2/s2 layers run on the MFMA tiles (csrc/conv_fwd.hip, conv_wgrad.hip); the 5x5 stride-2 conv and the
+three 5x5 stride-2 transposed convs on the direct kernels of csrc/deconv_ops.hip; batch norm = seg_bn_fwd / seg_bn_relu_bwd
+(three fixed-order reduction stages, the backward fused with the ReLU-grad of the layer in front).
+
+Reference behaviour kept on purpose: infer() runs the TRAINING graph -- y_hat is built with training=True
+(models/deconvolution.py:80,102), so inference normalises with the statistics of the batch it is given and, when
+`bayesian`, keeps dropout ON (slim.dropout's is_training defaults to True): every infer() call is one stochastic pass;
+test() is the moving-average graph (models/basemodel.py:397).  Moving averages are updated by train_step()
+(UPDATE_OPS, models/basemodel.py:364-365).  Dropout masks come from the build's counter-based generator (seed, site, global
+step): TF's RNG stream cannot be reproduced, so the masks are build-defined (oracle.np_ops.dropout_mask restates them).
+Limits: even input sizes (the reference pads an odd one by a row after deconv3_0; rejected here), input >= 140 pixels.
+Data parallel: batch statistics are per rank (like slim towers); rank 0's moving averages are the ones snapshotted."""
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import engine as E
+from .basemodel import BaseModel
+
+# (name, kind, k, stride, padding, cin factor, cout factor) in graph order; factors multiply n_kernels (0 = special)
+GRAPH = ['conv1_0', 'bn1', 'conv2_0', 'bn2', 'conv3_0', 'bn3', 'conv4_0', 'bn4', 'deconv1_0', 'bn5', 'deconv2_0', 'bn6',
+         'deconv2_1', 'bn7', 'deconv3_0', 'bn8', 'conv_out']
+BWD_ORDER = list(reversed(GRAPH))
+DROP_SITES = {'bn2': 1, 'bn4': 2, 'bn5': 3}                    # batch norm followed by a `bayesian` dropout -> seed increment
+
+
+def deconv_layers(n_classes, nk, cin):
+    Ly = {}
+
+    def add(name, kind, k, ci, co, padding='VALID', relu=True, stride=1):
+        Ly[name] = E.Layer(name, kind, k, [ci], co, padding, relu, stride)
+    add('conv1_0', 'direct', 5, cin, nk, 'SAME', stride=2); add('bn1', 'bn', 1, nk, nk)
+    add('conv2_0', 'conv', 3, nk, 2 * nk); add('bn2', 'bn', 1, 2 * nk, 2 * nk)
+    add('conv3_0', 'conv', 3, 2 * nk, 4 * nk); add('bn3', 'bn', 1, 4 * nk, 4 * nk)
+    add('conv4_0', 'conv', 3, 4 * nk, 8 * nk); add('bn4', 'bn', 1, 8 * nk, 8 * nk)
+    add('deconv1_0', 'dtrans', 5, 8 * nk, 2 * nk, stride=2); add('bn5', 'bn', 1, 2 * nk, 2 * nk)
+    add('deconv2_0', 'dtrans', 5, 2 * nk, nk, stride=2); add('bn6', 'bn', 1, nk, nk)
+    add('deconv2_1', 'dtrans', 5, nk, nk, stride=2); add('bn7', 'bn', 1, nk, nk)
+    add('deconv3_0', 'up', 2, nk, n_classes); add('bn8', 'bn', 1, n_classes, n_classes)
+    add('conv_out', 'conv', 3, n_classes, n_classes, 'SAME', relu=False)
+    Ly['conv1_0'].need_dgrad = False
+    return [Ly[n] for n in BWD_ORDER]
+
+
+def deconv_sizes(H):
+    """spatial ladder for an (even) input edge H; raises when the all-VALID middle collapses"""
+    if H % 2:
+        raise Exception('DeconvModel needs even input sizes (got %d)' % H)
+    s = {'conv1_0': (H + 1) // 2}
+    s['pool1'] = s['conv1_0'] // 2
+    s['conv2_0'] = s['pool1'] - 2; s['pool2'] = s['conv2_0'] // 3
+    s['conv3_0'] = s['pool2'] - 2; s['pool3'] = s['conv3_0'] // 3
+    s['conv4_0'] = s['pool3'] - 2
+    if min(s.values()) < 1:
+        raise Exception('DeconvModel infeasible for input %d (needs >= 140): conv4_0 would see a %dx%d map' % (H, s['pool3'], s['pool3']))
+    s['deconv1_0'] = 2 * s['conv4_0'] + 3; s['deconv2_0'] = 2 * s['deconv1_0'] + 3; s['deconv2_1'] = 2 * s['deconv2_0'] + 3
+    s['resize'] = H // 2; s['deconv3_0'] = 2 * s['resize']
+    return s
+
+
+class DeconvModel(BaseModel):
+    def __init__(self,
+                 sess=None,
+                 n_classes=2,
+                 log_dir=None,
+                 dataset=None,
+                 save_dir=None,
+                 bayesian=False,
+                 input_dims=512,
+                 mode='TRAINING',
+                 input_channel=3,
+                 test_dataset=None,
+                 learning_rate=1e-4,
+                 load_snapshot=None,
+                 load_snapshot_from=None,
+                 n_kernels=32,
+                 autoencoder=False,
+                 adversarial_training=False,
+                 **mi355x):
+        super(DeconvModel, self).__init__(
+            sess=sess, mode=mode, log_dir=log_dir, dataset=dataset, bayesian=bayesian, save_dir=save_dir,
+            n_classes=n_classes, input_dims=input_dims, autoencoder=autoencoder, test_dataset=test_dataset,
+            input_channel=input_channel, load_snapshot=load_snapshot, learning_rate=learning_rate,
+            load_snapshot_from=load_snapshot_from, adversarial_training=adversarial_training, **mi355x)
+        self.model_name = 'deconvolution'
+        self.IN_OUT_EQUAL = True
+        self.n_kernels = n_kernels
+        if n_classes > 32:
+            raise Exception('n_classes > 32 not supported')
+        self.keep_prob, self.drop_seed = 0.5, self.seed
+        self._init_input()
+        training = self.mode != 'INFERENCE'
+        self.layers = deconv_layers(n_classes, n_kernels, input_channel)
+        self.store = E.ParamStore(self.layers, self.dtype, self.device, training=training)
+        self._xavier_init(GRAPH)
+        self.bn = None
+        self.net = None
+        if training:
+            self._build_training()
+        self._repack_initial()
+        self.inference_ops = ['y_hat_sig', 'output']
+        self._init_saver(self.model_name)
+
+    def model(self, input_op=None, reuse=False, training=True):
+        return self.fwd_plan if training else self.test_plan
+
+    # ---- batch-norm state (shared by every plan of this model) ----
+    def _bn_states(self, net):
+        if self.bn is None:
+            self.bn = {n: net.bn_state(self.store.layers[n]) for n in GRAPH if n.startswith('bn')}
+        return self.bn
+
+    def _state_blob(self):
+        out = {}
+        for n, st in (self.bn or {}).items():
+            c = self.store.layers[n].cout
+            cp = self.store.layers[n].cout_p
+            mv = st['moving'].cpu().numpy()
+            out[n + '/moving_mean'] = mv[:c].copy(); out[n + '/moving_variance'] = mv[cp:cp + c].copy()
+        return out
+
+    def _load_state(self, z):
+        if self.bn is None:
+            self._bn_states(self.net or E.Net(self.store, 1, self.dtype, self.device))
+        for n, st in self.bn.items():
+            if n + '/moving_mean' in z:
+                c, cp = self.store.layers[n].cout, self.store.layers[n].cout_p
+                mv = st['moving'].cpu().numpy()
+                mv[:c] = z[n + '/moving_mean']; mv[cp:cp + c] = z[n + '/moving_variance']
+                st['moving'].copy_(torch.from_numpy(mv))
+
+    def set_moving(self, moving):
+        """moving: {bn: (moving_mean, moving_variance)} (tests / interchange)"""
+        blob = {}
+        for n, (m_, v_) in moving.items():
+            blob[n + '/moving_mean'] = np.asarray(m_, np.float32); blob[n + '/moving_variance'] = np.asarray(v_, np.float32)
+        self._load_state(blob)
+
+    def get_moving(self):
+        """{bn: (moving_mean, moving_variance)} as numpy (tests / interchange)"""
+        return {n: (v[n + '/moving_mean'], v[n + '/moving_variance']) for v in [self._state_blob()] for n in self.bn}
+
+    # ---- forward graph (training / test / inference plans share it) ----
+    def _emit_forward(self, net, plan, x_in, H, W, bn_training, update_moving, dropout_step):
+        """dropout_step: True -> masks keyed by the device-side global step (train / test plans); False -> by a host offset
+        (ctypes c_uint64 in self._infer_off: one fresh mask per infer() call)"""
+        if H != W:
+            raise Exception('DeconvModel plans are built for square inputs (got %dx%d)' % (H, W))
+        Ly, nk = self.store.layers, self.n_kernels
+        sz = deconv_sizes(H)
+        bn = self._bn_states(net)
+        A, Y = {}, {}
+        xin = net.act(H, W, self.input_channel, name='x')
+        net.cast_pad(plan, x_in, xin)
+        net.join_aux(plan)                     # packed weights (re-packed on the aux stream in training) are needed from here on
+
+        def act_bn(name, a):
+            """ReLU output of `name` -> batch norm (-> dropout)"""
+            b = 'bn' + str(GRAPH.index(name) // 2 + 1)
+            A[name] = a
+            Y[b] = net.act(a.H, a.W, a.C, name=b)
+            net.bn_fwd(plan, Ly[b], bn[b], a, Y[b], training=bn_training, update_moving=update_moving)
+            out = Y[b]
+            if self.bayesian and b in DROP_SITES:
+                Y[b + '/drop'] = net.act(a.H, a.W, a.C, name=b + '/drop')
+                if dropout_step:
+                    net.dropout_step(plan, Y[b], Y[b + '/drop'], self.keep_prob, self.drop_seed + DROP_SITES[b], 0)
+                else:
+                    v, o = Y[b].view(), Y[b + '/drop'].view()
+                    plan.keep += [v, o]
+                    plan.add('dropout', net.lib.seg_dropout, E.C.byref(v), E.C.byref(o), net.B, a.H, a.W, a.Cp, float(self.keep_prob),
+                             int(self.drop_seed + DROP_SITES[b]), self._infer_off, net.dtype, kernel='dropout_kernel')
+                out = Y[b + '/drop']
+            return out
+
+        a = net.act(sz['conv1_0'], sz['conv1_0'], nk, name='conv1_0')
+        net.dlayer_fwd(plan, Ly['conv1_0'], xin, a)
+        t = act_bn('conv1_0', a)
+        P = {}
+        P[1] = net.act(sz['pool1'], sz['pool1'], nk, name='pool1'); net.pool_k_fwd(plan, t, P[1], 2)
+        for i, (cn, k) in enumerate((('conv2_0', 3), ('conv3_0', 3)), 2):
+            a = net.act(sz[cn], sz[cn], Ly[cn].cout, name=cn)
+            net.conv_fwd(plan, Ly[cn], [(P[i - 1], 0, 0)], P[i - 1].H, P[i - 1].W, a)
+            t = act_bn(cn, a)
+            P[i] = net.act(sz['pool%d' % i], sz['pool%d' % i], Ly[cn].cout, name='pool%d' % i); net.pool_k_fwd(plan, t, P[i], k)
+        a = net.act(sz['conv4_0'], sz['conv4_0'], Ly['conv4_0'].cout, name='conv4_0')
+        net.conv_fwd(plan, Ly['conv4_0'], [(P[3], 0, 0)], P[3].H, P[3].W, a)
+        t = act_bn('conv4_0', a)
+        for dn in ('deconv1_0', 'deconv2_0', 'deconv2_1'):
+            a = net.act(sz[dn], sz[dn], Ly[dn].cout, name=dn)
+            net.dlayer_fwd(plan, Ly[dn], t, a)
+            t = act_bn(dn, a)
+        R = net.act(sz['resize'], sz['resize'], Ly['deconv2_1'].cout, name='resize')
+        net.resize_fwd(plan, t, R)
+        a = net.act(sz['deconv3_0'], sz['deconv3_0'], self.n_classes, name='deconv3_0')
+        net.up_fwd(plan, Ly['deconv3_0'], R, R.H, R.W, a)
+        t = act_bn('deconv3_0', a)             # (resize_image_with_crop_or_pad to (H, W) is the identity for even H)
+        A['logits'] = net.act(H, W, self.n_classes, f32=True, name='logits')
+        net.conv_fwd(plan, Ly['conv_out'], [(t, 0, 0)], H, W, A['logits'], out_f32=True)
+        A['x'], A['resize'] = xin, R
+        return A, Y, P, sz
+
+    # ---- training plans ----
+    def _build_training(self):
+        B, (H, W) = self.batch_size, self.input_dims
+        net = self.net = E.Net(self.store, B, self.dtype, self.device)
+        net.n_wgrad_streams = max(1, len(self._side) - 1) if self._side else 1
+        Ly, nc = self.store.layers, self.n_classes
+        fwd = self.fwd_plan = E.Plan('fwd')
+        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+        net.step_begin(fwd, self.loss_buf)
+        net.pack(fwd, aux=True)
+        A, Y, P, sz = self._emit_forward(net, fwd, self.input_x, H, W, bn_training=True, update_moving=True, dropout_step=True)
+        self.acts, self.bn_out = A, Y
+        self.out_hw, self.label_off = (H, W), (0, 0)
+        dlog = net.act(H, W, nc, name='dlogits')
+        net.softmax_xent(fwd, A['logits'], self.input_y, H, W, (0, 0), H, W, nc, self.loss_buf, dlog)
+        self.dlogits = dlog
+        # the test() graph: moving averages, no update; dropout (if bayesian) stays on, exactly as in the reference's test graph
+        tnet = self.test_net = E.Net(self.store, B, self.dtype, self.device)
+        self.test_plan = E.Plan('test')
+        TA, _, _, _ = self._emit_forward(tnet, self.test_plan, self.input_x, H, W, bn_training=False, update_moving=False, dropout_step=True)
+        tdl = tnet.act(H, W, nc, name='dlogits_test')
+        tnet.softmax_xent(self.test_plan, TA['logits'], self.input_y, H, W, (0, 0), H, W, nc, self.loss_buf, tdl)
+
+        seg = E.Plan('bwd0')
+
+        def like(a, name):
+            return net.act(a.H, a.W, a.C, name=name)
+
+        G = {}
+
+        def bn_bwd(b, name, dy):
+            """gradient at the (dropout) output behind batch norm `b` -> masked pre-activation gradient of layer `name`"""
+            if self.bayesian and b in DROP_SITES:
+                d2 = like(Y[b], 'd_' + b)
+                net.dropout_step(seg, dy, d2, self.keep_prob, self.drop_seed + DROP_SITES[b], 0)
+                dy = d2
+            G[name] = like(A[name], 'dz_' + name)
+            net.bn_relu_bwd(seg, Ly[b], self.bn[b], A[name], dy, G[name])
+            return G[name]
+
+        last = lambda b: Y[b + '/drop'] if (self.bayesian and b in DROP_SITES) else Y[b]
+        # conv_out
+        dY8 = like(Y['bn8'], 'd_bn8')
+        net.conv_bwd(seg, Ly['conv_out'], [(Y['bn8'], 0, 0)], H, W, dlog, [(dY8, (0, 0), None, (0, 0))])
+        dz = bn_bwd('bn8', 'deconv3_0', dY8)
+        dR = like(A['resize'], 'd_resize')
+        net.up_bwd(seg, Ly['deconv3_0'], A['resize'], A['resize'].H, A['resize'].W, dz, dR, None)
+        d = like(Y['bn7'], 'd_bn7')
+        net.resize_bwd(seg, dR, d)
+        srcs = {'deconv2_1': 'bn6', 'deconv2_0': 'bn5', 'deconv1_0': 'bn4'}
+        for dn, b in (('deconv2_1', 'bn7'), ('deconv2_0', 'bn6'), ('deconv1_0', 'bn5')):
+            dz = bn_bwd(b, dn, d)
+            src = last(srcs[dn])
+            d = like(src, 'd_' + srcs[dn] + '_out')
+            net.dlayer_bwd(seg, Ly[dn], src, dz, dsrc=d, mask=None)
+        dz = bn_bwd('bn4', 'conv4_0', d)
+        dP = {3: like(P[3], 'dpool3')}
+        net.conv_bwd(seg, Ly['conv4_0'], [(P[3], 0, 0)], P[3].H, P[3].W, dz, [(dP[3], (0, 0), None, (0, 0))])
+        for i, (cn, b, k) in ((3, ('conv3_0', 'bn3', 3)), (2, ('conv2_0', 'bn2', 3))):
+            src = last(b)
+            d = like(src, 'd_' + b + '_out')
+            net.pool_k_bwd(seg, src, dP[i], d, k)
+            dz = bn_bwd(b, cn, d)
+            dP[i - 1] = like(P[i - 1], 'dpool%d' % (i - 1))
+            net.conv_bwd(seg, Ly[cn], [(P[i - 1], 0, 0)], P[i - 1].H, P[i - 1].W, dz, [(dP[i - 1], (0, 0), None, (0, 0))])
+        d = like(Y['bn1'], 'd_bn1')
+        net.pool_k_bwd(seg, Y['bn1'], dP[1], d, 2)
+        dz = bn_bwd('bn1', 'conv1_0', d)
+        net.dlayer_bwd(seg, Ly['conv1_0'], A['x'], dz, dsrc=None)
+        self.grads_act = G
+        net.flush_reduce(seg)
+        l = Ly['conv1_0']
+        self._finish_training_plans([(seg, l.b_off + l.nbias)])
+        self.y_hat = A['logits']
+
+    def test(self):
+        """moving-average graph on a held-out batch, mean x-entropy (models/basemodel.py:397,420-421,506-518)"""
+        if self.mode == 'INFERENCE':
+            print('test() with INFERENCE mode invalid')
+            return
+        ds = self.test_dataset if self.test_dataset is not None else self.dataset
+        train_loss = self.loss_buf.clone()
+        if self._packed_dirty:
+            self._repack()                 # the MFMA layers read the packed copy, which train_step refreshes at the head of the NEXT step
+        self._load_batch(ds, self.input_x, self.input_y)           # (the test plan reads the model's own input buffers)
+        self.loss_buf.zero_()
+        self.test_plan.run(self._stream())
+        self.last_test_loss = float(self.loss_buf.item())
+        self.loss_buf.copy_(train_loss)
+        print('TEST LOSS', self.last_test_loss, self.global_step)
+        self.write_summary({'test_loss': self.last_test_loss})
+
+    # ---- inference: the reference feeds the TRAINING graph (batch statistics; dropout on when bayesian) ----
+    def _build_infer(self, B, H, W, Cin):
+        if Cin != self.input_channel:
+            raise Exception('infer(): expected %d input channels, got %d' % (self.input_channel, Cin))
+        import ctypes as C
+        net = E.Net(self.store, B, self.dtype, self.device)
+        plan = E.Plan('infer')
+        x_in = torch.zeros((B, H, W, Cin), dtype=torch.float32, device=self.device)
+        if not hasattr(self, '_infer_off'):
+            self._infer_off = C.c_uint64(0)
+        plan.keep.append(self._infer_off)
+        A, _, _, _ = self._emit_forward(net, plan, x_in, H, W, bn_training=True, update_moving=False, dropout_step=False)
+        sig = torch.zeros((B, H, W, self.n_classes), dtype=torch.float32, device=self.device)
+        out = torch.zeros((B, H, W, 1), dtype=torch.float32, device=self.device)
+        net.sigmoid_argmax(plan, A['logits'], H, W, self.n_classes, sig, out)
+        plan.net, plan.acts = net, A
+        return plan, x_in, sig, out
+
+    def infer(self, imgs, dropout_offset=None):
+        """[sigmoid, argmax] of ONE pass of the training graph; with `bayesian` every call draws fresh dropout masks (counter
+        offset = call number << 40, or `dropout_offset` when given: tests replay a known mask)."""
+        if not hasattr(self, '_infer_off'):
+            import ctypes as C
+            self._infer_off = C.c_uint64(0)
+            self._infer_calls = 0
+        self._infer_calls = getattr(self, '_infer_calls', 0) + 1
+        self._infer_off.value = (self._infer_calls << 40) if dropout_offset is None else int(dropout_offset)
+        return super(DeconvModel, self).infer(imgs)

@@ -38,22 +38,35 @@ class Act(object):
 
 
 class Layer(object):
-    """One weighted layer.  kind: 'first' (3x3, raw float input), 'conv' (k x k), 'up' (2x2/s2 transposed)."""
+    """One trainable layer.  kind: 'first' (3x3, raw float input), 'conv' (k x k stride 1, MFMA tiles), 'up' (2x2/s2 transposed,
+    MFMA tiles), 'direct' (k x k conv of any stride on the direct kernels), 'dtrans' (k x k transposed conv of any stride on
+    the direct kernels, filter [kh,kw,Cout,Cin]), 'bn' (slim.batch_norm with its defaults: a beta vector, no gamma)."""
 
-    def __init__(self, name, kind, k, cin_segs, cout, padding='VALID', relu=True):
-        self.name, self.kind, self.k, self.cout, self.padding, self.relu = name, kind, k, cout, padding, relu
+    def __init__(self, name, kind, k, cin_segs, cout, padding='VALID', relu=True, stride=1):
+        self.name, self.kind, self.k, self.cout, self.padding, self.relu, self.stride = name, kind, k, cout, padding, relu, stride
         self.cin_segs = list(cin_segs)                       # logical channels of each concat segment
         self.cin = sum(self.cin_segs)
         self.cin_p = [rup(c) for c in self.cin_segs]
         self.cout_p = rup(cout)
-        if kind == 'up':
-            self.wshape = (2, 2, cout, self.cin)              # TF conv2d_transpose filter layout
+        self.nbias = cout
+        self.wname, self.bname = 'weights', 'biases'
+        if kind in ('up', 'dtrans'):
+            self.wshape = (k, k, cout, self.cin)              # TF conv2d_transpose filter layout
+        elif kind == 'bn':
+            self.wshape = (cout,)                             # beta
+            self.nbias = 0
+            self.wname = 'beta'
         else:
             self.wshape = (k, k, self.cin, cout)              # HWIO
         self.pad = 0 if padding == 'VALID' else (k - 1) // 2  # TF SAME, odd k, stride 1: before = (k-1)//2
         self.w_off = self.b_off = -1
         self.pk_fwd = self.pk_dgrad = -1
         self.need_dgrad = True
+
+    @property
+    def packed(self):
+        """layers with a packed MFMA-operand copy of their weights"""
+        return self.kind in ('conv', 'up')
 
     @property
     def wsize(self):
@@ -72,7 +85,7 @@ class ParamStore(object):
         off = 0
         for l in layers:
             l.w_off = off; off += l.wsize
-            l.b_off = off; off += l.cout
+            l.b_off = off; off += l.nbias
         self.n = off
         self.p = torch.zeros(off, dtype=torch.float32, device=device)
         if training:
@@ -83,7 +96,7 @@ class ParamStore(object):
         # packed arena + table
         entries, poff, blk = [], 0, 0
         for l in layers:
-            if l.kind == 'first':
+            if not l.packed:
                 continue
             seg0, seg1 = l.cin_segs[0], (l.cin_segs[1] if len(l.cin_segs) > 1 else 0)
             seg0p, seg1p = l.cin_p[0], (l.cin_p[1] if len(l.cin_p) > 1 else 0)
@@ -121,10 +134,10 @@ class ParamStore(object):
                 nxt = entries[i + 1] if i + 1 < len(entries) else None
                 dg.append(nxt.dst_off if nxt is not None and nxt.src_off == e.src_off and nxt.mode in (L.PACK_CONV_DGRAD, L.PACK_UP_DGRAD) else -1)
                 fwd.append(f)
-            firsts = [l for l in layers if l.kind == 'first']
-            lo = min([l.w_off for l in firsts] or [0]); hi = max([l.b_off + l.cout for l in firsts] or [0])
-            covered = sum(l.wsize + l.cout for l in layers if l.kind != 'first') + (hi - lo)
-            if covered == off and sum(l.wsize + l.cout for l in firsts) == hi - lo:
+            firsts = [l for l in layers if not l.packed]
+            lo = min([l.w_off for l in firsts] or [0]); hi = max([l.b_off + l.nbias for l in firsts] or [0])
+            covered = sum(l.wsize + l.nbias for l in layers if l.packed) + (hi - lo)
+            if covered == off and sum(l.wsize + l.nbias for l in firsts) == hi - lo:
                 self.adam_pack = (torch.frombuffer(bytearray(b''.join(bytes(f) for f in fwd)), dtype=torch.uint8).to(device),
                                   torch.tensor(dg, dtype=torch.int64, device=device), len(fwd), tiles, lo, hi - lo)
         if entries:
@@ -144,23 +157,27 @@ class ParamStore(object):
         return self.g.data_ptr() + off * 4
 
     def set_params(self, params):
-        """params: {name: {'weights': ndarray, 'biases': ndarray}} in TF layouts."""
+        """params: {name: {'weights': ndarray, 'biases': ndarray}} in TF layouts ({'beta': ndarray} for a batch norm)."""
         host = self.p.cpu().numpy().copy()
         for name, l in self.layers.items():
-            w = np.asarray(params[name]['weights'], np.float32)
-            b = np.asarray(params[name]['biases'], np.float32)
-            if tuple(w.shape) != tuple(l.wshape) or b.shape != (l.cout,):
+            w = np.asarray(params[name][l.wname], np.float32)
+            if tuple(w.shape) != tuple(l.wshape):
                 raise ValueError('shape mismatch for %s: %s vs %s' % (name, w.shape, l.wshape))
             host[l.w_off:l.w_off + l.wsize] = w.reshape(-1)
-            host[l.b_off:l.b_off + l.cout] = b
+            if l.nbias:
+                b = np.asarray(params[name][l.bname], np.float32)
+                if b.shape != (l.nbias,):
+                    raise ValueError('shape mismatch for %s biases: %s vs %s' % (name, b.shape, (l.nbias,)))
+                host[l.b_off:l.b_off + l.nbias] = b
         self.p.copy_(torch.from_numpy(host))
 
     def _unflatten(self, flat):
         host = flat.detach().cpu().numpy()
         out = {}
         for name, l in self.layers.items():
-            out[name] = {'weights': host[l.w_off:l.w_off + l.wsize].reshape(l.wshape).copy(),
-                         'biases': host[l.b_off:l.b_off + l.cout].copy()}
+            out[name] = {l.wname: host[l.w_off:l.w_off + l.wsize].reshape(l.wshape).copy()}
+            if l.nbias:
+                out[name][l.bname] = host[l.b_off:l.b_off + l.nbias].copy()
         return out
 
     def get_params(self):
@@ -823,6 +840,137 @@ class Net(object):
         plan.keep += [gv, sv, filt]
         plan.add('bilinear_up%d/bwd' % factor, self.lib.seg_bilinear_up_bwd, C.byref(gv), Hd, Wd, cy, cx, factor, filt.data_ptr(),
                  C.byref(sv), Hs, Ws, self.B, dsrc.Cp, 0, self.dtype, kernel='bilinear_bwd_kernel')
+
+    # ---------------- DeconvModel ops (models/deconvolution.py:101-178) ----------------
+    def _dconv_desc(self, layer, big, small, mask=None, bias=False, relu=False):
+        """descriptor of a direct-kernel layer.  'direct' (conv): x = input (k = Cin), y = output (n = Cout);
+        'dtrans' (transposed conv): x = the LARGE map (k = Cout), y = the small map (n = Cin) -- include/seg_hip.h."""
+        d = L.DconvDesc()
+        d.x = big.view(); d.y = small.view()
+        d.B, d.Hx, d.Wx, d.Hy, d.Wy = self.B, big.H, big.W, small.H, small.W
+        k, s_ = layer.k, layer.stride
+        d.KH = d.KW = k; d.stride = s_
+        if layer.kind == 'direct':
+            d.xc, d.yc = layer.cin, layer.cout
+            if layer.padding == 'SAME':              # TF: out = ceil(in/s); pad_total = max((out-1)s + k - in, 0); before = total // 2
+                d.pad_t = max((small.H - 1) * s_ + k - big.H, 0) // 2
+                d.pad_l = max((small.W - 1) * s_ + k - big.W, 0) // 2
+            else:
+                d.pad_t = d.pad_l = 0
+            d.w_sk = layer.cout
+        else:
+            d.xc, d.yc = layer.cout, layer.cin
+            d.pad_t = d.pad_l = 0                    # slim.convolution2d_transpose(padding='VALID'): out = in*s + max(k - s, 0)
+            d.w_sk = layer.cin
+        d.w_sv = layer.wshape[2] * layer.wshape[3]; d.w_su = k * d.w_sv
+        d.w = self.store.p_ptr(layer.w_off)
+        d.bias = self.store.p_ptr(layer.b_off) if bias else None
+        d.bias_n = layer.cout if bias else 0
+        d.relu = 1 if relu else 0
+        d.mask = mask.view() if mask is not None else L.null_view()
+        d.dtype = self.dtype
+        return d
+
+    def dlayer_fwd(self, plan, layer, src, dst):
+        """forward of a 'direct' conv (src -> dst) or a 'dtrans' transposed conv (small src -> large dst), bias + ReLU"""
+        k = layer.k
+        if layer.kind == 'direct':
+            d = self._dconv_desc(layer, src, dst, bias=True, relu=layer.relu)
+            fn, kern = self.lib.seg_dconv_fwd, 'dconv_fwd_kernel'
+            fl = 2 * self.B * dst.H * dst.W * k * k * layer.cin * layer.cout
+        else:
+            d = self._dconv_desc(layer, dst, src, bias=True, relu=layer.relu)
+            fn, kern = self.lib.seg_dconv_bwd_data, 'dconv_bwd_data_kernel'
+            fl = 2 * self.B * src.H * src.W * k * k * layer.cin * layer.cout
+        plan.keep.append(d)
+        plan.add(layer.name, fn, C.byref(d), kernel=kern, flops=fl)
+        plan.flops += fl
+
+    def dlayer_bwd(self, plan, layer, src, dz, dsrc=None, mask=None):
+        """filter / bias gradient of a direct-kernel layer from its masked output gradient dz, then (dsrc given) the input
+        gradient, optionally masked by `mask` (the ReLU output that produced src)"""
+        k = layer.k
+        if layer.kind == 'direct':
+            d = self._dconv_desc(layer, src, dz)
+            d.bias_n = layer.cout
+            mode, fl = 1, 2 * self.B * dz.H * dz.W * k * k * layer.cin * layer.cout
+        else:
+            d = self._dconv_desc(layer, dz, src)
+            d.bias_n = layer.cout
+            mode, fl = 2, 2 * self.B * src.H * src.W * k * k * layer.cin * layer.cout
+        plan.keep.append(d)
+        plan.add(layer.name + '/dw', self.lib.seg_dconv_wgrad, C.byref(d), self.store.g_ptr(layer.w_off), self.store.g_ptr(layer.b_off), mode,
+                 kernel='dconv_wgrad_kernel', flops=fl)
+        plan.flops += fl
+        if dsrc is None:
+            return
+        if layer.kind == 'direct':
+            d2 = self._dconv_desc(layer, dsrc, dz, mask=mask)
+            fn, kern = self.lib.seg_dconv_bwd_data, 'dconv_bwd_data_kernel'
+        else:
+            d2 = self._dconv_desc(layer, dz, dsrc, mask=mask)
+            fn, kern = self.lib.seg_dconv_fwd, 'dconv_fwd_kernel'
+        plan.keep.append(d2)
+        plan.add(layer.name + '/dx', fn, C.byref(d2), kernel=kern, flops=fl)
+        plan.flops += fl
+
+    def bn_state(self, layer):
+        """device state of one batch norm: moving [mean | variance], batch stats [mean | rstd], reduction workspace"""
+        Cp = layer.cout_p
+        mov = torch.zeros(2 * Cp, dtype=torch.float32, device=self.device); mov[Cp:] = 1.0
+        stats = torch.zeros(2 * Cp, dtype=torch.float32, device=self.device)
+        ws = torch.zeros(self.lib.seg_bn_ws_bytes(Cp) // 4, dtype=torch.float32, device=self.device)
+        return {'moving': mov, 'stats': stats, 'ws': ws}
+
+    def bn_fwd(self, plan, layer, st, a, y, training=True, update_moving=True, decay=0.999, eps=1e-3):
+        av, yv = a.view(), y.view()
+        plan.keep += [av, yv, st]
+        mov = st['moving'].data_ptr() if (update_moving or not training) else None
+        plan.add(layer.name, self.lib.seg_bn_fwd, C.byref(av), C.byref(yv), self.store.p_ptr(layer.w_off), mov, st['stats'].data_ptr(),
+                 1 if training else 0, decay, eps, self.B, a.H, a.W, a.Cp, layer.cout, st['ws'].data_ptr(), self.dtype, kernel='bn_apply_kernel')
+
+    def bn_relu_bwd(self, plan, layer, st, a, dy, dz):
+        av, gv, zv = a.view(), dy.view(), dz.view()
+        plan.keep += [av, gv, zv, st]
+        plan.add(layer.name + '/bwd', self.lib.seg_bn_relu_bwd, C.byref(av), C.byref(gv), C.byref(zv), st['stats'].data_ptr(),
+                 self.store.g_ptr(layer.w_off), self.B, a.H, a.W, a.Cp, layer.cout, st['ws'].data_ptr(), self.dtype, kernel='bn_apply_kernel')
+
+    def pool_k_fwd(self, plan, src, dst, k):
+        sv, dv = src.view(), dst.view()
+        plan.keep += [sv, dv]
+        plan.add('pool%d' % k, self.lib.seg_maxpool_k_fwd, C.byref(sv), C.byref(dv), k, self.B, dst.H, dst.W, src.Cp, self.dtype, kernel='maxpool_k_fwd_kernel')
+
+    def pool_k_bwd(self, plan, src, dpool, dsrc, k):
+        sv, pv, dv = src.view(), dpool.view(), dsrc.view()
+        plan.keep += [sv, pv, dv]
+        plan.add('pool%d/bwd' % k, self.lib.seg_maxpool_k_bwd, C.byref(sv), C.byref(pv), C.byref(dv), k, self.B, src.H, src.W, src.Cp, self.dtype,
+                 kernel='maxpool_k_bwd_kernel')
+
+    def resize_fwd(self, plan, src, dst):
+        sv, dv = src.view(), dst.view()
+        plan.keep += [sv, dv]
+        plan.add('resize', self.lib.seg_resize_bilinear_fwd, C.byref(sv), src.H, src.W, C.byref(dv), dst.H, dst.W, self.B, src.Cp, self.dtype,
+                 kernel='resize_fwd_kernel')
+
+    def resize_bwd(self, plan, ddst, dsrc):
+        gv, sv = ddst.view(), dsrc.view()
+        plan.keep += [gv, sv]
+        plan.add('resize/bwd', self.lib.seg_resize_bilinear_bwd, C.byref(gv), ddst.H, ddst.W, C.byref(sv), dsrc.H, dsrc.W, self.B, dsrc.Cp, self.dtype,
+                 kernel='resize_bwd_kernel')
+
+    def dropout_step(self, plan, src, dst, keep, seed, offset):
+        """training-time slim.dropout: the mask is a function of (seed, offset, global step read on the device); the backward
+        launch (gradient in, gradient out, same arguments) regenerates it"""
+        sv, dv = src.view(), dst.view()
+        plan.keep += [sv, dv]
+        plan.add('dropout', self.lib.seg_dropout_step, C.byref(sv), C.byref(dv), self.B, src.H, src.W, src.Cp, float(keep), int(seed), int(offset),
+                 self.store.step.data_ptr() + 8, self.dtype, kernel='dropout_kernel')
+
+    def cast_pad(self, plan, x_f32, dst):
+        """float32 NHWC image -> activation buffer (compute dtype, channels padded)"""
+        dv = dst.view()
+        plan.keep.append(dv)
+        plan.add('cast_pad', self.lib.seg_cast_pad, x_f32.data_ptr(), self.B * dst.H * dst.W, dst.C, C.byref(dv), self.dtype, kernel='cast_pad_kernel')
 
     # ---------------- loss / outputs / update ----------------
     def softmax_xent(self, plan, logits, labels_u8, LH, LW, loff, H, W, n_classes, loss_buf, dlogits):

@@ -218,7 +218,7 @@ class FCNModel(BaseModel):
         net.conv_bwd(seg, Ly['conv6'], [(A['pool5'], 0, 0)], fr.H, fr.W, dz6, [(dP[5], (0, 0), None, (0, 0))])
         l = Ly['conv6']
         net.flush_reduce(seg)
-        segs.append((seg, l.b_off + l.cout))
+        segs.append((seg, l.b_off + l.nbias))
         seg = E.Plan('bwd1')
         for i in (5, 4, 3, 2, 1):
             name = 'conv%d' % i
@@ -235,7 +235,7 @@ class FCNModel(BaseModel):
             net.conv_bwd(seg, Ly[name], [(pin, 0, 0)], pin.H, pin.W, dz, [(dP[i - 1], (0, 0), None, (0, 0), shared is not None)])
         l = Ly['conv1']
         net.flush_reduce(seg)
-        segs.append((seg, l.b_off + l.cout))
+        segs.append((seg, l.b_off + l.nbias))
         self._finish_training_plans(segs)
         self.y_hat = A['logits']
 

@@ -261,7 +261,7 @@ class UNetModel(BaseModel):
                 return
             l = Ly[last_layer]
             net.flush_reduce(seg)             # one slab-reduction launch per segment
-            segs.append((seg, l.b_off + l.cout))
+            segs.append((seg, l.b_off + l.nbias))
             seg = E.Plan('bwd%d' % len(segs))
 
         # output layer

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 18
     for n in names:
         assert hasattr(lib, n), n
-    bound = set(_lib.SIGNATURES) | {'seg_last_error', 'seg_version'}
+    bound = set(_lib.SIGNATURES) | {'seg_last_error', 'seg_version', 'seg_bn_ws_bytes'}
     assert bound == set(names)
     assert _lib.load().seg_version() == 100
 
@@ -34,14 +34,16 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_struct_layouts_match_c(tmp_path):
     from segmentation_amd import _lib
     src = tmp_path / 's.c'
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "seg_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "seg_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(seg_view),sizeof(seg_conv_desc),sizeof(seg_wgrad_desc),sizeof(seg_pack_entry),'
-                   'offsetof(seg_conv_desc,dst),offsetof(seg_conv_desc,cfg),offsetof(seg_wgrad_desc,dw));return 0;}')
+                   'offsetof(seg_conv_desc,dst),offsetof(seg_conv_desc,cfg),offsetof(seg_wgrad_desc,dw),'
+                   'sizeof(seg_dconv_desc),offsetof(seg_dconv_desc,w),offsetof(seg_dconv_desc,mask));return 0;}')
     exe = tmp_path / 's'
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     got = list(map(int, subprocess.check_output([str(exe)]).split()))
     want = [ctypes.sizeof(_lib.View), ctypes.sizeof(_lib.ConvDesc), ctypes.sizeof(_lib.WgradDesc), ctypes.sizeof(_lib.PackEntry),
-            _lib.ConvDesc.dst.offset, _lib.ConvDesc.cfg.offset, _lib.WgradDesc.dw.offset]
+            _lib.ConvDesc.dst.offset, _lib.ConvDesc.cfg.offset, _lib.WgradDesc.dw.offset,
+            ctypes.sizeof(_lib.DconvDesc), _lib.DconvDesc.w.offset, _lib.DconvDesc.mask.offset]
     assert got == want
 
 

@@ -1,0 +1,320 @@
+"""-m gpu parity tests of SURVEY 8(f) row N3: DeconvModel (models/deconvolution.py:101-178) -- its extra kernels one by one
+(direct 5x5 stride-2 conv / transposed conv, k x k max-pool, batch norm fused with the ReLU-grad, bilinear resize) and the
+model's train_step() / test() / infer() through the C-ABI against oracle/deconv.py on identical weights and inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ops as ops
+from oracle import deconv as odec
+from segmentation_amd import _lib as L
+from segmentation_amd import engine as E
+from segmentation_amd.datasets import ArrayDataSet
+from segmentation_amd.deconvolution import DeconvModel
+import gpu_util as U
+
+pytestmark = pytest.mark.gpu
+DT = [L.SEG_F32, L.SEG_BF16]
+
+
+def _store(layers, dtype, rng):
+    p = {}
+    for l in layers:
+        p[l.name] = {l.wname: (rng.standard_normal(l.wshape) * 0.2).astype(np.float32)}
+        if l.nbias:
+            p[l.name][l.bname] = (rng.standard_normal(l.nbias) * 0.1).astype(np.float32)
+    store = E.ParamStore(layers, dtype, U.dev(), training=True)
+    store.set_params(p)
+    return store, p
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('case', [('direct', 5, 2, 'SAME', 3, 16, 21, 24, 2), ('direct', 5, 2, 'SAME', 3, 40, 16, 16, 1),
+                                  ('direct', 3, 1, 'VALID', 12, 8, 9, 11, 2), ('dtrans', 5, 2, 'VALID', 24, 8, 5, 7, 2),
+                                  ('dtrans', 5, 2, 'VALID', 64, 32, 3, 3, 1), ('dtrans', 2, 2, 'VALID', 8, 3, 6, 5, 2)])
+def test_direct_conv_kernels(dtype, case):
+    kind, k, s, padding, cin, cout, H, W, B = case
+    rng = np.random.default_rng(k * 100 + cin + cout + H)
+    layer = E.Layer('c', kind, k, [cin], cout, padding, True, s)
+    store, p = _store([layer], dtype, rng)
+    net = E.Net(store, B, dtype, U.dev())
+    xv = U.round_dtype(rng.standard_normal((B, H, W, cin)), dtype)
+    xa = net.act(H, W, cin); U.fill_act(xa, xv)
+    w, b = p['c']['weights'].astype(np.float64), p['c']['biases'].astype(np.float64)
+    if kind == 'direct':
+        ref = ops.conv2d(xv, w, b, padding, s, True)
+    else:
+        ref = ops.conv2d_transpose(xv, w, b, s, 'VALID', True)
+    Ho, Wo = ref.shape[1:3]
+    out = net.act(Ho, Wo, cout)
+    out.t.fill_(7.0)                                          # pad channels must be rewritten as zero
+    plan = E.Plan('f'); net.dlayer_fwd(plan, layer, xa, out); plan.run(U.stream()); U.sync()
+    assert U.rel_err(U.read_act(out), ref) < U.tol(dtype, 2e-5, 1e-2), 'fwd'
+    assert U.pad_channels_zero(out)
+    dzv = U.round_dtype(rng.standard_normal(ref.shape) * 0.5, dtype)
+    dz = net.act(Ho, Wo, cout); U.fill_act(dz, dzv)
+    mv = U.round_dtype(rng.standard_normal(xv.shape), dtype)
+    mk = net.act(H, W, cin); U.fill_act(mk, mv)
+    dx = net.act(H, W, cin)
+    store.g.fill_(float('nan'))
+    bp = E.Plan('b'); net.dlayer_bwd(bp, layer, xa, dz, dsrc=dx, mask=mk); bp.run(U.stream()); U.sync()
+    if kind == 'direct':
+        dw_ref, db_ref = ops.conv2d_wgrad(xv, dzv, (k, k), padding, s)
+        dx_ref = ops.conv2d_dgrad(dzv, w, (H, W), padding, s)
+    else:
+        dw_ref, db_ref = ops.conv2d_transpose_wgrad(xv, dzv, (k, k), s, 'VALID')
+        dx_ref = ops.conv2d_transpose_dgrad(dzv, w, (H, W), s, 'VALID')
+    g = store.get_grads()['c']
+    assert U.rel_err(g['weights'], dw_ref) < U.tol(dtype, 2e-5, 1e-2), 'wgrad'
+    assert U.rel_err(g['biases'], db_ref) < U.tol(dtype, 2e-5, 1e-2), 'bias grad'
+    assert U.rel_err(U.read_act(dx), dx_ref * (mv > 0)) < U.tol(dtype, 2e-5, 1e-2), 'dgrad'
+    g1 = store.g.clone(); bp.run(U.stream()); U.sync()
+    assert torch.equal(g1, store.g)                           # fixed summation order
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('k,H,W,Cc', [(2, 9, 8, 16), (3, 14, 11, 40), (3, 9, 9, 8)])
+def test_maxpool_k(dtype, k, H, W, Cc):
+    B = 2
+    rng = np.random.default_rng(k + H)
+    net = E.Net(None, B, dtype, U.dev())
+    xv = U.round_dtype(rng.standard_normal((B, H, W, Cc)), dtype)
+    xv[0, :k, :k, 0] = 0.25                                   # a tie inside one window: the first position wins
+    xa = net.act(H, W, Cc); U.fill_act(xa, xv)
+    ya = net.act(H // k, W // k, Cc)
+    plan = E.Plan('p'); net.pool_k_fwd(plan, xa, ya, k); plan.run(U.stream()); U.sync()
+    yref, idx = ops.max_pool_k(xv, k)
+    assert np.array_equal(U.read_act(ya), yref)
+    dyv = U.round_dtype(rng.standard_normal(yref.shape), dtype)
+    dy = net.act(H // k, W // k, Cc); U.fill_act(dy, dyv)
+    dx = net.act(H, W, Cc); dx.t.fill_(5.0)
+    bp = E.Plan('b'); net.pool_k_bwd(bp, xa, dy, dx, k); bp.run(U.stream()); U.sync()
+    assert np.array_equal(U.read_act(dx), ops.max_pool_k_bwd(dyv, idx, (H, W), k))
+    assert U.pad_channels_zero(dx)
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('B,H,W,Cc', [(2, 13, 11, 8), (3, 40, 37, 40), (1, 5, 5, 256), (16, 64, 64, 32)])
+def test_batch_norm_fwd_bwd(dtype, B, H, W, Cc):
+    rng = np.random.default_rng(H + Cc)
+    layer = E.Layer('bn', 'bn', 1, [Cc], Cc)
+    store, p = _store([layer], dtype, rng)
+    net = E.Net(store, B, dtype, U.dev())
+    av = np.maximum(U.round_dtype(rng.standard_normal((B, H, W, Cc)) + 0.3, dtype), 0)      # a ReLU output
+    a = net.act(H, W, Cc); U.fill_act(a, av)
+    y = net.act(H, W, Cc); y.t.fill_(3.0)
+    st = net.bn_state(layer)
+    mm0 = rng.standard_normal(Cc).astype(np.float32) * 0.1; mv0 = (rng.uniform(0.5, 1.5, Cc)).astype(np.float32)
+    Cp = layer.cout_p
+    mov = st['moving'].cpu().numpy(); mov[:Cc] = mm0; mov[Cp:Cp + Cc] = mv0; st['moving'].copy_(torch.from_numpy(mov))
+    beta = p['bn']['beta'].astype(np.float64)
+    plan = E.Plan('f'); net.bn_fwd(plan, layer, st, a, y, training=True, update_moving=True); plan.run(U.stream()); U.sync()
+    yref, cache, nm, nv = ops.batch_norm(av, beta, mm0, mv0, True)
+    tol = 1e-5 if dtype == L.SEG_F32 else 2e-2
+    assert np.abs(U.read_act(y) - yref).max() < tol * max(1.0, np.abs(yref).max())
+    assert U.pad_channels_zero(y)
+    mov = st['moving'].cpu().numpy()
+    assert np.abs(mov[:Cc] - nm).max() < 1e-6 and np.abs(mov[Cp:Cp + Cc] - nv).max() < 1e-6
+    # backward (training statistics), fused with the ReLU-grad mask of `a`
+    dyv = U.round_dtype(rng.standard_normal(av.shape), dtype)
+    dy = net.act(H, W, Cc); U.fill_act(dy, dyv)
+    dz = net.act(H, W, Cc); dz.t.fill_(2.0)
+    store.g.fill_(float('nan'))
+    bp = E.Plan('b'); net.bn_relu_bwd(bp, layer, st, a, dy, dz); bp.run(U.stream()); U.sync()
+    dref, dbeta = ops.batch_norm_bwd(dyv, cache)
+    dref = dref * (av > 0)
+    assert np.abs(U.read_act(dz) - dref).max() < (2e-5 if dtype == L.SEG_F32 else 3e-2) * max(1.0, np.abs(dref).max())
+    assert U.rel_err(store.get_grads()['bn']['beta'], dbeta) < (1e-5 if dtype == L.SEG_F32 else 1e-2)
+    assert U.pad_channels_zero(dz)
+    # inference statistics (the test() graph): moving averages, nothing updated
+    before = st['moving'].clone()
+    ip = E.Plan('i'); net.bn_fwd(ip, layer, st, a, y, training=False, update_moving=False); ip.run(U.stream()); U.sync()
+    yinf, _, _, _ = ops.batch_norm(av, beta, mov[:Cc], mov[Cp:Cp + Cc], False)
+    assert np.abs(U.read_act(y) - yinf).max() < tol * max(1.0, np.abs(yinf).max())
+    assert torch.equal(before, st['moving'])
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('Hs,Ws,Hd,Wd,Cc', [(13, 13, 32, 32, 8), (29, 29, 80, 80, 16), (9, 12, 9, 12, 8), (20, 16, 7, 5, 40), (5, 7, 11, 9, 8)])
+def test_resize_bilinear(dtype, Hs, Ws, Hd, Wd, Cc):
+    B = 2
+    rng = np.random.default_rng(Hs * 7 + Hd)
+    net = E.Net(None, B, dtype, U.dev())
+    xv = U.round_dtype(rng.standard_normal((B, Hs, Ws, Cc)), dtype)
+    xa = net.act(Hs, Ws, Cc); U.fill_act(xa, xv)
+    ya = net.act(Hd, Wd, Cc)
+    plan = E.Plan('r'); net.resize_fwd(plan, xa, ya); plan.run(U.stream()); U.sync()
+    ref = ops.resize_bilinear(xv, (Hd, Wd))
+    # independent loop restatement of TF's legacy kernel on a few pixels
+    sy, sx = np.float32(Hs) / np.float32(Hd), np.float32(Ws) / np.float32(Wd)
+    for (yy, xx) in ((0, 0), (Hd - 1, Wd - 1), (Hd // 2, Wd // 3)):
+        fy, fx = np.float32(yy) * sy, np.float32(xx) * sx
+        y0, x0 = int(np.floor(fy)), int(np.floor(fx)); y1, x1 = min(y0 + 1, Hs - 1), min(x0 + 1, Ws - 1)
+        ly, lx = float(fy - np.floor(fy)), float(fx - np.floor(fx))
+        top = xv[:, y0, x0] + (xv[:, y0, x1] - xv[:, y0, x0]) * lx; bot = xv[:, y1, x0] + (xv[:, y1, x1] - xv[:, y1, x0]) * lx
+        assert np.allclose(ref[:, yy, xx], top + (bot - top) * ly, atol=1e-12)
+    assert np.abs(U.read_act(ya) - ref).max() < (1e-5 if dtype == L.SEG_F32 else 2e-2) * max(1.0, np.abs(ref).max())
+    dyv = U.round_dtype(rng.standard_normal(ref.shape), dtype)
+    dy = net.act(Hd, Wd, Cc); U.fill_act(dy, dyv)
+    dx = net.act(Hs, Ws, Cc)
+    bp = E.Plan('b'); net.resize_bwd(bp, dy, dx); bp.run(U.stream()); U.sync()
+    dref = ops.resize_bilinear_bwd(dyv, (Hs, Ws))
+    assert np.abs(U.read_act(dx) - dref).max() < (2e-5 if dtype == L.SEG_F32 else 3e-2) * max(1.0, np.abs(dref).max())
+
+
+# ------------------------------------------------------------------------------------------------------------- model level
+def _data(B, S, nc, seed=5555, n=1):
+    rng = np.random.default_rng(seed)
+    return (rng.uniform(0, 1, (n, B, S, S, 3)).astype(np.float32), rng.integers(0, nc, (n, B, S, S, 1)).astype(np.uint8))
+
+
+def _model(x, y, nc, S, dtype, nk=8, **kw):
+    kw.setdefault('learning_rate', 1e-3)
+    return DeconvModel(sess=None, dataset=ArrayDataSet(x, y), n_classes=nc, input_dims=S, n_kernels=nk, log_dir=None, save_dir=None,
+                       load_snapshot=False, dtype=dtype, seed=5555, **kw)
+
+
+def _oracle_params(m, rng=None):
+    """the model's parameters in the oracle's format (+ randomised biases / betas / moving averages so nothing is trivially 0)"""
+    p = m.store.get_params()
+    mov = m.get_moving()
+    for n in p:
+        if rng is not None:
+            for k in ('biases', 'beta'):
+                if k in p[n]:
+                    p[n][k] = (rng.standard_normal(p[n][k].shape) * 0.05).astype(np.float32)
+        if n in mov:
+            if rng is not None:
+                mov[n] = ((rng.standard_normal(mov[n][0].shape) * 0.1).astype(np.float32), rng.uniform(0.5, 1.5, mov[n][1].shape).astype(np.float32))
+            p[n]['moving_mean'], p[n]['moving_variance'] = mov[n]
+    if rng is not None:
+        m.set_weights(p); m.set_moving(mov)
+    return p
+
+
+def _grads_close(g, g_ref, rtol):
+    for n in g_ref:
+        for k in g_ref[n]:
+            ref = np.asarray(g_ref[n][k])
+            err = np.abs(g[n][k] - ref).max() / (np.abs(ref).max() + 1e-20)
+            assert err < rtol, (n, k, err)
+
+
+@pytest.mark.parametrize('bayesian', [False, True])
+def test_deconv_f32_forward_backward_parity(bayesian):
+    # (224 -> a 3x3 bottleneck: at 160 conv4_0 is 1x1 and bn4 normalises over the TWO values of the batch, where 1/sqrt(var+eps)
+    # turns f32 round-off of nearly equal pairs into 4e-4 logit differences)
+    B, S, nc = 2, 224, 3
+    x, y = _data(B, S, nc)
+    m = _model(x, y, nc, S, 'f32', use_graph=False, bayesian=bayesian)
+    assert sum(v[k].size for v in m.store.get_params().values() for k in v) == 55682
+    p = _oracle_params(m, np.random.default_rng(1))
+    m._load_batch(m.dataset, m.input_x, m.input_y)
+    m.store.g.fill_(float('nan'))
+    m._run_fwd_bwd()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(m.store.g).all())
+    # first step: completed-step counter 0 -> dropout offset 0
+    loss_ref, g_ref, c, newmov = odec.loss_and_grads(p, x[0], y[0], bayesian=bayesian, dropout={'keep': 0.5, 'seed': 5555, 'offset': 0})
+    logits = m.acts['logits'].t[..., :nc].cpu().numpy()
+    assert logits.shape == (B, S, S, nc)
+    # Tolerance: batch norm over the 18 values a channel has at the 3x3 bottleneck amplifies round-off by 1/sqrt(var + eps);
+    # the float32 run of the ORACLE ITSELF deviates from its float64 run by 3.9e-3 on these logits (2.7e-3 at 160, 1.3e-2 at
+    # 256).  The HIP f32 path measured 1.2e-4 (4.4e-4 with dropout); typical pixels agree to 1e-6.
+    assert np.abs(logits - c['logits']).max() < 1e-3
+    assert np.median(np.abs(logits - c['logits'])) < 5e-6
+    assert abs(m.last_loss() - loss_ref) < 1e-5
+    for name in ('conv1_0', 'conv3_0', 'deconv1_0', 'deconv2_1', 'deconv3_0'):
+        a = m.acts[name]
+        assert np.abs(a.t[..., :a.C].cpu().numpy() - c[name]).max() < 1e-4, name
+    for bn in ('bn1', 'bn4', 'bn8'):
+        a = m.bn_out[bn]
+        assert np.abs(a.t[..., :a.C].cpu().numpy() - c[bn]).max() < 2e-4, bn
+    _grads_close(m.store.get_grads(), g_ref, 5e-4)
+    mov = m.get_moving()
+    for bn, (nm, nv) in newmov.items():
+        assert np.abs(mov[bn][0] - nm).max() < 1e-6 and np.abs(mov[bn][1] - nv).max() < 1e-6, bn
+
+
+def test_deconv_train_steps_test_and_infer_match_oracle():
+    B, S, nc = 2, 224, 2
+    x, y = _data(B, S, nc, seed=7, n=2)
+    m = _model(x, y, nc, S, 'f32', use_graph=False, bayesian=True)
+    p = _oracle_params(m, np.random.default_rng(2))
+    mm, vv = odec.init_opt_state(p)
+    losses, ref = [], []
+    for t in (1, 2):
+        m.train_step(); losses.append(m.last_loss())
+        l, p, mm, vv = odec.train_step(p, mm, vv, t, x[t - 1], y[t - 1], lr=1e-3, bayesian=True, dropout={'keep': 0.5, 'seed': 5555, 'offset': (t - 1) << 40})
+        ref.append(l)
+    assert m.global_step == 2 and np.allclose(losses, ref, atol=3e-5)
+    got = m.store.get_params()
+    for n in got:
+        for k in got[n]:
+            # Adam normalises every step to ~lr: a gradient that is pure round-off moves its weight by up to lr = 1e-3 per step
+            d = np.abs(got[n][k] - np.asarray(p[n][k]))
+            assert d.max() < 1e-3 and np.median(d) < 5e-6, (n, k, d.max())
+    mov = m.get_moving()
+    for bn in mov:
+        assert np.abs(mov[bn][0] - p[bn]['moving_mean']).max() < 1e-6 and np.abs(mov[bn][1] - p[bn]['moving_variance']).max() < 1e-6
+    # (from here on the oracle takes the MODEL's weights: the Adam round-off drift measured above is not what is under test)
+    p = _oracle_params(m)
+    # test(): moving-average graph, dropout still on (is_training defaults True); the device-side step counter still holds
+    # the value of the last train step (1 completed before it)
+    m.test()
+    lt, _, _ = odec.forward(p, x[0], training=False, bayesian=True, dropout={'keep': 0.5, 'seed': 5555, 'offset': 1 << 40})
+    loss_t, _, _ = ops.softmax_xent(lt, y[0])
+    assert abs(m.last_test_loss - loss_t) < 1e-4 * max(1.0, abs(loss_t)), (m.last_test_loss, loss_t)
+    assert abs(m.last_loss() - losses[-1]) < 1e-7                       # test() does not disturb the training loss
+    # infer(): the TRAINING graph on the fed batch (batch statistics, dropout on), moving averages untouched
+    sig, out = m.infer(x[1], dropout_offset=5 << 40)
+    sref, oref = odec.infer(p, x[1], bayesian=True, dropout={'keep': 0.5, 'seed': 5555, 'offset': 5 << 40})
+    assert sig.shape == (B, S, S, nc) and np.abs(sig - sref).max() < 5e-4
+    srt = np.sort(sref.astype(np.float64), -1)
+    decided = (srt[..., -1] - srt[..., -2]) > 1e-3
+    assert np.array_equal(out[..., 0][decided], oref[..., 0][decided])
+    s2, _ = m.infer(x[1])                                               # a second call draws other masks
+    assert np.abs(s2 - sig).max() > 1e-3
+    assert all(np.array_equal(mov[bn][0], m.get_moving()[bn][0]) for bn in mov)
+
+
+def test_deconv_bf16_graph_equals_eager_and_trains(tmp_path):
+    B, S, nc = 4, 256, 4
+    x, y = _data(B, S, nc, seed=3)
+    m1 = DeconvModel(sess=None, dataset=ArrayDataSet(x, y), n_classes=nc, input_dims=S, n_kernels=32, log_dir=None, save_dir=str(tmp_path / 's1'),
+                     load_snapshot=False, dtype='bf16', use_graph=False, learning_rate=1e-3)
+    m2 = DeconvModel(sess=None, dataset=ArrayDataSet(x, y), n_classes=nc, input_dims=S, n_kernels=32, log_dir=None, save_dir=str(tmp_path / 's2'),
+                     load_snapshot=False, dtype='bf16', use_graph=True, learning_rate=1e-3)
+    mf = DeconvModel(sess=None, dataset=ArrayDataSet(x, y), n_classes=nc, input_dims=S, n_kernels=32, log_dir=None, save_dir=None,
+                     load_snapshot=False, dtype='f32', use_graph=False, learning_rate=1e-3)
+    l0 = None
+    for i in range(8):
+        m1.train_step(); m2.train_step()
+        if i == 0:
+            l0 = m1.last_loss(); mf.train_step()
+    torch.cuda.synchronize()
+    assert torch.equal(m1.store.p, m2.store.p)
+    assert all(torch.equal(m1.bn[b]['moving'], m2.bn[b]['moving']) for b in m1.bn)
+    assert abs(l0 - mf.last_loss()) < 2e-2 * abs(mf.last_loss())          # bf16 vs f32 first-step loss
+    assert m1.last_loss() < l0
+    # snapshot / restore keeps the moving averages and the trajectory
+    m1.snapshot()
+    m3 = DeconvModel(sess=None, dataset=ArrayDataSet(x, y), n_classes=nc, input_dims=S, n_kernels=32, log_dir=None, save_dir=str(tmp_path / 's1'),
+                     load_snapshot=True, dtype='bf16', use_graph=False, learning_rate=1e-3)
+    assert m3.global_step == 8 and torch.equal(m3.store.p, m1.store.p)
+    assert all(torch.equal(m1.bn[b]['moving'], m3.bn[b]['moving']) for b in m1.bn)
+    names = set(np.load(m3._latest_checkpoint()).files)
+    assert {'bn1/beta', 'bn1/moving_mean', 'bn8/moving_variance', 'deconv1_0/weights', 'conv_out/biases'} <= names
+    m1.train_step(); m3.train_step()
+    torch.cuda.synchronize()
+    assert torch.equal(m1.store.p, m3.store.p)
+
+
+def test_deconv_rejects_infeasible_and_odd_sizes():
+    x, y = _data(1, 128, 2)
+    with pytest.raises(Exception):
+        _model(x, y, 2, 128, 'f32')
+    with pytest.raises(Exception):
+        DeconvModel(sess=None, dataset=ArrayDataSet(*_data(1, 161, 2)), n_classes=2, input_dims=161, save_dir=None, load_snapshot=False)

@@ -36,6 +36,9 @@ def _rand_params(layer, rng, dtype):
     (3, 'VALID', [64], 32, 10, 10, 2, False, 14),
     (3, 'VALID', [64, 32], 64, 35, 37, 2, True, 15),
     (3, 'SAME', [64], 64, 19, 33, 1, True, 15),
+    (3, 'VALID', [64, 32], 64, 35, 37, 2, True, 16),       # 512-pixel tile, 8 waves (two K chunk sources, ragged edges)
+    (3, 'SAME', [64], 128, 19, 67, 2, True, 16),
+    (3, 'VALID', [32], 32, 50, 40, 1, False, 17),
     (3, 'VALID', [64], 64, 21, 19, 2, True, 51),          # weight-stationary persistent kernel (fwd + dgrad)
     (3, 'SAME', [32], 64, 13, 35, 3, True, 51),
     (3, 'VALID', [32, 32], 32, 20, 20, 2, True, 52),

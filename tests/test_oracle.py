@@ -239,3 +239,52 @@ def test_train_step_tf_adam_vs_torch():
     names = [(n, k) for n in p for k in ('weights', 'biases')]
     for (n, k), t in zip(names, st.flat):
         assert np.allclose(p2[n][k], t.detach().numpy(), atol=2e-5), (n, k)
+
+
+# ---------------- DeconvModel: numpy restatement vs the independent torch-autograd composition ----------------
+@pytest.mark.parametrize('bayesian', [False, True])
+def test_deconv_oracle_agrees_with_torch_autograd(bayesian):
+    from oracle import deconv as odec
+    p = odec.init_params(3, 8, 3, seed=3)
+    assert odec.n_params(p) == 55682 and odec.n_params(odec.init_params(2, 32, 3)) == 877386
+    rng = np.random.default_rng(1)
+    for n in p:
+        for k in ('biases', 'beta'):
+            if k in p[n]:
+                p[n][k] = (rng.standard_normal(p[n][k].shape) * 0.1).astype(np.float32)
+    x = rng.uniform(0, 1, (2, 160, 160, 3)).astype(np.float32)
+    y = rng.integers(0, 3, (2, 160, 160, 1)).astype(np.uint8)
+    loss, g, c, newmov = odec.loss_and_grads(p, x, y, bayesian=bayesian, dropout={'keep': 0.5, 'seed': 7, 'offset': 1 << 40})
+    # size ladder of models/deconvolution.py at 160: 80, 40, 38, 12, 10, 3, 1, then 5, 13, 29, resize 80, 160
+    assert [c[k].shape[1] for k in ('conv1_0', 'pool1', 'conv2_0', 'pool2', 'conv3_0', 'pool3', 'conv4_0', 'd1', 'd2', 'd3', 'resize', 'd4')] == \
+        [80, 40, 38, 12, 10, 3, 1, 5, 13, 29, 80, 160]
+    masks = {bn: c[bn + '/mask'] for bn in odec.DROP_SITES} if bayesian else None
+    l2, g2, lg2, st = torch_ref.deconv_loss_and_grads(p, x, y, masks)
+    assert abs(loss - l2) < 1e-10 and np.abs(c['logits'] - lg2).max() < 1e-9
+    for n in g:
+        for k in g[n]:
+            assert np.abs(g[n][k] - g2[n][k]).max() <= 1e-8 * (np.abs(g2[n][k]).max() + 1e-30), (n, k)
+    for bn, (nm, nv) in newmov.items():        # UPDATE_OPS: decay 0.999 moving averages of the batch mean / population variance
+        assert np.allclose(nm, 0.999 * p[bn]['moving_mean'] + 0.001 * st[bn][0], atol=1e-12)
+        assert np.allclose(nv, 0.999 * p[bn]['moving_variance'] + 0.001 * st[bn][1], atol=1e-12)
+    # test()-graph: moving averages, not batch statistics
+    lt, _, nm2 = odec.forward(p, x, training=False)
+    assert nm2 == {} and np.abs(lt - c['logits']).max() > 1e-3
+
+
+def test_pool_k_and_resize_oracle_properties():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 11, 10, 3))
+    y, idx = ops.max_pool_k(x, 3)
+    assert y.shape == (2, 3, 3, 3) and y[0, 0, 0, 0] == x[0, :3, :3, 0].max()
+    y2, idx2 = ops.max_pool_k(x, 2)
+    y2b, idx2b = ops.max_pool2x2(x)
+    assert np.array_equal(y2, y2b) and np.array_equal(idx2, idx2b)
+    dy = rng.standard_normal(y.shape)
+    dx = ops.max_pool_k_bwd(dy, idx, (11, 10), 3)
+    assert dx.shape == x.shape and np.isclose(dx.sum(), dy.sum()) and (dx[:, 9:] == 0).all() and (dx[:, :, 9:] == 0).all()
+    r = ops.resize_bilinear(x, (22, 25))
+    g = rng.standard_normal(r.shape)
+    assert abs((r * g).sum() - (x * ops.resize_bilinear_bwd(g, (11, 10))).sum()) < 1e-10       # adjoint
+    assert np.array_equal(ops.resize_bilinear(x, (11, 10)), x)                                    # identity size
+    assert np.allclose(ops.resize_bilinear(np.ones((1, 5, 5, 1)), (13, 9)), 1.0)
