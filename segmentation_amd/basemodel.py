@@ -274,7 +274,9 @@ class BaseModel(object):
             side = torch.cuda.Stream(self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
-                with torch.cuda.graph(graph, stream=side):
+                # thread_local: the loader / prefetcher threads keep calling event-synchronize and copy APIs while this thread
+                # captures; under the default (global) mode any such call from ANOTHER thread invalidates the capture
+                with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
                     fn()
             torch.cuda.current_stream(self.device).wait_stream(side)
             self._graphs[key] = graph

@@ -266,7 +266,11 @@ class ThreadedImageMaskDataSet(object):
             t.start()
 
     def stop(self):
+        """stops and JOINS the producer threads (a process must not reach interpreter shutdown with them inside torch calls)"""
         self._stop.set()
+        for t in self._workers:
+            if t is not threading.current_thread():
+                t.join(timeout=5.0)
 
     def get_batch(self):
         """-> (float32 [B,c,c,3] in [0,1], uint8 [B,c,c,1]); views of a pinned ring slot, valid until the second-next call."""
@@ -389,6 +393,9 @@ class DevicePrefetcher(object):
 
     def stop(self):
         self._stop.set()
+        for t in self._thr or []:
+            if t is not threading.current_thread():
+                t.join(timeout=5.0)
         if hasattr(self.ds, 'stop'):
             self.ds.stop()
 

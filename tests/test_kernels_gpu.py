@@ -170,8 +170,8 @@ def test_wgrad_layouts(case):
     net.conv_bwd(bplan, layer, srcs, H, W, dz, [None] * len(segs), wcfg=wcfg)
     net.flush_reduce(bplan)
     name = bplan.kernel_name(0)
-    if wcfg in (11, 14) or (wcfg == 0 and all(c_ % 64 == 0 for c_ in layer.cin_p) and layer.cout_p % 64 == 0):
-        assert ',4,1,1,4,' in name, name
+    if wcfg in (11, 14):
+        assert ',4,1,1,4,' in name, name              # (wcfg 0: the cost model picks layout and tile by the amount of work)
     bplan.run(U.stream()); U.sync()
     dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (k, k), padding, 1)
     g = store.get_grads()['c']
