@@ -216,19 +216,10 @@ typedef struct seg_pack_entry {
 int seg_pack_weights(const float* arena, void* packed, const seg_pack_entry* table_dev, int32_t n_entries,
                      int64_t total_blocks, int32_t dtype, void* stream);
 
-/* seg_adam fused with seg_pack_weights (same arithmetic, same packed bytes): the optimiser walks the weights in the 32x32 tiles of
- * the FORWARD packed layout and the block that has updated a tile writes its packed copies (the forward tile and, transposed, the
- * dgrad tile holding the same weights), so the re-pack at the head of the next step and its two extra reads of the arena go away.
- * fwd_table_dev: the SEG_PACK_CONV_FWD / SEG_PACK_UP_FWD entries only, blk_start counted over them; dgrad_dst_off_dev[i]: packed
- * offset of entry i's dgrad copy or -1; biases (stored right behind their weights) are updated by the tile blocks; [flat_off,
- * flat_off + flat_len) is one extra range updated element-wise (the unpacked first layer). */
-int seg_adam_pack(float* p, const float* g, float* m, float* v, int64_t n, void* packed,
-                  const seg_pack_entry* fwd_table_dev, const int64_t* dgrad_dst_off_dev, int32_t n_entries,
-                  int64_t total_tiles, int64_t flat_off, int64_t flat_len, float lr, float b1, float b2, float eps,
-                  float grad_scale, const int64_t* step_dev, int32_t dtype, void* stream);
-
-/* seg_pack_weights with ONE read of the fp32 arena for both packed copies (same tables as seg_adam_pack, same packed bytes as
- * seg_pack_weights): each 32x32 source tile is written as its forward tile and, transposed, as its dgrad tile. */
+/* seg_pack_weights with ONE read of the fp32 arena for both packed copies (same packed bytes as seg_pack_weights): each 32x32
+ * source tile is written as its forward tile and, transposed, as its dgrad tile.  fwd_table_dev: the SEG_PACK_CONV_FWD /
+ * SEG_PACK_UP_FWD entries only, blk_start counted over them in 32x32 tiles; dgrad_dst_off_dev[i]: packed offset of entry i's
+ * dgrad copy or -1. */
 int seg_pack_weights_dual(const float* arena, void* packed, const seg_pack_entry* fwd_table_dev,
                           const int64_t* dgrad_dst_off_dev, int32_t n_entries, int64_t total_tiles, int32_t dtype, void* stream);
 

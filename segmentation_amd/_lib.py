@@ -80,7 +80,6 @@ SIGNATURES = {
     'seg_step_begin': [vp, vp, vp],
     'seg_pack_weights': [vp, vp, vp, i32, i64, i32, vp],
     'seg_pack_weights_dual': [vp, vp, vp, vp, i32, i64, i32, vp],
-    'seg_adam_pack': [vp, vp, vp, vp, i64, vp, vp, vp, i32, i64, i64, i64, f32, f32, f32, f32, f32, vp, i32, vp],
     'seg_bilinear_up_fwd': [PV, i32, i32, i32, vp, PV, PV, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     'seg_bilinear_up_bwd': [PV, i32, i32, i32, i32, i32, vp, PV, i32, i32, i32, i32, i32, i32, vp],
     'seg_relu_grad': [PV, PV, PV, i32, i32, i32, i32, i32, vp],

@@ -192,15 +192,6 @@ class BaseModel(object):
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    @property
-    def fused_adam_pack(self):
-        """Adam writes the packed copies of the weights it has just updated (no re-pack at the head of the next step)."""
-        # Opt-in (SEG_FUSED_ADAM_PACK=1): bit-identical results, the first layer runs 36 instead of ~50 us without the re-pack
-        # beside it, but the fused kernel itself takes 70 us against Adam's 36 (4-byte accesses, three dependent round trips
-        # per block) at the serial tail of the step: 1.260 against 1.253 ms.
-        return (self.store.training and self.store.adam_pack is not None and os.environ.get('SEG_FUSED_ADAM_PACK', '0') != '0'
-                and os.environ.get('SEG_EARLY_ADAM', '0') == '0')
-
     def _flavor(self):
         """Which form of the slab reductions the plans run.  Per layer (right behind each filter gradient, on its stream) in
         both step modes: eagerly it needs no fork of its own (Plan.run), and then beats the batched form (one launch per
@@ -252,11 +243,11 @@ class BaseModel(object):
     def _run_step(self):
         s = self._stream()
         self.step_plan.run(s, self._side, flavor=self._flavor())
-        self._packed_dirty = not self.fused_adam_pack
+        self._packed_dirty = True        # (the packed copy is refreshed by the next forward, or lazily by infer() / test())
 
     def _run_update(self):
         self.upd_plan.run(self._stream())
-        self._packed_dirty = not self.fused_adam_pack      # (else the packed copy is refreshed by the next forward, or lazily by infer())
+        self._packed_dirty = True
 
     def _replay(self, key, fn):
         """Runs fn eagerly once (warm-up), then captures it into a hipGraph and replays the graph."""
@@ -305,14 +296,7 @@ class BaseModel(object):
     def _train_step_body(self):
         key = self._bind_batch(self.dataset)
         if not self.pg.enabled:
-            if self.use_graph and os.environ.get('SEG_HYBRID', '0') != '0':
-                # forward as a graph (a linear chain: nothing to gain from eager launches), backward + Adam launched eagerly
-                # (the cross-stream fork points cost ~7 us eagerly against ~12 us inside a captured graph)
-                self._replay(('fwd', key), lambda: self.fwd_plan.run(self._stream(), self._side, flavor=self._flavor()))
-                self.bwd_upd_plan.run(self._stream(), self._side, flavor=self._flavor())
-                self._packed_dirty = not self.fused_adam_pack
-            else:
-                self._replay(('step', key), self._run_step)
+            self._replay(('step', key), self._run_step)
         else:
             self._train_step_dp(key)
         self._gs_host += 1
@@ -514,27 +498,13 @@ class BaseModel(object):
         for plan, _ in self.bwd_segments:
             self.bwd_plan.extend(plan)
         upd = self.upd_plan = E.Plan('update')
-        fused = self.fused_adam_pack
-        if fused:
-            self.net.adam_pack(upd, self.learning_rate, grad_scale=1.0 / self.pg.world)
-        else:
-            self.net.adam(upd, self.learning_rate, grad_scale=1.0 / self.pg.world)
+        self.net.adam(upd, self.learning_rate, grad_scale=1.0 / self.pg.world)
         # the re-pack of the updated weights is the first op of the next forward plan (aux stream)
-        # Single-GPU step (SEG_EARLY_ADAM=1, measured 3 % slower under hipGraph, hence off): Adam of the buckets that are complete before the last backward segment runs on the auxiliary
-        # stream BESIDE that segment (nothing in backward reads the fp32 master weights); only the last, small bucket is
-        # updated after it.  The data-parallel path keeps one Adam after the last all-reduce (upd_plan).
         self.bwd_upd_plan = E.Plan('bwd+update')
-        early = len(self.bwd_segments) >= 2 and self._side is not None and os.environ.get('SEG_EARLY_ADAM', '0') != '0'
-        cut = self.bwd_segments[-2][1][1] if early else 0
-        for i, (plan, _) in enumerate(self.bwd_segments):
+        for plan, _ in self.bwd_segments:
             self.bwd_upd_plan.extend(plan)
-            if early and i == len(self.bwd_segments) - 2:
-                self.net.adam(self.bwd_upd_plan, self.learning_rate, grad_scale=1.0, lo=0, hi=cut, side='aux_join')
         self.net.join_all(self.bwd_upd_plan)           # the last filter gradients / reductions are on the side streams
-        if fused and cut == 0:
-            self.net.adam_pack(self.bwd_upd_plan, self.learning_rate, grad_scale=1.0)
-        else:
-            self.net.adam(self.bwd_upd_plan, self.learning_rate, grad_scale=1.0, lo=cut, hi=self.store.n)
+        self.net.adam(self.bwd_upd_plan, self.learning_rate, grad_scale=1.0)
         # the whole single-GPU step as ONE plan: no join of the side streams between forward and backward (the only forward
         # side-stream product, the im2col of the input, is consumed on the same side stream)
         self.step_plan = E.Plan('step')

@@ -23,7 +23,6 @@ struct ConvK {          // kernel-side copy of the descriptor (trivially copyabl
   seg_conv_desc d;
   int tiles_x, tiles_y; // spatial tiles per image
   int nchunks0, nchunks; // K chunks from src0 / total
-  int nst;               // weight-stationary kernel: LDS ring stages
 };
 
 // ---- epilogue: bias, ReLU, ReLU-grad mask, store 8 channels per lane ----
@@ -424,36 +423,6 @@ void conv_fwd_kernel(const ConvK P) {
 // ---------------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0, 0, 0, 0};
 
-// Bare s_barrier: __syncthreads() also drains vmcnt (workgroup-scope release), which would make the loader wait for
-// EVERY fill in flight and the consumers for their output stores at each stage.  The hand-over needs neither: the loader
-// has waited (vmcnt) for exactly the stage it hands over, and a consumer's LDS reads of a stage have returned before its
-// MFMAs could issue, i.e. before it arrives at the next barrier.
-SEG_DEV void ws_barrier() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a constant): waits for at most n
-// outstanding vector-memory operations; values above the table wait for fewer (safe).
-SEG_DEV void wait_vmcnt(int n) {
-#define SEG_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-  switch (n) {
-    SEG_VMC(0) SEG_VMC(1) SEG_VMC(2) SEG_VMC(3) SEG_VMC(4) SEG_VMC(5) SEG_VMC(6) SEG_VMC(7) SEG_VMC(8) SEG_VMC(9)
-    SEG_VMC(10) SEG_VMC(11) SEG_VMC(12) SEG_VMC(13) SEG_VMC(14) SEG_VMC(15) SEG_VMC(16) SEG_VMC(17) SEG_VMC(18) SEG_VMC(19)
-    SEG_VMC(20) SEG_VMC(21) SEG_VMC(22) SEG_VMC(23) SEG_VMC(24) SEG_VMC(25) SEG_VMC(26) SEG_VMC(27) SEG_VMC(28) SEG_VMC(29)
-    SEG_VMC(30) SEG_VMC(31) SEG_VMC(32) SEG_VMC(33) SEG_VMC(34) SEG_VMC(35) SEG_VMC(36) SEG_VMC(37) SEG_VMC(38) SEG_VMC(39)
-    SEG_VMC(40) SEG_VMC(41) SEG_VMC(42) SEG_VMC(43) SEG_VMC(44) SEG_VMC(45) SEG_VMC(46) SEG_VMC(47) SEG_VMC(48)
-    default:
-      if (n > 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      break;
-  }
-#undef SEG_VMC
-}
-
-template <int N> SEG_DEV void wait_vmcnt_c() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
 SEG_DEV void glds16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -461,6 +430,7 @@ SEG_DEV void glds16(const void* gsrc, char* lds_wave_base) {
 
 // NBUF = 2: double-buffered (chunk c+1 in flight during chunk c, ~1 workgroup/CU); NBUF = 1: single LDS buffer, loads are
 // not overlapped inside a workgroup but 4-5 small workgroups per CU overlap each other (no staging VGPRs -> 4+ waves/SIMD).
+// (Deeper rings and a weight-stationary persistent form were measured slower in the overlapped step and removed: DESIGN.md.)
 template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, int NBUF>
 __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_glds_kernel(const ConvK P) {
   using T = bf16_t;
@@ -563,14 +533,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_glds_kernel(const ConvK
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = f32x4{0, 0, 0, 0};
 
-  // NBUF >= 2: ring of NBUF LDS stages, chunks c+1 .. c+NBUF-1 are in flight while chunk c feeds the MFMAs (deep
-  // layers: a K step is ~300 MFMA cycles but a load round trip is > 1 us, so one chunk of prefetch is not enough)
-  constexpr int PD = NBUF - 1;
-  int lpw = 0;                                             // glds instructions this wave issues per chunk
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) lpw += (i * NW + wave < PINST) ? 1 : 0;
-#pragma unroll
-  for (int i = 0; i < WPW; ++i) lpw += (i * NW + wave < WINST) ? 1 : 0;
+  static_assert(NBUF == 1 || NBUF == 2, "single- or double-buffered");
+  constexpr int PD = NBUF - 1;                             // chunks in flight ahead of the one being computed
   if (NBUF >= 2) {
 #pragma unroll
     for (int i = 0; i < PD; ++i) if (i < P.nchunks) issue(i, smem + i * BUF);
@@ -584,12 +548,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_glds_kernel(const ConvK
       issue(c, smem);
       if (SBIAS && c == 0) bias_to_lds<BN>(bias_r, tid, sB);
     }
-    if (NBUF <= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of chunk c has landed
-    else {
-      const int later = P.nchunks - 1 - c < PD - 1 ? P.nchunks - 1 - c : PD - 1;   // chunk issues younger than c
-      wait_vmcnt(later * lpw);
-    }
-    if (NBUF >= 3) ws_barrier(); else __syncthreads();    // ... everyone's has, and nobody still reads the stage refilled next (bare barrier: no vmcnt drain of the younger fills)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of chunk c has landed
+    __syncthreads();                                      // ... everyone's has, and nobody still reads the stage refilled next
     if (NBUF >= 2 && c + PD < P.nchunks) {
       const int ns = slot == 0 ? NBUF - 1 : slot - 1;      // (c + PD) % NBUF == (c - 1) % NBUF
       issue(c + PD, smem + ns * BUF);
@@ -619,278 +579,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_glds_kernel(const ConvK
   epi_setup<BN, WN, FN / 2>(d, n0, wn, g, epi, sB);
   if (SBIAS) epi_bias<BN, WN, FN / 2>(sB, wn, g, epi);
   conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN>(d, acc, epi, b, oy0, ox0, wm, lr);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Weight-stationary persistent variant (bf16, 3x3 stride 1, K*BN small enough for LDS).
-// The tiled kernels above re-fetch all 9*K*BN filter bytes for every pixel tile: at 128 px x 64 ch that is 3x the
-// bytes of the input patch (L2 hits, but every tile pays their round trip before its first MFMA -- DESIGN.md section 5).
-// Here a workgroup loads its BN filter rows for ALL K once, then walks pixel tiles (blockIdx.x, +gridDim.x, ...); only
-// input patches stream, through a ring of NST LDS stages (one 32-channel chunk of
-// one tile each) filled by a dedicated LOADER wave (wave 4) with global_load_lds.  The four consumer waves never wait
-// on vmcnt for a fill (their vmcnt only sees their own mask loads / output stores), so epilogue stores do not drain
-// the prefetch pipeline; one s_barrier per stage hands a landed stage to the consumers and a consumed one back.
-// ---------------------------------------------------------------------------------------------------------
-#ifdef SEG_STAMPS
-__device__ long long* g_stamps = nullptr;      // debug builds only: [workgroup][wave 0..4][3][32] s_memtime stamps
-#define SEG_STAMP(row, idx) do { if (stp && lane == 0 && (idx) < 32) stp[(row) * 32 + (idx)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define SEG_STAMP(row, idx) do { } while (0)
-#endif
-
-
-// TEAMS = 2: two groups of four consumer waves work on ALTERNATE tiles, the second one shifted by one stage, so that one
-// team's epilogue / tile setup runs in the shadow of the other team's MFMAs (each SIMD then holds one wave of either team).
-// Ring order: stage q = TEAMS*j + t is team t's j-th stage; interval i (one s_barrier each) has team t on its stage i - t.
-template <int TH, int TW, int BN, int WM, int WN, int NLOAD, int TEAMS>
-__global__ __launch_bounds__(256 * TEAMS + 64 * NLOAD) void conv_ws_kernel(const ConvK P) {
-  using T = bf16_t;
-  using TT = Tr<T>;
-  constexpr int KW = 3, NT = 9, BM = TH * TW;
-  constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW;
-  constexpr int RSTR = TT::RSTR;
-  constexpr int PINST = (NPIX * 4 + 63) / 64, STAGE = PINST * 1024;
-  const int NST = P.nst, PD = NST - 1;              // ring depth: as many stages as fit beside the filters (launcher)
-  constexpr int FM = BM / WM / 16, FN = BN / WN / 16, NJ = FN / 2;
-  static_assert(WM * WN == 4 && FN % 2 == 0, "wave layout");
-  static_assert(PINST % NLOAD == 0, "every loader wave issues the same number of fills per stage");
-  constexpr int LPI = PINST / NLOAD;          // fill instructions per loader wave and stage
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const seg_conv_desc& d = P.d;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n0 = blockIdx.y * BN;
-  const int wbytes = P.nchunks * NT * BN * RSTR;
-  char* sW = smem;
-  char* sS = smem + wbytes;
-  const int ntiles = d.B * P.tiles_y * P.tiles_x;
-  const int nk = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // pixel tiles of this workgroup
-  const int nkt = (nk + TEAMS - 1) / TEAMS;                                               // tiles per team (the last may be missing)
-  const int S = nkt * P.nchunks;                                                          // stages per team
-  const int Q = TEAMS * S;                                                                // ring sequence length
-  const int J = S + TEAMS - 1;                                                            // intervals = barriers every wave executes
-  constexpr int NCW = 4 * TEAMS;                                                          // consumer waves
-  const T* wp = reinterpret_cast<const T*>(d.w_packed);
-#ifdef SEG_STAMPS
-  long long* stp = (g_stamps && blockIdx.y == 0 && blockIdx.x < 64) ? g_stamps + ((int64_t)blockIdx.x * 12 + (wave >= NCW ? 11 : wave)) * 96 : nullptr;
-#endif
-  SEG_STAMP(2, 0);
-
-  // ---- filters: LDS rows ((chunk*9 + tap)*BN + row), same piece swizzle as the tiled kernels ----
-  {
-    const int winst = P.nchunks * NT * BN * 4 / 64;
-    for (int j = wave; j < winst; j += NCW + NLOAD) {
-      const int piece = j * 64 + lane;
-      const int rowg = piece >> 2, h = (piece & 3) ^ ((rowg >> 1) & 2);
-      const int c = rowg / (NT * BN), rem = rowg - c * (NT * BN);
-      const int tap = rem / BN, row = rem - tap * BN;
-      glds16(wp + ((int64_t)(tap * P.nchunks + c) * d.n_total + d.n_off + n0 + row) * 32 + h * 8, sW + j * 1024);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  SEG_STAMP(2, 1);
-
-  if (wave >= NCW) {
-    // ================= loader waves: wave NCW+j fills instructions j, j+NLOAD, ... of every stage =================
-    const int lw = wave - NCW;
-    int spy[LPI], spx[LPI], sh[LPI];
-#pragma unroll
-    for (int i = 0; i < LPI; ++i) {
-      const int piece = (i * NLOAD + lw) * 64 + lane;
-      const int q = piece >> 2;
-      sh[i] = ((piece & 3) ^ ((q >> 1) & 2)) * 8;
-      spy[i] = q < NPIX ? q / PW : -100000;                  // pieces past the patch always read the zero word
-      spx[i] = q % PW;
-    }
-    int off0[TEAMS][LPI], off1[TEAMS][LPI];
-    const T* src0[TEAMS]; const T* src1[TEAMS];
-    auto set_tile = [&](int t_, int k) {            // offsets of team t_'s tile k (k >= nk: a missing tile -> zero fills)
-      const bool real = k < nk;
-      int t = blockIdx.x + (real ? k : 0) * gridDim.x;
-      const int tx = t % P.tiles_x; t /= P.tiles_x;
-      const int ty = t % P.tiles_y; const int b = t / P.tiles_y;
-      const int iy0 = ty * TH - d.pad_t, ix0 = tx * TW - d.pad_l;
-      src0[t_] = reinterpret_cast<const T*>(d.src0.ptr) + (int64_t)b * d.src0.H * d.src0.W * d.src0.cs;
-      src1[t_] = reinterpret_cast<const T*>(d.src1.ptr) + (int64_t)b * d.src1.H * d.src1.W * d.src1.cs;
-#pragma unroll
-      for (int i = 0; i < LPI; ++i) {
-        const int iy = iy0 + spy[i], ix = ix0 + spx[i];
-        const bool in = real && iy >= 0 && iy < d.Hi && ix >= 0 && ix < d.Wi;
-        off0[t_][i] = in ? ((iy + d.src0.oy) * d.src0.W + ix + d.src0.ox) * d.src0.cs + d.src0.coff + sh[i] : -1;
-        off1[t_][i] = in ? ((iy + d.src1.oy) * d.src1.W + ix + d.src1.ox) * d.src1.cs + d.src1.coff + sh[i] : -1;
-      }
-    };
-    int next = 0;                                    // next ring sequence index to issue
-    auto issue_next = [&]() {
-      const int t_ = next % TEAMS, j = next / TEAMS;
-      const int ic = j % P.nchunks;
-      if (ic == 0) {
-#pragma unroll
-        for (int tt = 0; tt < TEAMS; ++tt) if (tt == t_) set_tile(tt, TEAMS * (j / P.nchunks) + tt);
-      }
-      const bool first = ic < P.nchunks0;
-      char* buf = sS + (next % NST) * STAGE;
-#pragma unroll
-      for (int tt = 0; tt < TEAMS; ++tt) {
-        if (tt != t_) continue;
-        const T* sb = first ? src0[tt] + ic * 32 : src1[tt] + (ic - P.nchunks0) * 32;
-#pragma unroll
-        for (int i = 0; i < LPI; ++i) {
-          const int off = first ? off0[tt][i] : off1[tt][i];
-          glds16(off >= 0 ? (const void*)(sb + off) : (const void*)g_zero16, buf + (i * NLOAD + lw) * 1024);
-        }
-      }
-      ++next;
-    };
-    // stage q (team t = q % TEAMS, its j-th) is consumed during interval j + t, i.e. known consumed at barrier j + t + 1
-    while (next < Q && next < NST) issue_next();
-    for (int i = 0; i < J; ++i) {
-      const int need = TEAMS * i < Q - 1 ? TEAMS * i : Q - 1;              // everything up to here must have landed
-      const int later = next - 1 - need;
-      wait_vmcnt(later > 0 ? later * LPI : 0);
-      SEG_STAMP(0, i);
-      ws_barrier();                        // interval i starts; the consumers are done with interval i-1
-      SEG_STAMP(1, i);
-      while (next < Q) {
-        const int qo = next - NST;         // current occupant of the slot
-        if (qo >= 0 && qo / TEAMS + qo % TEAMS + 1 > i) break;
-        issue_next();
-      }
-    }
-    return;
-  }
-
-  // ================= consumer waves =================
-  const int team = wave >> 2, cw = wave & 3;
-  const int wm = cw / WN, wn = cw % WN;
-  const int lr = lane & 15, g = lane >> 4;
-  int a_addr[FN];
-#pragma unroll
-  for (int fn = 0; fn < FN; ++fn) a_addr[fn] = frag_addr<T>(wn * (BN / WN) + fn * 16 + lr, g);
-  int b_addr[NT][FM];
-  int mrow[FM], mcol[FM];
-#pragma unroll
-  for (int fm = 0; fm < FM; ++fm) {
-    const int m = wm * (BM / WM) + fm * 16 + lr;
-    mrow[fm] = m / TW; mcol[fm] = m % TW;
-#pragma unroll
-    for (int u = 0; u < 3; ++u)
-#pragma unroll
-      for (int v = 0; v < 3; ++v) b_addr[u * KW + v][fm] = frag_addr<T>((mrow[fm] + u) * PW + mcol[fm] + v, g);
-  }
-  EpiCtx<NJ> epi;
-  epi_setup<BN, WN, NJ>(d, n0, wn, g, epi);
-  const bool has_mask = d.mask.ptr != nullptr;
-  const float lo = d.relu ? 0.f : -INFINITY;
-
-  f32x4 acc[FN][FM];
-  Vec8<T> mk[NJ][FM];
-  int poff_d[FM];
-  int64_t dbase = 0;
-  int cc = 0, ck = team;                           // chunk within the tile; index of the tile in this workgroup's list
-  for (int iv = 0; iv < J; ++iv) {
-    SEG_STAMP(0, iv);
-    ws_barrier();
-    SEG_STAMP(1, iv);
-    const int js = iv - team;                        // this team's stage in this interval
-    if (js < 0 || js >= S || ck >= nk) continue;     // shifted start / tail, or the missing last tile of this team
-    const int slot = (TEAMS * js + team) % NST;
-    if (cc == 0) {
-      int t = blockIdx.x + ck * gridDim.x;
-      const int tx = t % P.tiles_x; t /= P.tiles_x;
-      const int ty = t % P.tiles_y; const int b = t / P.tiles_y;
-      dbase = ((int64_t)(b * d.dst.H + d.dst.oy) * d.dst.W + d.dst.ox) * d.dst.cs + d.dst.coff;
-      const T* mbase = reinterpret_cast<const T*>(d.mask.ptr) + ((int64_t)(b * d.mask.H + d.mask.oy) * d.mask.W + d.mask.ox) * d.mask.cs + d.mask.coff;
-#pragma unroll
-      for (int fm = 0; fm < FM; ++fm) {
-        const int oy = ty * TH + mrow[fm], ox = tx * TW + mcol[fm];
-        poff_d[fm] = (oy < d.Ho && ox < d.Wo) ? (oy * d.dst.W + ox) * d.dst.cs : -1;
-        if (has_mask) {
-          // the ReLU-grad mask of this tile is requested now and consumed after the tile's last chunk
-          const int pm = (oy * d.mask.W + ox) * d.mask.cs;
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            if (epi.on[j] && poff_d[fm] >= 0) mk[j][fm].load(mbase + pm + epi.co[j]);
-        }
-      }
-#pragma unroll
-      for (int fn = 0; fn < FN; ++fn)
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = f32x4{0, 0, 0, 0};
-    }
-    const char* cur = sS + slot * STAGE;
-    const char* wc = sW + cc * (NT * BN * RSTR);
-    Frag<T> fa[2][FN], fb[2][FM];
-#pragma unroll
-    for (int fn = 0; fn < FN; ++fn) fa[0][fn] = lds_read_frag_at<T>(wc + a_addr[fn]);
-#pragma unroll
-    for (int fm = 0; fm < FM; ++fm) fb[0][fm] = lds_read_frag_at<T>(cur + b_addr[0][fm]);
-    // one wave per SIMD: nothing else hides LDS latency, so the order is pinned -- the reads of tap t+1 are ISSUED
-    // before the MFMAs of tap t (left alone, the scheduler sinks every read next to its first use and each tap
-    // exposes two full LDS round trips: 38 instead of 16 cycles per MFMA measured)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int tap = 0; tap < NT; ++tap) {
-      if (tap + 1 < NT) {
-        // read order = order of first use by the fn-major MFMA sequence below: fb0, fa0, fb1.., then fa1..
-        fb[(tap + 1) & 1][0] = lds_read_frag_at<T>(cur + b_addr[tap + 1 < NT ? tap + 1 : 0][0]);
-        fa[(tap + 1) & 1][0] = lds_read_frag_at<T>(wc + a_addr[0] + (tap + 1) * BN * RSTR);
-#pragma unroll
-        for (int fm = 1; fm < FM; ++fm) fb[(tap + 1) & 1][fm] = lds_read_frag_at<T>(cur + b_addr[tap + 1 < NT ? tap + 1 : 0][fm]);
-#pragma unroll
-        for (int fn = 1; fn < FN; ++fn) fa[(tap + 1) & 1][fn] = lds_read_frag_at<T>(wc + a_addr[fn] + (tap + 1) * BN * RSTR);
-      }
-#pragma unroll
-      for (int fn = 0; fn < FN; ++fn)
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm) mma32(acc[fn][fm], fa[tap & 1][fn], fb[tap & 1][fm]);
-      // interleave: one LDS read of tap t+1 in the issue shadow of every MPR MFMAs of tap t (a burst of 6-8 reads in
-      // front of the MFMAs leaves the matrix pipe idle while they issue)
-      if (tap + 1 < NT) {
-        constexpr int NRD = FN + FM, NMM = FN * FM, MPR = NMM / NRD;
-#pragma unroll
-        for (int i = 0; i < NRD; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
-        }
-        if (NMM - NRD * MPR > 0) __builtin_amdgcn_sched_group_barrier(0x008, NMM - NRD * MPR, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    SEG_STAMP(2, 2 + iv);
-    if (++cc == P.nchunks) {
-      cc = 0; ck += TEAMS;
-      // ---- epilogue of the finished tile: bias, ReLU / ReLU-grad mask, 16-byte stores ----
-      // Two passes: all values first (the only wait is for the mask loads requested a whole tile ago), then the
-      // stores back to back -- vmcnt also counts stores on gfx9, so a mask wait between two stores would serialise them.
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v0 = fmaxf(acc[2 * j][fm][e] + epi.bv[j][e], lo);
-            float v1 = fmaxf(acc[2 * j + 1][fm][e] + epi.bv[j][4 + e], lo);
-            if (has_mask) {
-              v0 = mk[j][fm].get(e) > 0.f ? v0 : 0.f;
-              v1 = mk[j][fm].get(4 + e) > 0.f ? v1 : 0.f;
-            }
-            acc[2 * j][fm][e] = v0; acc[2 * j + 1][fm][e] = v1;
-          }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm) {
-          Vec8<T> o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { o.set(e, acc[2 * j][fm][e]); o.set(4 + e, acc[2 * j + 1][fm][e]); }
-          if (epi.on[j] && poff_d[fm] >= 0) o.store(reinterpret_cast<T*>(d.dst.ptr) + dbase + poff_d[fm] + epi.co[j]);
-        }
-      }
-    }
-  }
 }
 
 thread_local char* g_name_out = nullptr;   // when set, launches are dry: only the kernel name is reported
@@ -953,47 +641,6 @@ int launch_glds(const ConvK& P0, hipStream_t st) {
 }
 
 
-// Weight-stationary launch: grid.x persistent workgroups per BN block walk the pixel tiles.
-template <int TH, int TW, int BN, int WM, int WN, int NLOAD, int TEAMS = 1>
-int launch_ws(const ConvK& P0, hipStream_t st) {
-  if (g_name_out) {
-    snprintf(g_name_out, g_name_cap, "conv_ws_kernel<%d,%d,%d,%d,%d,%d,%d>", TH, TW, BN, WM, WN, NLOAD, TEAMS);
-    return SEG_OK;
-  }
-  constexpr int PINST = ((TH + 2) * (TW + 2) * 4 + 63) / 64;
-  ConvK P = P0;
-  if (P.d.n_count % BN != 0) { seg_set_error("conv_ws: n_count %d not a multiple of BN %d", P.d.n_count, BN); return SEG_ERR_ARG; }
-  P.tiles_x = cdiv(P.d.Wo, TW);
-  P.tiles_y = cdiv(P.d.Ho, TH);
-  // ring depth: bytes in flight per CU are what buys fill bandwidth (Little's law at ~4 us loaded latency), so one
-  // workgroup per CU takes all the LDS the filters leave; vmcnt can count (PD-1)*LPI <= 48 outstanding fills
-  static const int nst_env = getenv("SEG_WS_STAGES") ? atoi(getenv("SEG_WS_STAGES")) : 0;
-  const int wbytes = P.nchunks * 9 * BN * 64;
-  int nst = (160 * 1024 - wbytes) / (PINST * 1024);
-  const int nst_cap = 48 / (PINST / NLOAD) + 2;
-  if (nst > nst_cap) nst = nst_cap;
-  if (nst_env > 1 && nst_env < nst) nst = nst_env;
-  if (nst < 2) { seg_set_error("conv_ws: filters leave no room for the patch ring"); return SEG_ERR_ARG; }
-  P.nst = nst;
-  const int lds = wbytes + nst * PINST * 1024;
-  auto kern = conv_ws_kernel<TH, TW, BN, WM, WN, NLOAD, TEAMS>;
-  static int lds_max = 0;
-  if (lds > lds_max) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      seg_set_error("conv_ws: cannot raise dynamic LDS"); return SEG_ERR_LAUNCH;
-    }
-    lds_max = 160 * 1024;
-  }
-  const int ntiles = P.d.B * P.tiles_y * P.tiles_x, nblk = P.d.n_count / BN;
-  int occ = (160 * 1024) / lds; if (occ > 3) occ = 3; if (occ < 1) occ = 1;
-  static const int ncu = [] { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256; return pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }();
-  int maxwg = ncu * occ / nblk; if (maxwg < 1) maxwg = 1;
-  const int rounds = cdiv(ntiles, maxwg);
-  const int gx = cdiv(ntiles, rounds);               // balanced: every workgroup walks `rounds` (or rounds-1) tiles
-  SEG_LAUNCH(kern, dim3(gx, nblk), dim3(256 * TEAMS + 64 * NLOAD), lds, st, P);
-  return seg_check_launch("conv_ws");
-}
-
 // padded output area for a tile shape (smaller = less wasted MFMA work)
 inline long waste(int Ho, int Wo, int th, int tw) { return (long)cdiv(Ho, th) * th * cdiv(Wo, tw) * tw; }
 
@@ -1002,29 +649,6 @@ int launch_k(const ConvK& P, hipStream_t st) {
   const seg_conv_desc& d = P.d;
   int cfg = d.cfg;
   const int mode_hint = cfg < 0 ? -cfg : 0;      // cfg < 0: automatic tile choice with staging mode |cfg| (see below)
-  if (sizeof(T) == 2 && KH == 3 && S == 1 && (cfg <= 0 || cfg >= 50) && !d.up2 && !d.accum && !d.out_f32 && d.n_split == 0) {
-    // weight-stationary persistent kernel whenever the BN filter rows of all K fit beside the patch ring
-    static const int ws_on = getenv("SEG_CONV_WS") ? atoi(getenv("SEG_CONV_WS")) : 0;   // opt-in: not yet faster than the tiled kernels
-    const int ntiles = d.B * cdiv(d.Ho, 8) * cdiv(d.Wo, 16);
-    const int bn = (cfg == 51 || cfg == 53 || cfg == 55) ? 64 : (cfg == 52 || cfg == 54 || cfg == 56) ? 32 : (d.n_count % 64 == 0 && P.nchunks * 9 * 64 * 64 <= 80 * 1024) ? 64 : 32;
-    const bool fits = P.nchunks * 9 * bn * 64 <= 80 * 1024;
-    if (cfg >= 50 || (ws_on && fits && (long)ntiles * (d.n_count / bn) >= 512)) {
-      if (!fits) { seg_set_error("conv_ws: K %d x BN %d does not fit in LDS", P.nchunks * 32, bn); return SEG_ERR_ARG; }
-      const int sel = cfg >= 50 ? cfg : (bn == 64 ? 55 : 56);       // SEG_CONV_WS=1: the two-team form
-      static const int nload = getenv("SEG_WS_LOADERS") ? atoi(getenv("SEG_WS_LOADERS")) : 4;
-      if (sel == 51 && nload == 1) return launch_ws<8, 16, 64, 4, 1, 1>(P, st);
-      if (sel == 51 && nload == 2) return launch_ws<8, 16, 64, 4, 1, 2>(P, st);
-      if (sel == 51) return launch_ws<8, 16, 64, 4, 1, 4>(P, st);
-      if (sel == 55) return launch_ws<8, 16, 64, 4, 1, 4, 2>(P, st);      // two consumer teams on alternate tiles
-      if (sel == 56) return launch_ws<8, 16, 32, 4, 1, 4, 2>(P, st);
-      if (sel == 53) return launch_ws<16, 16, 64, 4, 1, 3>(P, st);     // 256-pixel tiles: 64 ch x 64 px per wave halves the LDS reads per MFMA
-      if (sel == 54) return launch_ws<16, 16, 32, 4, 1, 3>(P, st);
-      if (sel == 52 && nload == 1) return launch_ws<8, 16, 32, 4, 1, 1>(P, st);
-      if (sel == 52 && nload == 2) return launch_ws<8, 16, 32, 4, 1, 2>(P, st);
-      if (sel == 52) return launch_ws<8, 16, 32, 4, 1, 4>(P, st);
-      seg_set_error("conv: unknown cfg %d", cfg); return SEG_ERR_ARG;
-    }
-  }
   if (d.pool.ptr) {
     // fused max-pool: only the 8x16 register-staged tiles carry it (bf16, 3x3/s1); anything else is refused so that the
     // caller keeps the separate pool launch (it asks seg_conv2d_kernel_name first)
@@ -1057,8 +681,7 @@ int launch_k(const ConvK& P, hipStream_t st) {
       // the host asks for it on the forward pass; in backward the dgrads share the chip with the filter gradients and 3 wins)
       static const int env_mode = getenv("SEG_CONV_MODE") ? atoi(getenv("SEG_CONV_MODE")) : -1;
       const int mode = env_mode >= 0 ? env_mode : (mode_hint ? mode_hint : 3);
-      static const int ring = getenv("SEG_GLDS_RING") ? atoi(getenv("SEG_GLDS_RING")) : 2;      // LDS stages of the 64-pixel direct-to-LDS tiles
-      if (mode == 1 || mode == 2 || (mode == 3 && cfg >= 3)) cfg += (cfg >= 3 && P.nchunks >= 4 && ring >= 3) ? (ring == 3 ? 30 : 40) : 10;
+      if (mode == 1 || mode == 2 || (mode == 3 && cfg >= 3)) cfg += 10;
       if (mode == 4) cfg += 20;          // single-buffered direct-to-LDS (default: fastest on every measured layer)
       if (mode == 5) cfg = (cfg == 1 || cfg == 2) ? 22 : 24;   // ... and always 32-channel tiles
       if (mode == 2 && cfg == 11 && d.Ho >= 32 && d.Wo >= 32) cfg = 15;
@@ -1080,18 +703,10 @@ int launch_k(const ConvK& P, hipStream_t st) {
       case 13: return launch_glds<8, 8, 64, 2, 2, KH, KW, S>(P, st);
       case 14: return launch_glds<8, 8, 32, 4, 1, KH, KW, S>(P, st);
       case 15: return launch_glds<16, 16, 64, 4, 1, KH, KW, S>(P, st);  // 256 px x 64 ch
-      case 16: if constexpr (S == 1) return launch_glds<16, 32, 64, 8, 1, KH, KW, S>(P, st); else break;   // 512 px x 64 ch, 8 waves (64 px x 64 ch each), 150 KB of LDS
-      case 17: if constexpr (S == 1) return launch_glds<16, 32, 32, 8, 1, KH, KW, S>(P, st); else break;   // 512 px x 32 ch
       case 21: return launch_glds<8, 16, 64, 4, 1, KH, KW, S, 1>(P, st);  // single-buffered variants
       case 22: return launch_glds<8, 16, 32, 4, 1, KH, KW, S, 1>(P, st);
       case 23: return launch_glds<8, 8, 64, 2, 2, KH, KW, S, 1>(P, st);
       case 24: return launch_glds<8, 8, 32, 4, 1, KH, KW, S, 1>(P, st);
-      case 32: return launch_glds<8, 16, 32, 4, 1, KH, KW, S, 3>(P, st);  // 3-stage ring
-      case 33: return launch_glds<8, 8, 64, 2, 2, KH, KW, S, 3>(P, st);
-      case 34: return launch_glds<8, 8, 32, 4, 1, KH, KW, S, 3>(P, st);
-      case 42: return launch_glds<8, 16, 32, 4, 1, KH, KW, S, 4>(P, st);  // 4-stage ring
-      case 43: return launch_glds<8, 8, 64, 2, 2, KH, KW, S, 3>(P, st);  // (4 stages of 43 KB do not fit)
-      case 44: return launch_glds<8, 8, 32, 4, 1, KH, KW, S, 4>(P, st);
       default: break;
     }
   }
@@ -1163,16 +778,10 @@ extern "C" int seg_conv2d(const seg_conv_desc* dp, void* stream) {
   if (!d.src1.ptr) { P.d.src1 = d.src0; P.d.src1.c = 0; }
   P.nchunks0 = d.src0.c / 32;
   P.nchunks = P.nchunks0 + (d.src1.ptr ? d.src1.c / 32 : 0);
-  P.tiles_x = P.tiles_y = 0; P.nst = 0;
+  P.tiles_x = P.tiles_y = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d.dtype == SEG_F32) return launch_t<float>(P, st);
   if (d.dtype == SEG_BF16) return launch_t<bf16_t>(P, st);
   seg_set_error("conv: bad dtype %d", d.dtype);
   return SEG_ERR_ARG;
 }
-
-#ifdef SEG_STAMPS
-extern "C" int seg_dbg_set_stamps(void* p) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
-}
-#endif

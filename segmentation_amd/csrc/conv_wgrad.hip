@@ -591,12 +591,6 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
     if (ks2 > P.ntiles / 8) ks2 = P.ntiles / 8;
     if (ks2 > ks) ks = ks2;
   }
-  {
-    // deep layers (filter rows split over blockIdx.z, no K split): the walk over the pixel tiles is a serial latency chain;
-    // SEG_WGRAD_DEEPSPLIT=n splits it n ways at the price of one slab write + read of the filter (experiment)
-    static const int deep = getenv("SEG_WGRAD_DEEPSPLIT") ? atoi(getenv("SEG_WGRAD_DEEPSPLIT")) : 0;
-    if (deep > 1 && P.d.ksplit <= 0 && ks == 1 && P.ntiles >= 8 * deep) ks = deep;
-  }
   if (ks > P.ntiles) ks = P.ntiles;
   if (ks < 1) ks = 1;
   P.ksplit = ks;

@@ -532,42 +532,19 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* arena, T* packed
 }
 
 // ------------------------------------------------------------------------------------------
-// Adam fused with the re-pack: the optimiser walks the weights in the 32(k) x 32(n) tiles of the FORWARD packed layout
-// (reads and writes of p / g / m / v are still whole 128-byte lines of the TF-layout arena), and the block that has just
-// updated a tile writes its packed copies -- the forward tile and, transposed, the one dgrad tile that holds the same
-// weights (taps flipped, the roles of the channel blocks swapped) -- from LDS.  The separate re-pack at the head of the
-// next step (two more reads of the fp32 arena, on the auxiliary stream beside the first layer) disappears.  The tile
-// blocks of tap 0 / chunk 0 also update their 32 biases; one flat range (the unpacked first layer) follows the tiles.
+// Re-pack with ONE read of the fp32 arena for both packed copies: the walk goes over the 32(k) x 32(n) tiles of the FORWARD
+// packed layout (reads are whole 128-byte lines of the TF-layout arena); a workgroup writes, from LDS, the forward tile and,
+// transposed, the one dgrad tile that holds the same weights (taps flipped, the roles of the channel blocks swapped).  (A form
+// of this walk that also did the Adam update was bit-identical but slower at the serial tail of the step and was removed.)
 // ------------------------------------------------------------------------------------------
 constexpr int AP_TPB = 2;
-// ADAM = false: the re-pack alone in the same walk -- ONE read of the fp32 arena for both packed copies (the table-driven
-// pack_kernel reads it once per copy).
-template <typename T, bool ADAM>
-__global__ __launch_bounds__(256) void adam_pack_kernel(float* p, const float* g, float* m, float* v, T* packed, const seg_pack_entry* tab,
-                                                        const int64_t* dgrad_off, int n_entries, int64_t total_tiles, int64_t flat_off,
-                                                        int64_t flat_len, float lr, float b1, float b2, float eps, float gs,
-                                                        const int64_t* step_dev) {
-  __shared__ float s_lrt;
+template <typename T>
+__global__ __launch_bounds__(256) void pack_dual_kernel(const float* p, T* packed, const seg_pack_entry* tab, const int64_t* dgrad_off,
+                                                        int n_entries, int64_t total_tiles) {
   __shared__ int s_e[AP_TPB];
   __shared__ float tile[AP_TPB][32][33];
-  if (ADAM && threadIdx.x == 64) {
-    const double t = (double)(*step_dev + 1);
-    s_lrt = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
-  }
   const int64_t tile_blocks = (total_tiles + AP_TPB - 1) / AP_TPB;
-  if ((int64_t)blockIdx.x >= tile_blocks) {
-    if (!ADAM) return;
-    // flat range (first layer: weights + biases, contiguous in the arena)
-    __syncthreads();
-    const float lr_t = s_lrt;
-    for (int64_t i = ((int64_t)blockIdx.x - tile_blocks) * 256 + threadIdx.x; i < flat_len; i += ((int64_t)gridDim.x - tile_blocks) * 256) {
-      const int64_t a = flat_off + i;
-      float pp = p[a], mm = m[a], vv = v[a];
-      adam1(pp, g[a], mm, vv, lr_t, b1, b2, eps, gs);
-      p[a] = pp; m[a] = mm; v[a] = vv;
-    }
-    return;
-  }
+  if ((int64_t)blockIdx.x >= tile_blocks) return;
   const int64_t tile0 = (int64_t)blockIdx.x * AP_TPB;
   if (threadIdx.x < 64) {
     int cnt[AP_TPB];
@@ -585,18 +562,15 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(float* p, const float* g
     }
   }
   __syncthreads();
-  const float lr_t = ADAM ? s_lrt : 0.f;
-  float pp[AP_TPB][4], gg[AP_TPB][4], mm[AP_TPB][4], vv[AP_TPB][4];
+  float pp[AP_TPB][4];
   int64_t sidx[AP_TPB][4];
   T* dstf[AP_TPB]; T* dstd[AP_TPB];
   bool nfast[AP_TPB];
-  int64_t bidx[AP_TPB];                          // this thread's bias element of the tile (or -1)
-  float bp[AP_TPB], bg[AP_TPB], bm[AP_TPB], bv[AP_TPB];
 #pragma unroll
   for (int q = 0; q < AP_TPB; ++q) {
-    dstf[q] = nullptr; dstd[q] = nullptr; nfast[q] = true; bidx[q] = -1;
+    dstf[q] = nullptr; dstd[q] = nullptr; nfast[q] = true;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { sidx[q][i] = -1; pp[q][i] = 0.f; gg[q][i] = 0.f; mm[q][i] = 0.f; vv[q][i] = 0.f; }
+    for (int i = 0; i < 4; ++i) { sidx[q][i] = -1; pp[q][i] = 0.f; }
     if (tile0 + q >= total_tiles) continue;
     const seg_pack_entry e = tab[s_e[q]];
     int64_t t = tile0 + q - e.blk_start;
@@ -628,19 +602,7 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(float* p, const float* g
         const int tp = n / e.cout_pad, co = n % e.cout_pad;
         if (ci >= 0 && co < e.cout && tp < 4) sidx[q][i] = e.src_off + ((int64_t)tp * e.cout + co) * e.cin + ci;
       }
-      if (sidx[q][i] >= 0) {
-        pp[q][i] = p[sidx[q][i]];
-        if (ADAM) { gg[q][i] = g[sidx[q][i]]; mm[q][i] = m[sidx[q][i]]; vv[q][i] = v[sidx[q][i]]; }
-      }
-    }
-    if (ADAM && tap == 0 && chunk == 0 && threadIdx.x < 32) {
-      const int n = nb * 32 + threadIdx.x;
-      const int co = conv ? n : n % e.cout_pad;
-      const bool mine = conv ? n < e.cout : (n / e.cout_pad == 0 && co < e.cout);
-      if (mine) {
-        bidx[q] = e.src_off + (int64_t)(conv ? ntaps : 4) * e.cin * e.cout + co;
-        bp[q] = p[bidx[q]]; bg[q] = g[bidx[q]]; bm[q] = m[bidx[q]]; bv[q] = v[bidx[q]];
-      }
+      if (sidx[q][i] >= 0) pp[q][i] = p[sidx[q][i]];
     }
   }
 #pragma unroll
@@ -648,17 +610,9 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(float* p, const float* g
     if (dstf[q] == nullptr) continue;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (ADAM && sidx[q][i] >= 0) {
-        adam1(pp[q][i], gg[q][i], mm[q][i], vv[q][i], lr_t, b1, b2, eps, gs);
-        p[sidx[q][i]] = pp[q][i]; m[sidx[q][i]] = mm[q][i]; v[sidx[q][i]] = vv[q][i];
-      }
       const int idx = threadIdx.x + i * 256;
       const int fast = idx & 31, slow = idx >> 5;
       tile[q][nfast[q] ? fast : slow][nfast[q] ? slow : fast] = pp[q][i];       // [n][k]; 0 where the tile is padding
-    }
-    if (ADAM && bidx[q] >= 0) {
-      adam1(bp[q], bg[q], bm[q], bv[q], lr_t, b1, b2, eps, gs);
-      p[bidx[q]] = bp[q]; m[bidx[q]] = bm[q]; v[bidx[q]] = bv[q];
     }
   }
   __syncthreads();
@@ -894,29 +848,14 @@ extern "C" int seg_adam(float* p, const float* g, float* m, float* v, int64_t n,
   return seg_check_launch("adam");
 }
 
-extern "C" int seg_adam_pack(float* p, const float* g, float* m, float* v, int64_t n, void* packed, const seg_pack_entry* fwd_table_dev,
-                             const int64_t* dgrad_dst_off_dev, int32_t n_entries, int64_t total_tiles, int64_t flat_off, int64_t flat_len,
-                             float lr, float b1, float b2, float eps, float grad_scale, const int64_t* step_dev, int32_t dtype, void* stream) {
-  if (!p || !g || !m || !v || !packed || !fwd_table_dev || !dgrad_dst_off_dev || !step_dev || n <= 0 || n_entries <= 0 || total_tiles <= 0) { seg_set_error("adam_pack: bad args"); return SEG_ERR_ARG; }
-  if (flat_len < 0 || flat_off < 0 || flat_off + flat_len > n) { seg_set_error("adam_pack: flat range outside the arena"); return SEG_ERR_ARG; }
-  const int64_t tb = (total_tiles + AP_TPB - 1) / AP_TPB;
-  const int64_t fb = flat_len > 0 ? (flat_len + 255) / 256 : 0;
-  if (tb + fb > 0x7fffffff) { seg_set_error("adam_pack: too many blocks"); return SEG_ERR_ARG; }
-  DISPATCH(dtype,
-           SEG_LAUNCH((adam_pack_kernel<float, true>), dim3((unsigned)(tb + fb)), dim3(256), 0, ST(stream), p, g, m, v, reinterpret_cast<float*>(packed), fwd_table_dev, dgrad_dst_off_dev, n_entries, total_tiles, flat_off, flat_len, lr, b1, b2, eps, grad_scale, step_dev),
-           SEG_LAUNCH((adam_pack_kernel<bf16_t, true>), dim3((unsigned)(tb + fb)), dim3(256), 0, ST(stream), p, g, m, v, reinterpret_cast<bf16_t*>(packed), fwd_table_dev, dgrad_dst_off_dev, n_entries, total_tiles, flat_off, flat_len, lr, b1, b2, eps, grad_scale, step_dev));
-  return seg_check_launch("adam_pack");
-}
-
 extern "C" int seg_pack_weights_dual(const float* arena, void* packed, const seg_pack_entry* fwd_table_dev, const int64_t* dgrad_dst_off_dev,
                                      int32_t n_entries, int64_t total_tiles, int32_t dtype, void* stream) {
   if (!arena || !packed || !fwd_table_dev || !dgrad_dst_off_dev || n_entries <= 0 || total_tiles <= 0) { seg_set_error("pack_dual: bad args"); return SEG_ERR_ARG; }
   const int64_t tb = (total_tiles + AP_TPB - 1) / AP_TPB;
   if (tb > 0x7fffffff) { seg_set_error("pack_dual: too many blocks"); return SEG_ERR_ARG; }
-  float* a = const_cast<float*>(arena);            // (never written: ADAM = false)
   DISPATCH(dtype,
-           SEG_LAUNCH((adam_pack_kernel<float, false>), dim3((unsigned)tb), dim3(256), 0, ST(stream), a, nullptr, nullptr, nullptr, reinterpret_cast<float*>(packed), fwd_table_dev, dgrad_dst_off_dev, n_entries, total_tiles, 0, 0, 0.f, 0.f, 0.f, 0.f, 0.f, nullptr),
-           SEG_LAUNCH((adam_pack_kernel<bf16_t, false>), dim3((unsigned)tb), dim3(256), 0, ST(stream), a, nullptr, nullptr, nullptr, reinterpret_cast<bf16_t*>(packed), fwd_table_dev, dgrad_dst_off_dev, n_entries, total_tiles, 0, 0, 0.f, 0.f, 0.f, 0.f, 0.f, nullptr));
+           SEG_LAUNCH(pack_dual_kernel<float>, dim3((unsigned)tb), dim3(256), 0, ST(stream), arena, reinterpret_cast<float*>(packed), fwd_table_dev, dgrad_dst_off_dev, n_entries, total_tiles),
+           SEG_LAUNCH(pack_dual_kernel<bf16_t>, dim3((unsigned)tb), dim3(256), 0, ST(stream), arena, reinterpret_cast<bf16_t*>(packed), fwd_table_dev, dgrad_dst_off_dev, n_entries, total_tiles));
   return seg_check_launch("pack_weights_dual");
 }
 

@@ -120,9 +120,9 @@ class ParamStore(object):
                 blk += ne // 1024                 # one block per 32x32 tile
         self.packed = torch.zeros(max(poff, 8), dtype=torch_dtype(dtype), device=device)
         self.n_pack_entries, self.pack_blocks = len(entries), blk
-        # Adam fused with the re-pack (seg_adam_pack): the forward entries only, tiles counted over them, each with the packed
-        # offset of its dgrad copy; the unpacked first layer(s) form one flat range.  Usable when every parameter is covered.
-        self.adam_pack = None
+        # one-read re-pack (seg_pack_weights_dual): the forward entries only, 32x32 tiles counted over them, each with the packed
+        # offset of its dgrad copy (training stores; an inference store has no dgrad copies and uses the table-driven kernel)
+        self.pack_dual = None
         if training and entries:
             fwd, dg, tiles = [], [], 0
             for i, e in enumerate(entries):
@@ -134,12 +134,8 @@ class ParamStore(object):
                 nxt = entries[i + 1] if i + 1 < len(entries) else None
                 dg.append(nxt.dst_off if nxt is not None and nxt.src_off == e.src_off and nxt.mode in (L.PACK_CONV_DGRAD, L.PACK_UP_DGRAD) else -1)
                 fwd.append(f)
-            firsts = [l for l in layers if not l.packed]
-            lo = min([l.w_off for l in firsts] or [0]); hi = max([l.b_off + l.nbias for l in firsts] or [0])
-            covered = sum(l.wsize + l.nbias for l in layers if l.packed) + (hi - lo)
-            if covered == off and sum(l.wsize + l.nbias for l in firsts) == hi - lo:
-                self.adam_pack = (torch.frombuffer(bytearray(b''.join(bytes(f) for f in fwd)), dtype=torch.uint8).to(device),
-                                  torch.tensor(dg, dtype=torch.int64, device=device), len(fwd), tiles, lo, hi - lo)
+            self.pack_dual = (torch.frombuffer(bytearray(b''.join(bytes(f) for f in fwd)), dtype=torch.uint8).to(device),
+                              torch.tensor(dg, dtype=torch.int64, device=device), len(fwd), tiles)
         if entries:
             raw = b''.join(bytes(e) for e in entries)
             self.pack_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
@@ -187,30 +183,9 @@ class ParamStore(object):
         return self._unflatten(self.g)
 
 
-class _Forks(object):
-    """Cross-stream dependencies of one Plan.run: `dst waits for what src holds now`.  SEG_RAW_EVENTS=1 uses raw HIP
-    events created with hipEventDisableTiming | hipEventReleaseToDevice (recycled from a pool) instead of torch events."""
-
-    pool, raw = [], None
-
-    def __init__(self):
-        if _Forks.raw is None:
-            _Forks.raw = os.environ.get('SEG_RAW_EVENTS', '0') != '0'
-        self.i = 0
-
-    def __call__(self, src, dst):
-        if not _Forks.raw:
-            ev = torch.cuda.Event(); ev.record(src); dst.wait_event(ev)
-            return
-        h = L.hip_runtime()
-        if self.i == len(_Forks.pool):
-            e = C.c_void_p()
-            if h.hipEventCreateWithFlags(C.byref(e), L.HIP_EVENT_DISABLE_TIMING | L.HIP_EVENT_RELEASE_TO_DEVICE) != 0:
-                raise L.SegError('hipEventCreateWithFlags failed')
-            _Forks.pool.append(e)
-        e = _Forks.pool[self.i]; self.i += 1
-        if h.hipEventRecord(e, C.c_void_p(src.cuda_stream)) != 0 or h.hipStreamWaitEvent(C.c_void_p(dst.cuda_stream), e, 0) != 0:
-            raise L.SegError('hipEventRecord / hipStreamWaitEvent failed')
+def _fork(src, dst):
+    """cross-stream dependency: `dst waits for what src holds now` (under stream capture this becomes a graph edge)"""
+    ev = torch.cuda.Event(); ev.record(src); dst.wait_event(ev)
 
 
 class Plan(object):
@@ -248,17 +223,12 @@ class Plan(object):
                     torch.cuda.synchronize()
             return
         main = torch.cuda.current_stream()
-        fork = _Forks()
+        fork = _fork
         used = {}
         aux = side[-1]                   # dedicated stream for side='aux' ops (weight re-pack), joined by a 'join_aux' marker
         aux_used = False
-        defer = os.environ.get('SEG_DEFER_SIDE', '0') != '0'
-        batch = int(os.environ.get('SEG_SIDE_BATCH', '0'))     # > 0: fork the side streams once per `batch` main launches
-        pending = []
-        since = 0
         main_epoch, forked_at = 0, {}             # launches on the main stream so far; per side stream: the count at its last fork
         capturing = torch.cuda.is_current_stream_capturing()
-
         dirty = set()                             # side streams with launches the main stream has not waited for yet
 
         def join(st_):
@@ -271,24 +241,11 @@ class Plan(object):
                 # fork elision below must not treat it as up to date (a later op on it may consume st_'s output)
                 main_epoch += 1
 
-        def flush():
-            ev1 = None
-            if batch > 0 and pending:
-                ev1 = torch.cuda.Event(); ev1.record(main)      # one fork point for everything queued (later = still a valid dependency)
-            for ev_, st_, fn_, args_, name_ in pending:
-                st_.wait_event(ev1 if ev1 is not None else ev_)
-                dirty.add(id(st_))
-                rc_ = fn_(*args_, C.c_void_p(st_.cuda_stream))
-                if rc_ != 0:
-                    L.check(rc_, '%s/%s' % (self.name, name_))
-            del pending[:]
-
         for i, (name, fn, args) in enumerate(self.ops):
             tag = self.meta[i].get('side', 0)
             if name in skip or self.meta[i].get('flavor', flavor) != flavor:
                 continue
             if fn is None and name == 'join_all':      # marker: the main stream waits for every side stream used so far
-                flush()
                 for o_ in used.values():
                     join(o_)
                 if aux_used:
@@ -299,12 +256,7 @@ class Plan(object):
                     join(aux)
                     aux_used = False
                 continue
-            if tag == 'aux' or tag == 'aux_join':
-                if tag == 'aux_join':
-                    flush()
-                    for o_ in used.values():             # everything the filter-gradient streams hold so far
-                        if o_ is not aux:
-                            fork(o_, aux)
+            if tag == 'aux':
                 if capturing or forked_at.get(id(aux)) != main_epoch:
                     fork(main, aux)
                     forked_at[id(aux)] = main_epoch
@@ -313,18 +265,9 @@ class Plan(object):
                 rc = fn(*args, C.c_void_p(aux.cuda_stream))
             elif tag:
                 # side stream ids are assigned when the plan is built (Net._add_wgrad alternates 1, 2): a filter
-                # gradient and the batched reduction of its slabs are then in order on ONE stream
+                # gradient and the reduction of its slabs are then in order on ONE stream
                 st = side[(tag - 1) % (len(side) - 1)] if len(side) > 1 else side[0]
                 used[id(st)] = st
-                if batch > 0:
-                    pending.append((None, st, fn, args, name))
-                    continue
-                if defer:
-                    # same dependencies, but the side launch is ISSUED after the next main-stream launch: under capture
-                    # the main-stream successor then is the first child of its predecessor (graph order)
-                    ev = torch.cuda.Event(); ev.record(main)
-                    pending.append((ev, st, fn, args, name))
-                    continue
                 # A fork (event recorded on the main stream + wait on the side stream) is only needed if something was launched
                 # on the main stream since this side stream last forked from it: a launch right behind its producer on the SAME
                 # side stream (the slab reduction behind its filter gradient) is already ordered.  Each redundant fork costs ~20 us
@@ -339,13 +282,8 @@ class Plan(object):
             else:
                 main_epoch += 1
                 rc = fn(*args, sp)
-                if rc == 0 and pending:
-                    since += 1
-                    if batch <= 0 or since >= batch:
-                        flush(); since = 0
             if rc != 0:
                 L.check(rc, '%s/%s' % (self.name, name))
-        flush()
         if aux_used:
             used[id(aux)] = aux
         for st in used.values():
@@ -412,12 +350,8 @@ class Plan(object):
                 if side and aux_used:
                     ev = torch_mod.cuda.Event(); ev.record(aux); main.wait_event(ev); aux_used = False
                 continue
-            if tag == 'aux' or tag == 'aux_join':
+            if tag == 'aux':
                 st = aux; aux_used = True
-                if tag == 'aux_join':
-                    for o_ in used.values():
-                        if o_ is not aux:
-                            ev = torch_mod.cuda.Event(); ev.record(o_); aux.wait_event(ev)
             elif tag:
                 st = side[(tag - 1) % (len(side) - 1)] if len(side) > 1 else side[0]
                 used[id(st)] = st
@@ -440,31 +374,6 @@ class Plan(object):
         return [(self.ops[i][0], self.kernel_name(i), e0.elapsed_time(e1), self.meta[i].get('flops', 0), self.meta[i].get('bytes', 0)) for i, e0, e1 in recs]
 
 
-def tune_key(d):
-    """Shape signature of a conv / wgrad descriptor: the unit the per-shape tile table (tuning/gfx950.json) is keyed by."""
-    if isinstance(d, L.ConvDesc):
-        return 'c:%dx%ds%du%d:B%d:%dx%d:k%d:n%d/%d:m%d:p%d:a%d:f%d:s%d' % (d.KH, d.KW, d.stride, d.up2, d.B, d.Hi, d.Wi, d.src0.c + (d.src1.c if d.src1.ptr else 0),
-                                                                 d.n_count, d.n_total, 1 if d.mask.ptr else 0, d.pad_t, d.accum, d.out_f32, d.n_split)
-    return 'w:%dx%ds%d:B%d:%dx%d:k%d:n%d:b%d' % (d.KH, d.KW, d.stride, d.B, d.Ho, d.Wo, d.src0.c + (d.src1.c if d.src1.ptr else 0), d.dz.c, d.bias_mode)
-
-
-_TUNE = None
-
-
-def load_tuning():
-    """Per-shape tile choices found by tools/autotune.py IN the overlapped train step (a kernel that is fastest alone is
-    often not the one that co-runs best with the filter gradients).  SEG_TUNE=0 disables, SEG_TUNE_FILE overrides."""
-    global _TUNE
-    if _TUNE is None:
-        _TUNE = {}
-        if os.environ.get('SEG_TUNE', '1') != '0':
-            import json
-            path = os.environ.get('SEG_TUNE_FILE', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuning', 'gfx950.json'))
-            if os.path.exists(path):
-                _TUNE = {k: int(v) for k, v in json.load(open(path)).items() if not k.startswith('_')}
-    return _TUNE
-
-
 class Net(object):
     """Emits launches for one network instance (fixed batch / spatial size / dtype)."""
 
@@ -482,16 +391,11 @@ class Net(object):
         self._wg_rr = 0
         self.side_enabled = True
         self.pool_fused = False
-        self.tune = load_tuning() if dtype == L.SEG_BF16 else {}
 
     @property
     def es(self):
         """bytes per activation element in HBM"""
         return 4 if self.dtype == L.SEG_F32 else 2
-
-    def _tuned(self, d):
-        if d.cfg == 0 and self.tune:
-            d.cfg = self.tune.get(tune_key(d), 0)
 
     def act(self, H, W, C, f32=False, name=''):
         a = Act(self.B, H, W, C, self.dtype, self.device, f32=f32, name=name)
@@ -546,7 +450,6 @@ class Net(object):
         d.relu = 1 if layer.relu else 0
         d.out_f32 = 1 if out_f32 else 0
         d.dtype = self.dtype; d.cfg = cfg
-        self._tuned(d)
         name = layer.name
         if pool is not None and self.dtype == L.SEG_BF16 and dst_off == (0, 0) and os.environ.get('SEG_FUSE_POOL', '1') != '0':
             d.pool = pool.view(); d.pool_h, d.pool_w = pool.H, pool.W
@@ -576,7 +479,6 @@ class Net(object):
         d.bias = self.store.p_ptr(layer.b_off); d.bias_n = layer.cout
         d.dst = dst.view(); d.up2 = 1; d.up_cout = layer.cout_p; d.mask = L.null_view()
         d.relu = 1 if layer.relu else 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
-        self._tuned(d)
         plan.keep.append(d)
         fl = 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
         by = self.B * Hi * Wi * (layer.cin + 4 * layer.cout) * self.es + 4 * layer.cin * layer.cout * self.es
@@ -680,7 +582,6 @@ class Net(object):
         w.dz = dz.view(); w.n_log = layer.cout
         w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = 0
         w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
-        self._tuned(w)
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
         self._wg_bytes = self.B * (H * W * layer.cin * 4 + Ho * Wo * layer.cout * self.es) + 9 * layer.cin * layer.cout * 4
@@ -707,7 +608,6 @@ class Net(object):
         w.dz = dz.view(dz_off[0], dz_off[1]); w.n_log = layer.cout
         w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = wcfg
         w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
-        self._tuned(w)
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
         self._wg_bytes = self.B * (Hi * Wi * layer.cin + Ho * Wo * layer.cout) * self.es + k * k * layer.cin * layer.cout * 4
@@ -732,7 +632,6 @@ class Net(object):
             d.mask = mask0.view(moff0[0], moff0[1]) if mask0 is not None else L.null_view()
             d.mask1 = mask1.view(moff1[0], moff1[1]) if mask1 is not None else L.null_view()
             d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
-            self._tuned(d)
             plan.keep.append(d)
             fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
             nmask = sum(layer.cin_segs[i] for i, m_ in enumerate((mask0, mask1)) if m_ is not None)
@@ -755,7 +654,6 @@ class Net(object):
                 d.dst = dst.view(doff[0], doff[1]); d.up2 = 0; d.up_cout = 0
                 d.mask = mask.view(moff[0], moff[1]) if mask is not None else L.null_view()
                 d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
-                self._tuned(d)
                 plan.keep.append(d)
                 fl = 2 * self.B * Ho * Wo * k * k * layer.cin_segs[i] * layer.cout
                 by = (self.B * (Ho * Wo * layer.cout + Hi * Wi * layer.cin_segs[i] * (1 + (1 if mask is not None else 0) + (1 if d.accum else 0))) * self.es
@@ -774,7 +672,6 @@ class Net(object):
         w.dz = src.view(); w.n_log = layer.cin
         w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = wcfg
         w.bias_mode = 2; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
-        self._tuned(w)
         self._wgrad_ws(w, plan)
         fl = 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
         self._wg_bytes = self.B * Hi * Wi * (layer.cin + 4 * layer.cout) * self.es + 4 * layer.cin * layer.cout * 4
@@ -792,7 +689,6 @@ class Net(object):
             d.dst = dsrc.view(); d.up2 = 0; d.up_cout = 0
             d.mask = mask.view() if mask is not None else L.null_view()
             d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
-            self._tuned(d)
             plan.keep.append(d)
             by = self.B * Hi * Wi * (4 * layer.cout + layer.cin * (2 if mask is not None else 1)) * self.es + 4 * layer.cin * layer.cout * self.es
             plan.add(layer.name + '/dx', self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl, bytes=by)
@@ -1006,10 +902,10 @@ class Net(object):
         meta = {'kernel': 'pack_kernel'}
         if aux:
             meta['side'] = 'aux'
-        if getattr(s, 'adam_pack', None) is not None and os.environ.get('SEG_PACK_DUAL', '1') != '0':
+        if getattr(s, 'pack_dual', None) is not None:
             # training stores: both packed copies of a tile from ONE read of the arena
-            tab, dg, ne, tiles, _, _ = s.adam_pack
-            meta['kernel'] = 'adam_pack_kernel'
+            tab, dg, ne, tiles = s.pack_dual
+            meta['kernel'] = 'pack_dual_kernel'
             plan.add('pack', self.lib.seg_pack_weights_dual, s.p.data_ptr(), s.packed.data_ptr(), tab.data_ptr(), dg.data_ptr(), ne, tiles,
                      self.dtype, **meta)
             return
@@ -1025,28 +921,16 @@ class Net(object):
         plan.ops.append(('join_aux', None, ()))
         plan.meta.append({'kernel': 'marker'})
 
-    def adam(self, plan, lr, grad_scale=1.0, b1=0.9, b2=0.999, eps=1e-8, lo=0, hi=None, side=None):
-        """TF-Adam over the arena slice [lo, hi).  side='aux_join': on the auxiliary stream, after everything launched so
-        far on the main AND the filter-gradient streams (an early update of the buckets whose gradients are complete)."""
+    def adam(self, plan, lr, grad_scale=1.0, b1=0.9, b2=0.999, eps=1e-8, lo=0, hi=None):
+        """TF-Adam over the arena slice [lo, hi)."""
         s = self.store
         hi = s.n if hi is None else hi
         if hi <= lo:
             return
         meta = {'kernel': 'adam_kernel'}
-        if side:
-            meta['side'] = side
         o = lo * 4
         plan.add('adam[%d:%d]' % (lo, hi), self.lib.seg_adam, s.p.data_ptr() + o, s.g.data_ptr() + o, s.m.data_ptr() + o, s.v.data_ptr() + o,
                  hi - lo, lr, b1, b2, eps, grad_scale, s.step.data_ptr() + 8, **meta)
-
-    def adam_pack(self, plan, lr, grad_scale=1.0, b1=0.9, b2=0.999, eps=1e-8):
-        """TF-Adam over the whole arena fused with the re-pack of the updated weights (seg_adam_pack): same arithmetic and
-        the same packed bytes as adam() followed by pack(), without the two extra reads of the fp32 arena."""
-        s = self.store
-        tab, dg, ne, tiles, flo, flen = s.adam_pack
-        plan.add('adam+pack', self.lib.seg_adam_pack, s.p.data_ptr(), s.g.data_ptr(), s.m.data_ptr(), s.v.data_ptr(), s.n,
-                 s.packed.data_ptr(), tab.data_ptr(), dg.data_ptr(), ne, tiles, flo, flen, lr, b1, b2, eps, grad_scale,
-                 s.step.data_ptr() + 8, self.dtype, kernel='adam_pack_kernel')
 
     def step_begin(self, plan, loss_buf, aux=True):
         """global_step += 1 and loss accumulator = 0, first thing of a training forward (auxiliary stream: off the

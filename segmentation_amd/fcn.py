@@ -165,8 +165,7 @@ class FCNModel(BaseModel):
         fwd = self.fwd_plan = E.Plan('fwd')
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
         net.step_begin(fwd, self.loss_buf)     # aux stream: global_step += 1, loss accumulator = 0
-        if not self.fused_adam_pack:
-            net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1
+        net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1
         col = net.first_im2col(fwd, Ly['conv1'], self.input_x, H, W)         # side stream, overlaps the forward pass
         A, geo = self._emit_forward(net, fwd, self.input_x, H, W)
         self.acts = A

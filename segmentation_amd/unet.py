@@ -207,8 +207,7 @@ class UNetModel(BaseModel):
         fwd = self.fwd_plan = E.Plan('fwd')
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
         net.step_begin(fwd, self.loss_buf)     # aux stream: global_step += 1, loss accumulator = 0
-        if not self.fused_adam_pack:
-            net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1_1
+        net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1_1
         cols = []       # im2col of the input for conv1_1's filter gradient: side stream, right after conv1_1 (both are
         #                 bandwidth-bound), overlapping the rest of the forward pass
         fuse_head = (E.rup(Ly['output'].cin) in (32, 64) and self.n_classes <= 32 and os.environ.get('SEG_FUSE_HEAD', '1') != '0')

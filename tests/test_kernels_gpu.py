@@ -36,26 +36,6 @@ def _rand_params(layer, rng, dtype):
     (3, 'VALID', [64], 32, 10, 10, 2, False, 14),
     (3, 'VALID', [64, 32], 64, 35, 37, 2, True, 15),
     (3, 'SAME', [64], 64, 19, 33, 1, True, 15),
-    (3, 'VALID', [64, 32], 64, 35, 37, 2, True, 16),       # 512-pixel tile, 8 waves (two K chunk sources, ragged edges)
-    (3, 'SAME', [64], 128, 19, 67, 2, True, 16),
-    (3, 'VALID', [32], 32, 50, 40, 1, False, 17),
-    (3, 'VALID', [64], 64, 21, 19, 2, True, 51),          # weight-stationary persistent kernel (fwd + dgrad)
-    (3, 'SAME', [32], 64, 13, 35, 3, True, 51),
-    (3, 'VALID', [32, 32], 32, 20, 20, 2, True, 52),
-    (3, 'SAME', [64, 64], 32, 9, 40, 1, False, 52),
-    (3, 'VALID', [32], 32, 130, 130, 8, True, 52),        # > 768 tiles: every workgroup walks several tiles
-    (3, 'VALID', [64], 64, 21, 19, 2, True, 55),          # two consumer teams on alternate tiles
-    (3, 'SAME', [32], 64, 13, 35, 3, True, 55),
-    (3, 'VALID', [32, 32], 32, 20, 20, 2, True, 56),
-    (3, 'VALID', [32], 32, 130, 130, 8, True, 56),        # several tiles per team (odd and even counts)
-    (3, 'VALID', [64], 64, 122, 122, 3, True, 55),
-    (3, 'VALID', [160], 32, 21, 19, 1, True, 32),         # N-stage direct-to-LDS rings: 5 K chunks, 3 / 4 stages
-    (3, 'VALID', [96, 64], 64, 13, 15, 2, True, 33),
-    (3, 'SAME', [192], 32, 10, 10, 2, False, 34),
-    (3, 'VALID', [64], 32, 10, 10, 2, False, 34),         # fewer chunks than stages
-    (3, 'VALID', [160], 32, 21, 19, 1, True, 42),
-    (3, 'VALID', [96, 64], 32, 9, 12, 2, True, 44),
-    (1, 'SAME', [256], 32, 9, 9, 2, True, 44),
     (3, 'SAME', [64], 96, 9, 11, 2, True, 0),
     (3, 'VALID', [64, 32], 64, 12, 12, 2, True, 0),
     (3, 'VALID', [16], 24, 11, 11, 1, True, 0),          # unpadded channel counts (n_kernels=16 style)
@@ -111,9 +91,7 @@ def test_conv_fwd_bwd(dtype, case):
         dsrc_acts.append(da)
     store.g.zero_()
     bplan = E.Plan('b')
-    # two-source layers take the merged two-destination dgrad launch (n_split), which the tiled kernels serve
-    dcfg = 0 if (cfg < 50 or len(segs) > 1) else (cfg if all(c % 64 == 0 for c in layer.cin_p) or cfg in (52, 56) else (56 if cfg == 55 else 52))
-    net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs, cfg=dcfg)
+    net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs, cfg=0)
     net.flush_reduce(bplan)
     bplan.run(U.stream()); U.sync()
     dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (k, k), padding, 1)
@@ -407,45 +385,6 @@ def test_pack_of_several_layers_equals_packing_each_alone(dtype):
             nxt = min([x for l in s1.layers.values() for x in (getattr(l, 'pk_fwd', None), getattr(l, 'pk_dgrad', None)) if x is not None and x > o1] + [alone.size])
             n = nxt - o1
             assert np.array_equal(whole[o:o + n], alone[o1:o1 + n]), (sp[0], attr)
-
-
-@pytest.mark.parametrize('dtype', DT)
-def test_fused_adam_pack_is_bitwise_adam_then_pack(dtype, monkeypatch):
-    """seg_adam_pack, and seg_adam followed by seg_pack_weights_dual, against seg_adam followed by the table-driven
-    seg_pack_weights on a store with every layer kind (first, plain and two-source convs, 1x1, transposed conv):
-    parameters, both moments and the packed arena must agree bit for bit."""
-    dev = torch.device('cuda', 0)
-    rng = np.random.default_rng(23)
-    layers = [E.Layer('f', 'first', 3, [3], 32, 'VALID', True), E.Layer('a', 'conv', 3, [32], 64, 'VALID', True),
-              E.Layer('u', 'up', 2, [64], 32, 'VALID', True), E.Layer('c', 'conv', 3, [32, 32], 40, 'VALID', True),
-              E.Layer('o', 'conv', 1, [40], 4, 'SAME', False)]
-    params = {l.name: _rand_params(l, rng, dtype) for l in layers}
-
-    def fresh():
-        st = E.ParamStore(layers, dtype, dev, training=True)
-        st.set_params(params)
-        g = torch.Generator(device='cpu'); g.manual_seed(5)
-        st.g.copy_(torch.randn(st.n, generator=g)); st.m.copy_(torch.randn(st.n, generator=g) * 0.1); st.v.copy_(torch.rand(st.n, generator=g) * 0.01)
-        st.step.fill_(3)
-        return st, E.Net(st, 1, dtype, dev)
-
-    s0, n0 = fresh()
-    s1, n1 = fresh()
-    s2, n2 = fresh()
-    assert s1.adam_pack is not None
-    stream = torch.cuda.current_stream().cuda_stream
-    monkeypatch.setenv('SEG_PACK_DUAL', '0')
-    a = E.Plan('a'); n0.adam(a, 1e-3, grad_scale=0.5); n0.pack(a); a.run(stream)
-    assert a.meta[-1]['kernel'] == 'pack_kernel'
-    monkeypatch.setenv('SEG_PACK_DUAL', '1')
-    b = E.Plan('b'); n1.adam_pack(b, 1e-3, grad_scale=0.5); b.run(stream)
-    c = E.Plan('c'); n2.adam(c, 1e-3, grad_scale=0.5); n2.pack(c); c.run(stream)
-    assert c.meta[-1]['kernel'] == 'adam_pack_kernel'
-    torch.cuda.synchronize()
-    for other in (s1, s2):
-        for name in ('p', 'm', 'v'):
-            assert torch.equal(getattr(s0, name), getattr(other, name)), name
-        assert torch.equal(s0.packed.view(torch.uint8), other.packed.view(torch.uint8))
 
 
 def test_adam_matches_tf_variant():

@@ -2,7 +2,7 @@
 """Turns rocprofv3 outputs into the committed summaries under profiles/:
    python tools/profile_summary.py <stats_dir> <fetch_dir> <write_dir> <round-tag>
  - <tag>_kernel_stats.csv : copy of the --kernel-trace --stats table (per-kernel calls / average ns)
- - pmc_summary.json       : per kernel instance (bench.py naming) HBM bytes per launch from the TCC counters,
+ - <tag>_pmc_summary.json (+ pmc_summary.json for a round's headline tag rNN): per kernel instance (bench.py naming) HBM bytes per launch from the TCC counters,
                             corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE is in KiB and reports HALF of a wide
                             coalesced read stream on gfx950 (doubled here); WRITE_SIZE in KiB is exact."""
 import csv, glob, json, os, re, shutil, sys, collections
@@ -56,8 +56,11 @@ def main():
     for k in sorted(set(fetch) | set(write)):
         fb, wb = fetch.get(k, 0.0) * 1024 * 2, write.get(k, 0.0) * 1024
         out[k] = {'hbm_bytes_per_launch': int(fb + wb), 'fetch_bytes_corrected_x2': int(fb), 'write_bytes': int(wb)}
-    json.dump(out, open(os.path.join(root, 'pmc_summary.json'), 'w'), indent=1, sort_keys=True)
-    print('wrote', tag + '_kernel_stats.csv', 'and pmc_summary.json with', len(out), 'kernels')
+    out['_commit'] = tag                        # which build / round the counters belong to (bench.py prints it as traffic_source)
+    json.dump(out, open(os.path.join(root, tag + '_pmc_summary.json'), 'w'), indent=1, sort_keys=True)
+    if re.fullmatch(r'r\d+', tag):               # the headline workload of a round: what bench.py's roofline.traffic reads
+        json.dump(out, open(os.path.join(root, 'pmc_summary.json'), 'w'), indent=1, sort_keys=True)
+    print('wrote', tag + '_kernel_stats.csv', 'and', tag + '_pmc_summary.json with', len(out) - 1, 'kernels')
 
 
 if __name__ == '__main__':
