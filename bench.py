@@ -43,7 +43,7 @@ def parse():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--classes', type=int, default=4)
     ap.add_argument('--dtype', default='bf16')
-    ap.add_argument('--model', default='unet', choices=['unet', 'fcn8s'], help='fcn8s = BASELINE config 3 (use --size 512 --classes 21 --batch 8)')
+    ap.add_argument('--model', default='unet', choices=['unet', 'fcn8s', 'deconv'], help='fcn8s = BASELINE config 3 (use --size 512 --classes 21 --batch 8); deconv = the reference DeconvModel (SURVEY N3)')
     ap.add_argument('--mode', default='train', choices=['train', 'infer', 'mc'], help='train step (headline) / inference forward / MC-dropout inference (config 5)')
     ap.add_argument('--passes', type=int, default=30, help='--mode mc: stochastic forward passes per step')
     ap.add_argument('--nk', type=int, default=32, help='n_kernels')
@@ -247,6 +247,9 @@ def main():
     def make_model(dp_cuts=None):
         if args.model == 'unet':
             m = UNetModel(crop_aware=not args.dense, wgrad_streams=args.streams, dp_cuts=dp_cuts, **common)
+        elif args.model == 'deconv':
+            from segmentation_amd.deconvolution import DeconvModel
+            m = DeconvModel(**common)
         else:
             from segmentation_amd.fcn import FCNModel
             m = FCNModel(fcn_type='8s', **common)
@@ -338,7 +341,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic' if not args.host_data else 'synthetic, fed from host memory over PCIe (pinned ring + async H2D)',
             'config': {'workload': '%s %dx%dx3 %d-class batch=%d/GPU %s %s, n_kernels=%d'
-                                   % ('U-Net' if args.model == 'unet' else 'FCN-8s', args.size, args.size, args.classes, args.batch, args.dtype, what, args.nk),
+                                   % ({'unet': 'U-Net', 'fcn8s': 'FCN-8s', 'deconv': 'DeconvModel (BatchNorm)'}[args.model], args.size, args.size, args.classes, args.batch, args.dtype, what, args.nk),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
                        'conv1_2': ('dense' if args.dense else 'crop-aware (only the window that survives the last skip crop is computed)') if args.model == 'unet' else None,
                        'hip_graph': bool(model.use_graph) if training else False,
