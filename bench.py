@@ -150,7 +150,19 @@ def cpu_baseline(args):
     while n < 2 or (time.time() - t0 < 15.0 and n < 50):
         fn(); n += 1
     dt = time.time() - t0
-    return {'value': round(bs * n / dt / per, 3), 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'cpu_model': cpu_model(),
+    plain_c = None
+    if args.mode == 'train' and args.size <= 256:
+        # the plain-C restatement (oracle/seg_cpu.c, OpenMP): the same step without a vendor library underneath
+        from oracle import c_ops
+        cst = c_ops.CUNetStepper(p, lr=1e-4, threads=threads)
+        cb = min(bs, 2)
+        cst.train_step(x[:cb], y[:cb])
+        cn, c0 = 0, time.time()
+        while cn < 1 or (time.time() - c0 < 6.0 and cn < 10):
+            cst.train_step(x[:cb], y[:cb]); cn += 1
+        plain_c = {'value': round(cb * cn / (time.time() - c0), 3), 'unit': 'images/s', 'cores': cst.threads, 'batch': cb,
+                   'sample': '%d train steps of batch %d on libseg_cpu.so (gcc -O3 -mavx2 -mfma -fopenmp loop nests)' % (cn, cb)}
+    return {'plain_c': plain_c, 'value': round(bs * n / dt / per, 3), 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'cpu_model': cpu_model(),
             'batch': bs,
             'sample': '%d %s of batch %d at %dx%d, %d-class (oracle/torch_ref.py: the same graph%s in float32 on '
                       'torch-CPU/oneDNN, the stand-in for the TF-CPU path, which cannot run here)'

@@ -288,3 +288,57 @@ def test_pool_k_and_resize_oracle_properties():
     assert abs((r * g).sum() - (x * ops.resize_bilinear_bwd(g, (11, 10))).sum()) < 1e-10       # adjoint
     assert np.array_equal(ops.resize_bilinear(x, (11, 10)), x)                                    # identity size
     assert np.allclose(ops.resize_bilinear(np.ones((1, 5, 5, 1)), (13, 9)), 1.0)
+
+
+# ---------------- plain-C restatement (oracle/seg_cpu.c -> libseg_cpu.so) vs the numpy restatement ----------------
+def test_c_restatement_ops_match_numpy():
+    from oracle import c_ops as co
+    assert co.load().segcpu_version() == 100 and co.load().segcpu_threads() >= 1
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 13, 11, 5)).astype(np.float32)
+    w = rng.standard_normal((3, 3, 5, 7)).astype(np.float32); b = rng.standard_normal(7).astype(np.float32)
+    for pad, s in (('VALID', 1), ('SAME', 1), ('SAME', 2), ('VALID', 2)):
+        r = ops.conv2d(x, w, b, pad, s, True)
+        assert np.abs(co.conv2d(x, w, b, pad, s, True) - r).max() < 2e-5
+        dz = rng.standard_normal(r.shape).astype(np.float32)
+        assert np.abs(co.conv2d_dgrad(dz, w, (13, 11), pad, s) - ops.conv2d_dgrad(dz, w, (13, 11), pad, s)).max() < 2e-5
+        dw, db = co.conv2d_wgrad(x, dz, 3, pad, s)
+        rdw, rdb = ops.conv2d_wgrad(x, dz, (3, 3), pad, s)
+        assert np.abs(dw - rdw).max() < 1e-4 and np.abs(db - rdb).max() < 1e-5
+    # crop by view: convolving a window of x == convolving the cropped copy
+    assert np.array_equal(co.conv2d(x, w, b, window=(2, 1, 9, 8)), co.conv2d(np.ascontiguousarray(x[:, 2:11, 1:9]), w, b))
+    wt = rng.standard_normal((2, 2, 6, 5)).astype(np.float32); bt = rng.standard_normal(6).astype(np.float32)
+    r = ops.conv2d_transpose(x, wt, bt, 2, 'VALID', True)
+    assert np.abs(co.convT2x2(x, wt, bt) - r).max() < 1e-5
+    dz = rng.standard_normal(r.shape).astype(np.float32)
+    dx, dw, db = co.convT2x2_bwd(x, wt, dz)
+    rdw, rdb = ops.conv2d_transpose_wgrad(x, dz, (2, 2), 2, 'VALID')
+    assert np.abs(dx - ops.conv2d_transpose_dgrad(dz, wt, (13, 11), 2, 'VALID')).max() < 2e-5
+    assert np.abs(dw - rdw).max() < 1e-4 and np.abs(db - rdb).max() < 2e-5
+    x[0, 0:2, 0:2, 0] = 0.5                                   # tie: first position wins
+    yp, idx = co.maxpool2x2(x); rp, ridx = ops.max_pool2x2(x)
+    assert np.array_equal(yp, rp.astype(np.float32)) and np.array_equal(idx, ridx)
+    dyp = rng.standard_normal(rp.shape).astype(np.float32)
+    assert np.array_equal(co.maxpool2x2_bwd(dyp, idx, (13, 11)), ops.max_pool2x2_bwd(dyp, ridx, (13, 11)))
+    z = (rng.standard_normal((2, 5, 4, 4)) * 3).astype(np.float32); lab = rng.integers(0, 4, (2, 5, 4)).astype(np.uint8)
+    l, dzc = co.softmax_xent(z, lab)
+    lr_, _, dref = ops.softmax_xent(z, lab)
+    assert abs(l - lr_) < 1e-6 and np.abs(dzc - dref).max() < 1e-7
+
+
+def test_c_restatement_unet_train_step_matches_numpy():
+    from oracle import c_ops as co
+    p = ounet.init_params(2, 8, 3, seed=1)
+    rng = np.random.default_rng(3)
+    xb = rng.uniform(0, 1, (1, 188, 188, 3)).astype(np.float32); yb = rng.integers(0, 2, (1, 188, 188, 1)).astype(np.uint8)
+    st = co.CUNetStepper(p, lr=1e-3, threads=2)
+    l, g, c = st.loss_and_grads(xb, yb)
+    lr_, gr, cr = ounet.loss_and_grads(p, xb, yb)
+    assert abs(l - lr_) < 1e-6 and np.abs(c['logits'] - cr['logits']).max() < 1e-5
+    for n in gr:
+        for k in ('weights', 'biases'):
+            assert np.abs(g[n][k] - gr[n][k]).max() <= 2e-4 * (np.abs(gr[n][k]).max() + 1e-30), (n, k)
+    mm, vv = ounet.init_opt_state(p)
+    st.train_step(xb, yb)
+    _, p1, _, _ = ounet.train_step(p, mm, vv, 1, xb, yb, lr=1e-3)
+    assert max(np.abs(st.p[n][k] - p1[n][k]).max() for n in p1 for k in ('weights', 'biases')) < 1e-5
