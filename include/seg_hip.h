@@ -290,12 +290,13 @@ int seg_maxpool_k_bwd(const seg_view* src, const seg_view* dpool, const seg_view
  *               training == 0: mean / variance come from moving[] (the test() path).
  *               y = (a - mean) * rstd + beta.   ws: >= seg_bn_ws_bytes(C) bytes of scratch (partial sums, fixed order).
  *   seg_bn_relu_bwd  (training statistics)  dbeta[c] = sum dy;  da = rstd * (dy - mean(dy) - xhat * mean(dy * xhat));
- *               dz = da where a > 0 else 0  (the ReLU-grad of the producing convolution, fused: dz feeds its wgrad / dgrad). */
+ *               dz = da where a > 0 else 0  (the ReLU-grad of the producing convolution, fused: dz feeds its wgrad / dgrad).
+ *               dbeta_add != 0: dbeta += (a second pass through the same layer, e.g. the adversary's real and fake batches). */
 int64_t seg_bn_ws_bytes(int32_t C);
 int seg_bn_fwd(const seg_view* a, const seg_view* y, const float* beta, float* moving, float* stats, int32_t training, float decay,
                float eps, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype, void* stream);
-int seg_bn_relu_bwd(const seg_view* a, const seg_view* dy, const seg_view* dz, const float* stats, float* dbeta, int32_t B,
-                    int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype, void* stream);
+int seg_bn_relu_bwd(const seg_view* a, const seg_view* dy, const seg_view* dz, const float* stats, float* dbeta, int32_t dbeta_add,
+                    int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype, void* stream);
 
 /* tf.image.resize_bilinear(x, [Hd, Wd]) with align_corners=False (models/deconvolution.py:160): source coordinate =
  * dst * (Hs/Hd), lerp of the 2x2 neighbours (upper index clamped).  bwd is the adjoint, in gather form (fixed order). */
@@ -308,6 +309,28 @@ int seg_resize_bilinear_bwd(const seg_view* ddst, int32_t Hd, int32_t Wd, const 
  * draws a fresh mask at every replay; the backward launch (dy -> dz with the same arguments) regenerates the forward mask. */
 int seg_dropout_step(const seg_view* x, const seg_view* y, int32_t B, int32_t H, int32_t W, int32_t C, float keep, uint64_t seed,
                      uint64_t offset, const int64_t* step_dev, int32_t dtype, void* stream);
+
+/* ---- adversarial segmentation training (models/basemodel.py:215-355; csrc/adv_ops.hip).  The adversary's convolutions,
+ * pools, resize and dense layers are seg_dconv_*, seg_maxpool_k_*, seg_resize_bilinear_*; these are the remaining pieces. ----
+ *   seg_onehot          tf.one_hot(input_y) over the output window -> the adversary's "real" map           (basemodel.py:283)
+ *   seg_softmax_probs   softmax(y_hat) -> the adversary's "fake" map (float logits in, compute dtype out)   (basemodel.py:285)
+ *   seg_softmax_bwd_add dlogits += scale * p * (dp - sum dp p): lambda * d l_bce_fake_one / d y_hat         (basemodel.py:334)
+ *   seg_flatten         slim.flatten (NHWC order of the logical channels) and its adjoint                   (basemodel.py:251)
+ *   seg_bn_rows_fwd/bwd slim.batch_norm on [B, F] feature rows (any F; training statistics; relu_mask gates
+ *                       dz by a > 0 when the rows are a ReLU output)                                        (basemodel.py:252,256)
+ *   seg_bce2            mean_b softmax_cross_entropy_with_logits(one_hot(label), adversary logits) stored to *loss_out,
+ *                       its gradient * grad_scale to dlogits                                                (basemodel.py:287-297) */
+int seg_onehot(const uint8_t* labels, int32_t LH, int32_t LW, int32_t ly0, int32_t lx0, int32_t B, int32_t H, int32_t W,
+               const seg_view* dst, int32_t dtype, void* stream);
+int seg_softmax_probs(const seg_view* logits, int32_t B, int32_t H, int32_t W, int32_t n_classes, const seg_view* dst, int32_t dtype, void* stream);
+int seg_softmax_bwd_add(const seg_view* logits, const seg_view* dprobs, int32_t B, int32_t H, int32_t W, int32_t n_classes, float scale,
+                        const seg_view* dlogits, int32_t dtype, void* stream);
+int seg_flatten(const seg_view* a, int32_t B, int32_t H, int32_t W, int32_t C, const seg_view* f, int32_t backward, int32_t dtype, void* stream);
+int seg_bn_rows_fwd(const seg_view* a, const seg_view* y, const float* beta, float* moving, float* stats, int32_t B, int32_t F,
+                    float decay, float eps, int32_t dtype, void* stream);
+int seg_bn_rows_bwd(const seg_view* a, const seg_view* dy, const seg_view* dz, const float* stats, float* dbeta, int32_t dbeta_add, int32_t B,
+                    int32_t F, int32_t relu_mask, int32_t dtype, void* stream);
+int seg_bce2(const seg_view* logits, int32_t B, int32_t label, float grad_scale, float* loss_out, const seg_view* dlogits, int32_t dtype, void* stream);
 
 /* float32 NHWC -> dtype NHWC with channel padding (feeding placeholder inputs). */
 int seg_cast_pad(const float* x, int64_t npix, int32_t c, const seg_view* dst_dense, int32_t dtype, void* stream);

@@ -280,3 +280,39 @@ def deconv_loss_and_grads(p, x, y, masks=None, keep=0.5, dtype=torch.float64):
     loss.backward()
     g = {n: {k: a.grad.numpy() for k, a in t.items()} for n, t in tp.items()}
     return float(loss.detach()), g, logits.detach().numpy(), {n: (m.numpy(), v.numpy()) for n, (m, v) in stats.items()}
+
+
+# Adversarial training terms (models/basemodel.py:215-355): independent torch-autograd composition of oracle/adversary.py
+# ---------------------------------------------------------------------------------------------------------------------
+def adversary_forward(tp, x):
+    """tp: {layer: {weights, biases | beta}} torch tensors; x [B,h,w,C] -> logits [B,2] (training-mode batch norms)"""
+    B = x.shape[0]
+    net = _resize_tf(x, (x.shape[1] // 4, x.shape[2] // 4))
+    net = _bn_train(_conv_s(net, tp['adv_conv1']['weights'], tp['adv_conv1']['biases'], 2, False), tp['adv_bn1']['beta'])[0]
+    net = F.max_pool2d(net.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    net = _bn_train(_conv_s(net, tp['adv_conv2']['weights'], tp['adv_conv2']['biases'], 2, False), tp['adv_bn2']['beta'])[0]
+    net = F.max_pool2d(net.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    f = net.reshape(B, 1, 1, -1)
+    f = _bn_train(f, tp['adv_bn3']['beta'])[0].reshape(B, -1)
+    h = torch.relu(f @ tp['adv_fc1']['weights'] + tp['adv_fc1']['biases'])
+    h = _bn_train(h.reshape(B, 1, 1, -1), tp['adv_bn4']['beta'])[0].reshape(B, -1)
+    return h @ tp['adv_output']['weights'] + tp['adv_output']['biases']
+
+
+def adversarial_terms(p_adv, seg_logits, y_win, n_classes, lam=2.0, dtype=torch.float64):
+    tp = {n: {k: torch.tensor(np.asarray(a), dtype=dtype, requires_grad=True) for k, a in t.items() if k in ('weights', 'biases', 'beta')}
+          for n, t in p_adv.items()}
+    z = torch.tensor(np.asarray(seg_logits), dtype=dtype, requires_grad=True)
+    real = F.one_hot(torch.as_tensor(np.asarray(y_win)[..., 0].astype(np.int64)), n_classes).to(dtype)
+    fake = torch.softmax(z, -1)
+    lr_, lf_ = adversary_forward(tp, real), adversary_forward(tp, fake)
+    B = z.shape[0]
+    ones, zeros = torch.ones(B, dtype=torch.int64), torch.zeros(B, dtype=torch.int64)
+    l_real, l_fake, l_one = F.cross_entropy(lr_, ones), F.cross_entropy(lf_, zeros), F.cross_entropy(lf_, ones)
+    flat = [a for t in tp.values() for a in t.values()]
+    ga = torch.autograd.grad(l_real + l_fake, flat, retain_graph=True)
+    gz = torch.autograd.grad(l_one, z)[0]
+    it = iter(ga)
+    adv_grads = {n: {k: next(it).numpy() for k in t} for n, t in tp.items()}
+    return {'l_bce_real': float(l_real.detach()), 'l_bce_fake': float(l_fake.detach()), 'l_bce_fake_one': float(l_one.detach()), 'd_seg_logits': lam * gz.numpy(),
+            'adv_grads': adv_grads, 'logits_real': lr_.detach().numpy(), 'logits_fake': lf_.detach().numpy()}

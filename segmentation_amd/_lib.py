@@ -91,10 +91,17 @@ SIGNATURES = {
     'seg_maxpool_k_fwd': [PV, PV, i32, i32, i32, i32, i32, i32, vp],
     'seg_maxpool_k_bwd': [PV, PV, PV, i32, i32, i32, i32, i32, i32, vp],
     'seg_bn_fwd': [PV, PV, vp, vp, vp, i32, f32, f32, i32, i32, i32, i32, i32, vp, i32, vp],
-    'seg_bn_relu_bwd': [PV, PV, PV, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp],
+    'seg_bn_relu_bwd': [PV, PV, PV, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp],
     'seg_resize_bilinear_fwd': [PV, i32, i32, PV, i32, i32, i32, i32, i32, vp],
     'seg_resize_bilinear_bwd': [PV, i32, i32, PV, i32, i32, i32, i32, i32, vp],
     'seg_dropout_step': [PV, PV, i32, i32, i32, i32, f32, u64, u64, vp, i32, vp],
+    'seg_onehot': [vp, i32, i32, i32, i32, i32, i32, i32, PV, i32, vp],
+    'seg_softmax_probs': [PV, i32, i32, i32, i32, PV, i32, vp],
+    'seg_softmax_bwd_add': [PV, PV, i32, i32, i32, i32, f32, PV, i32, vp],
+    'seg_flatten': [PV, i32, i32, i32, i32, PV, i32, i32, vp],
+    'seg_bn_rows_fwd': [PV, PV, vp, vp, vp, i32, i32, f32, f32, i32, vp],
+    'seg_bn_rows_bwd': [PV, PV, PV, vp, vp, i32, i32, i32, i32, i32, vp],
+    'seg_bce2': [PV, i32, i32, f32, vp, PV, i32, vp],
 }
 
 _lib = None

@@ -39,7 +39,7 @@ class BaseModel(object):
                  load_snapshot_from=None,
                  adversarial_training=False,
                  dtype='bf16', use_graph=True, crop_aware=True, device=None, process_group=None, seed=5555,
-                 overlap_allreduce=True, wgrad_streams=2, dp_cuts=None):
+                 overlap_allreduce=True, wgrad_streams=2, dp_cuts=None, adversarial_lr=1e-5, adv_lambda=2.0):
         self.mode = mode
         self.log_dir = log_dir
         self.dataset = dataset
@@ -51,9 +51,11 @@ class BaseModel(object):
         self.learning_rate = learning_rate
         self.input_channel = input_channel
         self.adversarial_training = adversarial_training
-        if adversarial_training:
-            # broken at HEAD in the reference and out of scope for the hot path
-            raise Exception('adversarial_training is not supported by the MI355X hot path')
+        # adversarial training (models/basemodel.py:215-355; broken at HEAD in the reference, SURVEY F9: rebuilt to its intended
+        # construction, segmentation_amd/adversary.py).  `adversarial_lr` is read but never set by the reference's seg models.
+        self.adversarial_lr = adversarial_lr
+        self.adv_lambda = adv_lambda
+        self.adversary = None
         if autoencoder:
             raise Exception('autoencoder mode is not supported by the MI355X hot path')
         if isinstance(input_dims, int):            # F6: the reference default is an int
@@ -88,6 +90,8 @@ class BaseModel(object):
         self.seed = seed
         self.dp_cuts = dp_cuts                   # gradient-bucket boundaries (layer names, backward order); None = model default
         self.pg = D.DataParallel(process_group, overlap=overlap_allreduce)
+        if adversarial_training and self.pg.enabled:
+            raise Exception('adversarial_training runs in one process (the adversary has no gradient all-reduce)')
         self._graphs = {}
         # side streams: wgrad_streams for the filter gradients + one auxiliary (weight re-pack)
         self._side = [torch.cuda.Stream(self.device) for _ in range(wgrad_streams + 1)] if wgrad_streams > 0 else None
@@ -391,6 +395,25 @@ class BaseModel(object):
         """Mean x-entropy of the most recent train_step (synchronises)."""
         return float(self.loss_buf.item())
 
+    def _attach_adversary(self, plan, logits, oh, ow, LH, LW, dlogits):
+        """adversarial_training: appends the adversary (forward on one_hot(labels) and softmax(logits), its own gradients, and the
+        adversarial term of the segmentation gradient added into `dlogits`) to the training forward plan, right behind the
+        x-entropy launch."""
+        from .adversary import Adversary
+        self.adversary = Adversary(self.batch_size, oh, ow, self.n_classes, self.dtype, self.device, self.store.step.data_ptr() + 8,
+                                   lr=self.adversarial_lr, lam=self.adv_lambda, seed=self.seed + 2222)
+        self.adversary.emit(plan, logits, self.input_y, LH, LW, self.label_off, dlogits)
+
+    def last_losses(self):
+        """The scalars the reference writes as summaries (models/basemodel.py:299-301,347-351), of the most recent train_step."""
+        x = self.last_loss()
+        if self.adversary is None:
+            return {'seg_xentropy': x, 'seg_loss': x, 'loss': x}
+        r, f, o = [float(v) for v in self.adversary.losses[:3].cpu().numpy()]
+        lam = self.adv_lambda
+        return {'seg_xentropy': x, 'l_bce_real': r, 'l_bce_fake': f, 'l_bce_fake_one': o, 'seg_loss': x + lam * o, 'adv_loss': r + f,
+                'loss': x - lam * (r + f)}
+
     def write_summary(self, op=None, feed_dict=None):
         if self._summary_fh is not None:
             rec = {'global_step': self.global_step, 'time': time.time()}
@@ -452,11 +475,13 @@ class BaseModel(object):
         self._repack()
 
     def _state_blob(self):
-        """non-trainable tensors to snapshot ({name: ndarray}); models with batch norm override"""
-        return {}
+        """tensors to snapshot beside the model's trainable ones ({name: ndarray}): the adversary's variables; models with batch
+        norm add their moving averages"""
+        return self.adversary.state_blob() if self.adversary is not None else {}
 
     def _load_state(self, z):
-        pass
+        if self.adversary is not None:
+            self.adversary.load_state(z)
 
     def _repack(self):
         self._packed_dirty = False
@@ -499,12 +524,16 @@ class BaseModel(object):
             self.bwd_plan.extend(plan)
         upd = self.upd_plan = E.Plan('update')
         self.net.adam(upd, self.learning_rate, grad_scale=1.0 / self.pg.world)
+        if self.adversary is not None:
+            self.adversary.emit_update(upd)
         # the re-pack of the updated weights is the first op of the next forward plan (aux stream)
         self.bwd_upd_plan = E.Plan('bwd+update')
         for plan, _ in self.bwd_segments:
             self.bwd_upd_plan.extend(plan)
         self.net.join_all(self.bwd_upd_plan)           # the last filter gradients / reductions are on the side streams
         self.net.adam(self.bwd_upd_plan, self.learning_rate, grad_scale=1.0)
+        if self.adversary is not None:
+            self.adversary.emit_update(self.bwd_upd_plan)
         # the whole single-GPU step as ONE plan: no join of the side streams between forward and backward (the only forward
         # side-stream product, the im2col of the input, is consumed on the same side stream)
         self.step_plan = E.Plan('step')

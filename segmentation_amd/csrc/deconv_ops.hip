@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(seg_view a, seg_view dy
 
 template <int MODE>
 __global__ void bn_final_kernel(const float* ws, int nb, int C, int c_log, double inv_n, float eps, float decay, int training,
-                                float* moving, float* stats, float* out2, float* dbeta) {
+                                float* moving, float* stats, float* out2, float* dbeta, int dbeta_add) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
@@ -369,7 +369,7 @@ __global__ void bn_final_kernel(const float* ws, int nb, int C, int c_log, doubl
   } else {
     out2[c] = (float)(s1 * inv_n);
     out2[C + c] = (float)(s2 * inv_n);
-    if (c < c_log) dbeta[c] = (float)s1;
+    if (c < c_log) dbeta[c] = dbeta_add ? dbeta[c] + (float)s1 : (float)s1;
   }
 }
 
@@ -567,7 +567,7 @@ extern "C" int seg_bn_fwd(const seg_view* a, const seg_view* y, const float* bet
     if (int rc = seg_check_launch("bn_partial")) return rc;
   }
   SEG_LAUNCH(bn_final_kernel<0>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, training ? nb : 0, C, c_log, 1.0 / (double)npix, eps, decay,
-             training, moving, stats, (float*)nullptr, (float*)nullptr);
+             training, moving, stats, (float*)nullptr, (float*)nullptr, 0);
   if (int rc = seg_check_launch("bn_final")) return rc;
   const int g = grid_for(npix * (C / 8));
   if (dtype == SEG_F32) SEG_LAUNCH((bn_apply_kernel<float, 0>), dim3(g), dim3(256), 0, st, *a, none, *y, (const float*)stats, beta, B, H, W, C / 8, C, c_log);
@@ -575,8 +575,8 @@ extern "C" int seg_bn_fwd(const seg_view* a, const seg_view* y, const float* bet
   return seg_check_launch("bn_apply");
 }
 
-extern "C" int seg_bn_relu_bwd(const seg_view* a, const seg_view* dy, const seg_view* dz, const float* stats, float* dbeta, int32_t B,
-                               int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype, void* stream) {
+extern "C" int seg_bn_relu_bwd(const seg_view* a, const seg_view* dy, const seg_view* dz, const float* stats, float* dbeta, int32_t dbeta_add,
+                               int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype, void* stream) {
   if (!a || !dy || !dz || !stats || !dbeta || !ws || C <= 0 || C % 8 || C > 2048 || c_log <= 0 || c_log > C || !view_ok(*a, H, W, C) ||
       !view_ok(*dy, H, W, C) || !view_ok(*dz, H, W, C) || (dtype != SEG_F32 && dtype != SEG_BF16)) { seg_set_error("bn_relu_bwd: bad arguments"); return SEG_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
@@ -587,7 +587,7 @@ extern "C" int seg_bn_relu_bwd(const seg_view* a, const seg_view* dy, const seg_
   else SEG_LAUNCH((bn_partial_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, st, *a, *dy, stats, B, H, W, C, ws);
   if (int rc = seg_check_launch("bn_partial_bwd")) return rc;
   SEG_LAUNCH(bn_final_kernel<1>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, nb, C, c_log, 1.0 / (double)npix, 0.f, 0.f, 1,
-             (float*)nullptr, (float*)nullptr, means, dbeta);
+             (float*)nullptr, (float*)nullptr, means, dbeta, dbeta_add);
   if (int rc = seg_check_launch("bn_final_bwd")) return rc;
   const int g = grid_for(npix * (C / 8));
   if (dtype == SEG_F32) SEG_LAUNCH((bn_apply_kernel<float, 1>), dim3(g), dim3(256), 0, st, *a, *dy, *dz, stats, (const float*)means, B, H, W, C / 8, C, c_log);

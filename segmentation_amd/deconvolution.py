@@ -85,6 +85,8 @@ class DeconvModel(BaseModel):
                  autoencoder=False,
                  adversarial_training=False,
                  **mi355x):
+        if adversarial_training:
+            raise Exception('adversarial_training is wired for UNetModel and FCNModel only')
         super(DeconvModel, self).__init__(
             sess=sess, mode=mode, log_dir=log_dir, dataset=dataset, bayesian=bayesian, save_dir=save_dir,
             n_classes=n_classes, input_dims=input_dims, autoencoder=autoencoder, test_dataset=test_dataset,

@@ -782,7 +782,7 @@ class Net(object):
         plan.add(layer.name, fn, C.byref(d), kernel=kern, flops=fl)
         plan.flops += fl
 
-    def dlayer_bwd(self, plan, layer, src, dz, dsrc=None, mask=None):
+    def dlayer_bwd(self, plan, layer, src, dz, dsrc=None, mask=None, wgrad=True):
         """filter / bias gradient of a direct-kernel layer from its masked output gradient dz, then (dsrc given) the input
         gradient, optionally masked by `mask` (the ReLU output that produced src)"""
         k = layer.k
@@ -794,10 +794,11 @@ class Net(object):
             d = self._dconv_desc(layer, dz, src)
             d.bias_n = layer.cout
             mode, fl = 2, 2 * self.B * src.H * src.W * k * k * layer.cin * layer.cout
-        plan.keep.append(d)
-        plan.add(layer.name + '/dw', self.lib.seg_dconv_wgrad, C.byref(d), self.store.g_ptr(layer.w_off), self.store.g_ptr(layer.b_off), mode,
-                 kernel='dconv_wgrad_kernel', flops=fl)
-        plan.flops += fl
+        if wgrad:
+            plan.keep.append(d)
+            plan.add(layer.name + '/dw', self.lib.seg_dconv_wgrad, C.byref(d), self.store.g_ptr(layer.w_off), self.store.g_ptr(layer.b_off), mode,
+                     kernel='dconv_wgrad_kernel', flops=fl)
+            plan.flops += fl
         if dsrc is None:
             return
         if layer.kind == 'direct':
@@ -825,11 +826,14 @@ class Net(object):
         plan.add(layer.name, self.lib.seg_bn_fwd, C.byref(av), C.byref(yv), self.store.p_ptr(layer.w_off), mov, st['stats'].data_ptr(),
                  1 if training else 0, decay, eps, self.B, a.H, a.W, a.Cp, layer.cout, st['ws'].data_ptr(), self.dtype, kernel='bn_apply_kernel')
 
-    def bn_relu_bwd(self, plan, layer, st, a, dy, dz):
+    def bn_relu_bwd(self, plan, layer, st, a, dy, dz, dbeta_ptr=None, dbeta_add=False):
+        """dbeta goes to the layer's slot of the gradient arena (dbeta_add: added to it -- a second batch through the same
+        layer) or to dbeta_ptr (a scratch buffer: data-gradient-only passes)"""
         av, gv, zv = a.view(), dy.view(), dz.view()
         plan.keep += [av, gv, zv, st]
         plan.add(layer.name + '/bwd', self.lib.seg_bn_relu_bwd, C.byref(av), C.byref(gv), C.byref(zv), st['stats'].data_ptr(),
-                 self.store.g_ptr(layer.w_off), self.B, a.H, a.W, a.Cp, layer.cout, st['ws'].data_ptr(), self.dtype, kernel='bn_apply_kernel')
+                 self.store.g_ptr(layer.w_off) if dbeta_ptr is None else dbeta_ptr, 1 if dbeta_add else 0, self.B, a.H, a.W, a.Cp, layer.cout,
+                 st['ws'].data_ptr(), self.dtype, kernel='bn_apply_kernel')
 
     def pool_k_fwd(self, plan, src, dst, k):
         sv, dv = src.view(), dst.view()

@@ -210,7 +210,8 @@ class UNetModel(BaseModel):
         net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1_1
         cols = []       # im2col of the input for conv1_1's filter gradient: side stream, right after conv1_1 (both are
         #                 bandwidth-bound), overlapping the rest of the forward pass
-        fuse_head = (E.rup(Ly['output'].cin) in (32, 64) and self.n_classes <= 32 and os.environ.get('SEG_FUSE_HEAD', '1') != '0')
+        fuse_head = (E.rup(Ly['output'].cin) in (32, 64) and self.n_classes <= 32 and os.environ.get('SEG_FUSE_HEAD', '1') != '0' and
+                     not self.adversarial_training)     # (the adversary adds its term to dlogits before the output layer's backward)
         A, sh, sw, skip_off, o4 = self._emit_forward(net, fwd, self.input_x, H, W, self.crop_aware, head=not fuse_head,
                                                      after_first=lambda: cols.append(net.first_im2col(fwd, Ly['conv1_1'], self.input_x, H, W)))
         col = cols[0]
@@ -229,6 +230,8 @@ class UNetModel(BaseModel):
                           A['logits'], dlog, G['conv9_2'])
         else:
             net.softmax_xent(fwd, A['logits'], self.input_y, H, W, self.label_off, oh, ow, self.n_classes, self.loss_buf, dlog)
+        if self.adversarial_training:
+            self._attach_adversary(fwd, A['logits'], oh, ow, H, W, dlog)
         self.dlogits = dlog
 
         def gz(name):

@@ -342,3 +342,34 @@ def test_c_restatement_unet_train_step_matches_numpy():
     st.train_step(xb, yb)
     _, p1, _, _ = ounet.train_step(p, mm, vv, 1, xb, yb, lr=1e-3)
     assert max(np.abs(st.p[n][k] - p1[n][k]).max() for n in p1 for k in ('weights', 'biases')) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# adversarial training terms: numpy restatement vs the torch-autograd composition, known-answer ladder
+# ---------------------------------------------------------------------------------------------------------------------
+def test_adversary_oracle_vs_torch_autograd():
+    from oracle import adversary as A
+    rng = np.random.default_rng(0)
+    B, h, w, nc = 4, 96, 100, 3
+    p = A.init_params(nc, h, w)
+    for n in p:
+        for k in ('biases', 'beta'):
+            if k in p[n]:
+                p[n][k] = (rng.standard_normal(p[n][k].shape) * 0.1).astype(np.float32)
+    assert A.sizes(324, 324)['pool2'] == (4, 4) and A.sizes(512, 512)['pool2'] == (7, 7)
+    with pytest.raises(ValueError):
+        A.sizes(68, 68)                    # the U-Net's 256^2 output: the adversary's map collapses (like F11 at 128^2)
+    assert A.n_params(A.init_params(4, 324, 324)) == 3 * 3 * 4 * 36 + 36 + 36 + 3 * 3 * 36 * 72 + 72 + 72 + 1152 + 1152 * 1024 + 1024 + 1024 + 1024 * 2 + 2
+    z = rng.standard_normal((B, h, w, nc)) * 2
+    y = rng.integers(0, nc, (B, h, w, 1)).astype(np.uint8)
+    a, t = A.adversarial_terms(p, z, y, nc), torch_ref.adversarial_terms(p, z, y, nc)
+    for k in ('l_bce_real', 'l_bce_fake', 'l_bce_fake_one'):
+        assert abs(a[k] - t[k]) < 1e-12
+    assert np.abs(a['d_seg_logits'] - t['d_seg_logits']).max() < 1e-12 * max(1.0, np.abs(t['d_seg_logits']).max())
+    for n in a['adv_grads']:
+        for k, v in a['adv_grads'][n].items():
+            r = t['adv_grads'][n][k].reshape(v.shape)
+            assert np.abs(v - r).max() < 1e-10 * max(np.abs(r).max(), 1e-3), (n, k)
+    # the moving averages see the real pass, then the fake pass
+    _, _, mv1 = A.forward(p, A.one_hot(y, nc))
+    assert all(np.allclose(a['moving'][n][0], 0.999 * mv1[n][0] + 0.001 * (a['moving'][n][0] - 0.999 * mv1[n][0]) / 0.001) for n in mv1)
