@@ -50,6 +50,7 @@ def parse():
     ap.add_argument('--dense', action='store_true', help='evaluate conv1_2 densely (no crop-aware window)')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph)')
     ap.add_argument('--graph', action='store_true', help='always replay the captured hipGraph (default: time both modes during warm-up, keep the faster)')
+    ap.add_argument('--adversarial', action='store_true', help='train step with adversarial_training=True (SURVEY N4; unet / fcn8s, output map >= 84 pixels)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--per-op', action='store_true', help='also print the per-op table to stderr')
@@ -251,6 +252,8 @@ def main():
         common.update(mode='INFERENCE')
     else:
         common.update(dataset=ds, use_graph=not args.no_graph)
+        if args.adversarial:
+            common.update(adversarial_training=True)
     def barrier():
         if world > 1:
             torch.distributed.barrier()
@@ -305,7 +308,7 @@ def main():
         if not args.no_graph and not args.graph:
             probe = model.autotune_step_mode()          # graph replay vs eager launches: real train steps, part of the warm-up
         flops_step = model.fwd_plan.flops + model.bwd_plan.flops      # (bwd_upd_plan = bwd_plan + Adam)
-        what = 'train step (fwd+xent+bwd+Adam+repack)'
+        what = 'train step (fwd+xent+bwd+Adam+repack)' + (' with adversarial training (adversary fwd on real+fake, its gradients, advAdam)' if args.adversarial else '')
     else:
         x_dev = ds.get_device_batch()[0]
         shape = tuple(x_dev.shape)

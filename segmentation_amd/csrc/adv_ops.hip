@@ -37,29 +37,38 @@ __global__ void onehot_kernel(const uint8_t* labels, int LH, int LW, int ly0, in
 }
 
 // softmax over the class axis of float logits -> activation (pad channels 0).  models/basemodel.py:285 (`y_hat` to the adversary)
-template <typename T>
+// (NCP = classes rounded up to 4 / 8 / 16 / 32 bounds the unrolled loops; the float logits are read as 16-byte vectors)
+template <int NCP>
+SEG_DEV float softmax_row(const float* z, int nc, float (&zv)[NCP]) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int c4 = 0; c4 < NCP / 4; ++c4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(z + c4 * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int c = c4 * 4 + e; zv[c] = c < nc ? v[e] : -INFINITY; m = fmaxf(m, zv[c]); }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCP; ++c) { zv[c] = c < nc ? expf(zv[c] - m) : 0.f; s += zv[c]; }
+  return 1.f / s;
+}
+
+template <typename T, int NCP>
 __global__ void softmax_probs_kernel(seg_view lg, int B, int H, int W, int nc, seg_view dst, int C8) {
   const int64_t total = (int64_t)B * H * W;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t t = i;
     const int x = t % W; t /= W;
     const int y = t % H; const int b = t / H;
-    const float* z = reinterpret_cast<const float*>(lg.ptr) + view_off(lg, b, y, x);
-    float zv[32];
-    float m = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) { zv[c] = c < nc ? z[c < nc ? c : 0] : -INFINITY; m = fmaxf(m, zv[c]); }
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) { zv[c] = c < nc ? expf(zv[c] - m) : 0.f; s += zv[c]; }
-    const float rs = 1.f / s;
+    float zv[NCP];
+    const float rs = softmax_row<NCP>(reinterpret_cast<const float*>(lg.ptr) + view_off(lg, b, y, x), nc, zv);
     T* o = reinterpret_cast<T*>(dst.ptr) + view_off(dst, b, y, x);
 #pragma unroll
     for (int c8 = 0; c8 < 4; ++c8) {
       if (c8 >= C8) break;
       Vec8<T> ov;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) ov.set(e, zv[c8 * 8 + e] * rs);
+      for (int e = 0; e < 8; ++e) ov.set(e, c8 * 8 + e < NCP ? zv[c8 * 8 + e < NCP ? c8 * 8 + e : 0] * rs : 0.f);
       ov.store(o + c8 * 8);
     }
   }
@@ -67,41 +76,35 @@ __global__ void softmax_probs_kernel(seg_view lg, int B, int H, int W, int nc, s
 
 // dlogits += scale * p * (dp - sum_c dp_c p_c): the adversary's input gradient through the softmax, added to the
 // x-entropy gradient already in dlogits.  (p is recomputed from the float logits: the stored copy is rounded.)
-template <typename T>
+template <typename T, int NCP>
 __global__ void softmax_bwd_add_kernel(seg_view lg, seg_view dp, int B, int H, int W, int nc, float scale, seg_view dl, int C8) {
   const int64_t total = (int64_t)B * H * W;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t t = i;
     const int x = t % W; t /= W;
     const int y = t % H; const int b = t / H;
-    const float* z = reinterpret_cast<const float*>(lg.ptr) + view_off(lg, b, y, x);
-    float zv[32];
-    float m = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) { zv[c] = c < nc ? z[c < nc ? c : 0] : -INFINITY; m = fmaxf(m, zv[c]); }
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) { zv[c] = c < nc ? expf(zv[c] - m) : 0.f; s += zv[c]; }
-    const float rs = 1.f / s;
+    float zv[NCP];
+    const float rs = softmax_row<NCP>(reinterpret_cast<const float*>(lg.ptr) + view_off(lg, b, y, x), nc, zv);
     const T* g = reinterpret_cast<const T*>(dp.ptr) + view_off(dp, b, y, x);
-    float gv[32];
+    float gv[NCP];
     float dot = 0.f;
 #pragma unroll
-    for (int c8 = 0; c8 < 4; ++c8) {
-      Vec8<T> v; v.zero();
-      if (c8 < C8) v.load(g + c8 * 8);
+    for (int c8 = 0; c8 < (NCP + 7) / 8; ++c8) {
+      Vec8<T> v; v.load(g + c8 * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { gv[c8 * 8 + e] = v.get(e); zv[c8 * 8 + e] *= rs; dot = fmaf(gv[c8 * 8 + e], zv[c8 * 8 + e], dot); }
+      for (int e = 0; e < 8; ++e) {
+        const int c = c8 * 8 + e;
+        if (c < NCP) { gv[c] = v.get(e); zv[c] *= rs; dot = fmaf(gv[c], zv[c], dot); }
+      }
     }
     T* o = reinterpret_cast<T*>(dl.ptr) + view_off(dl, b, y, x);
 #pragma unroll
-    for (int c8 = 0; c8 < 4; ++c8) {
-      if (c8 >= C8) break;
+    for (int c8 = 0; c8 < (NCP + 7) / 8; ++c8) {
       Vec8<T> ov; ov.load(o + c8 * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int c = c8 * 8 + e;
-        if (c < nc) ov.set(e, ov.get(e) + scale * zv[c] * (gv[c] - dot));
+        if (c < NCP && c < nc) ov.set(e, ov.get(e) + scale * zv[c < NCP ? c : 0] * (gv[c < NCP ? c : 0] - dot));
       }
       ov.store(o + c8 * 8);
     }
@@ -228,8 +231,11 @@ extern "C" int seg_softmax_probs(const seg_view* logits, int32_t B, int32_t H, i
   }
   const int g = grid_for((int64_t)B * H * W);
   hipStream_t st = (hipStream_t)stream;
-  ADV_DISPATCH(dtype, SEG_LAUNCH(softmax_probs_kernel<float>, dim3(g), dim3(256), 0, st, *logits, B, H, W, n_classes, *dst, dst->c / 8),
-               SEG_LAUNCH(softmax_probs_kernel<bf16_t>, dim3(g), dim3(256), 0, st, *logits, B, H, W, n_classes, *dst, dst->c / 8), "softmax_probs");
+#define SMX(TT, NCP) SEG_LAUNCH((softmax_probs_kernel<TT, NCP>), dim3(g), dim3(256), 0, st, *logits, B, H, W, n_classes, *dst, dst->c / 8)
+#define SMX_N(TT) do { if (n_classes <= 4) SMX(TT, 4); else if (n_classes <= 8) SMX(TT, 8); else if (n_classes <= 16) SMX(TT, 16); else SMX(TT, 32); } while (0)
+  ADV_DISPATCH(dtype, SMX_N(float), SMX_N(bf16_t), "softmax_probs");
+#undef SMX_N
+#undef SMX
   return seg_check_launch("softmax_probs");
 }
 
@@ -241,8 +247,11 @@ extern "C" int seg_softmax_bwd_add(const seg_view* logits, const seg_view* dprob
   }
   const int g = grid_for((int64_t)B * H * W);
   hipStream_t st = (hipStream_t)stream;
-  ADV_DISPATCH(dtype, SEG_LAUNCH(softmax_bwd_add_kernel<float>, dim3(g), dim3(256), 0, st, *logits, *dprobs, B, H, W, n_classes, scale, *dlogits, dlogits->c / 8),
-               SEG_LAUNCH(softmax_bwd_add_kernel<bf16_t>, dim3(g), dim3(256), 0, st, *logits, *dprobs, B, H, W, n_classes, scale, *dlogits, dlogits->c / 8), "softmax_bwd_add");
+#define SMB(TT, NCP) SEG_LAUNCH((softmax_bwd_add_kernel<TT, NCP>), dim3(g), dim3(256), 0, st, *logits, *dprobs, B, H, W, n_classes, scale, *dlogits, dlogits->c / 8)
+#define SMB_N(TT) do { if (n_classes <= 4) SMB(TT, 4); else if (n_classes <= 8) SMB(TT, 8); else if (n_classes <= 16) SMB(TT, 16); else SMB(TT, 32); } while (0)
+  ADV_DISPATCH(dtype, SMB_N(float), SMB_N(bf16_t), "softmax_bwd_add");
+#undef SMB_N
+#undef SMB
   return seg_check_launch("softmax_bwd_add");
 }
 

@@ -476,6 +476,131 @@ __global__ void resize_bwd_kernel(seg_view dd, int Hd, int Wd, seg_view ds, int 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Dense layers (slim.fully_connected = a 1x1 "convolution" over 1x1 maps; the adversary's adv_fc1 is [B, 3528] x [3528, 1024],
+// models/basemodel.py:255,260): weight-bandwidth-bound (14 MB of fp32 weights against 58 MFLOP), so the three forms below
+// stream the weight matrix w[k][n] exactly once per 16 rows of the batch with coalesced reads along n and keep a fixed
+// summation order.  The generic direct kernel took 1.9 ms for the forward alone (one thread walking all of k).
+// ------------------------------------------------------------------------------------------
+constexpr int FC_RB = 16;          // batch rows held in registers per pass
+
+// y[b][n] = act(sum_k x[b][k] w[k][n] + bias[n]).  Block = 64 n-columns (a wave reads 256 contiguous bytes of a weight row)
+// x 16 k-lanes.  The 16 batch rows of a 256-deep k chunk are staged in LDS as float [k][16 rows], so that a k step costs one
+// weight load and four broadcast ds_read_b128 instead of sixteen uniform global loads (the first form of this kernel spent
+// its time issuing those).  The k-lanes are reduced through LDS in lane order.
+constexpr int FC_KC = 256;
+template <typename T>
+__global__ __launch_bounds__(1024) void fc_fwd_kernel(const seg_dconv_desc d) {
+  extern __shared__ float fc_lds[];
+  float* xs_ = fc_lds;                                  // [FC_KC][FC_RB]
+  float* red = fc_lds + FC_KC * FC_RB;                  // [16 k-lanes][64 n][FC_RB + 1]
+  const int tid = threadIdx.x, nl = tid & 63, kl = tid >> 6;
+  const int n = blockIdx.x * 64 + nl;
+  const T* xp = reinterpret_cast<const T*>(d.x.ptr) + view_off(d.x, 0, 0, 0);
+  T* yp = reinterpret_cast<T*>(d.y.ptr) + view_off(d.y, 0, 0, 0);
+  const int64_t xs = (int64_t)d.x.H * d.x.W * d.x.cs, ys = (int64_t)d.y.H * d.y.W * d.y.cs;
+  for (int b0 = 0; b0 < d.B; b0 += FC_RB) {
+    float acc[FC_RB];
+#pragma unroll
+    for (int r = 0; r < FC_RB; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < d.xc; k0 += FC_KC) {
+      __syncthreads();
+      for (int i = tid; i < FC_KC * FC_RB; i += 1024) {     // coalesced along k within a row
+        const int r = i / FC_KC, kk = i % FC_KC;
+        xs_[kk * FC_RB + r] = (b0 + r < d.B && k0 + kk < d.xc) ? to_f32(xp[(b0 + r) * xs + k0 + kk]) : 0.f;
+      }
+      __syncthreads();
+      if (n < d.yc) {
+        const int kend = min(FC_KC, d.xc - k0);
+#pragma unroll 4
+        for (int kk = kl; kk < kend; kk += 16) {
+          const float wv = d.w[(int64_t)(k0 + kk) * d.w_sk + n];
+          const f32x4* xr = reinterpret_cast<const f32x4*>(xs_ + kk * FC_RB);
+#pragma unroll
+          for (int q = 0; q < FC_RB / 4; ++q) {
+            const f32x4 v = xr[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[q * 4 + e] = fmaf(v[e], wv, acc[q * 4 + e]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < FC_RB; ++r) red[(kl * 64 + nl) * (FC_RB + 1) + r] = acc[r];
+    __syncthreads();
+    {                                                   // thread (nl, r = kl): one output element, k-lanes added in order
+      const int r = kl;
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) s += red[(q * 64 + nl) * (FC_RB + 1) + r];
+      if (b0 + r < d.B && n < d.y.c) {
+        if (n < d.yc) { if (d.bias != nullptr && n < d.bias_n) s += d.bias[n]; if (d.relu) s = fmaxf(s, 0.f); } else s = 0.f;
+        yp[(b0 + r) * ys + n] = from_f32<T>(s);
+      }
+    }
+  }
+}
+
+// dx[b][k] = sum_n dz[b][n] w[k][n]: one wave per k-row, lanes along n, wave reduction per batch row
+template <typename T>
+__global__ __launch_bounds__(256) void fc_bwd_data_kernel(const seg_dconv_desc d) {
+  const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= d.x.c) return;
+  const T* zp = reinterpret_cast<const T*>(d.y.ptr) + view_off(d.y, 0, 0, 0);
+  T* xp = reinterpret_cast<T*>(d.x.ptr) + view_off(d.x, 0, 0, 0);
+  const int64_t xs = (int64_t)d.x.H * d.x.W * d.x.cs, zs = (int64_t)d.y.H * d.y.W * d.y.cs;
+  for (int b0 = 0; b0 < d.B; b0 += FC_RB) {
+    float acc[FC_RB];
+#pragma unroll
+    for (int r = 0; r < FC_RB; ++r) acc[r] = 0.f;
+    if (k < d.xc) {
+      for (int n = lane; n < d.yc; n += 64) {
+        const float wv = d.w[(int64_t)k * d.w_sk + n];
+#pragma unroll
+        for (int r = 0; r < FC_RB; ++r)
+          if (b0 + r < d.B) acc[r] = fmaf(to_f32(zp[(b0 + r) * zs + n]), wv, acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < FC_RB; ++r) {
+      const float s = wave_sum64(acc[r]);
+      if (lane == 0 && b0 + r < d.B) xp[(b0 + r) * xs + k] = from_f32<T>(s);
+    }
+  }
+}
+
+// dw[k][n] = sum_b x[b][k] dz[b][n] (batch rows added in order), db[n] = sum_b dz[b][n]; thread = one n, block = 8 k-rows
+template <typename T>
+__global__ __launch_bounds__(256) void fc_wgrad_kernel(const seg_dconv_desc d, float* dw, float* db) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int k0 = blockIdx.y * 8;
+  if (n >= d.yc) return;
+  const T* xp = reinterpret_cast<const T*>(d.x.ptr) + view_off(d.x, 0, 0, 0);
+  const T* zp = reinterpret_cast<const T*>(d.y.ptr) + view_off(d.y, 0, 0, 0);
+  const int64_t xs = (int64_t)d.x.H * d.x.W * d.x.cs, zs = (int64_t)d.y.H * d.y.W * d.y.cs;
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  float sb = 0.f;
+  for (int b = 0; b < d.B; ++b) {
+    const float zv = to_f32(zp[b * zs + n]);
+    sb += zv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (k0 + j < d.xc) s[j] = fmaf(to_f32(xp[b * xs + k0 + j]), zv, s[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (k0 + j < d.xc) dw[(int64_t)(k0 + j) * d.w_sk + n] = s[j];
+  if (db != nullptr && blockIdx.y == 0 && n < d.bias_n) db[n] = sb;
+}
+
+inline bool is_dense(const seg_dconv_desc& d) {
+  return d.KH == 1 && d.KW == 1 && d.stride == 1 && d.Hx == 1 && d.Wx == 1 && d.Hy == 1 && d.Wy == 1 && d.pad_t == 0 && d.pad_l == 0 &&
+         d.mask.ptr == nullptr && d.w_sk >= d.yc;
+}
+
 int check_dconv(const seg_dconv_desc* dp, const char* what) {
   if (!dp) { seg_set_error("%s: null descriptor", what); return SEG_ERR_ARG; }
   const seg_dconv_desc& d = *dp;
@@ -494,6 +619,21 @@ extern "C" int seg_dconv_fwd(const seg_dconv_desc* dp, void* stream) {
   if (int rc = check_dconv(dp, "dconv_fwd")) return rc;
   const seg_dconv_desc& d = *dp;
   if (d.mask.ptr && !view_ok(d.mask, d.Hy, d.Wy, d.y.c)) { seg_set_error("dconv_fwd: bad mask view"); return SEG_ERR_ARG; }
+  if (is_dense(d)) {
+    const dim3 g((d.y.c + 63) / 64);
+    constexpr int lds = (FC_KC * FC_RB + 16 * 64 * (FC_RB + 1)) * 4;      // 84 KB
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(fc_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(fc_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        seg_set_error("fc_fwd: cannot raise dynamic LDS to %d", lds); return SEG_ERR_LAUNCH;
+      }
+      attr_done = true;
+    }
+    if (d.dtype == SEG_F32) SEG_LAUNCH(fc_fwd_kernel<float>, g, dim3(1024), lds, (hipStream_t)stream, d);
+    else SEG_LAUNCH(fc_fwd_kernel<bf16_t>, g, dim3(1024), lds, (hipStream_t)stream, d);
+    return seg_check_launch("fc_fwd");
+  }
   const int g = grid_for((int64_t)d.B * d.Hy * d.Wy * (d.y.c / 8));
   if (d.dtype == SEG_F32) SEG_LAUNCH(dconv_fwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, d);
   else SEG_LAUNCH(dconv_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, d);
@@ -504,6 +644,12 @@ extern "C" int seg_dconv_bwd_data(const seg_dconv_desc* dp, void* stream) {
   if (int rc = check_dconv(dp, "dconv_bwd_data")) return rc;
   const seg_dconv_desc& d = *dp;
   if (d.mask.ptr && !view_ok(d.mask, d.Hx, d.Wx, d.x.c)) { seg_set_error("dconv_bwd_data: bad mask view"); return SEG_ERR_ARG; }
+  if (is_dense(d) && d.bias == nullptr && !d.relu) {
+    const dim3 g((d.x.c + 3) / 4);
+    if (d.dtype == SEG_F32) SEG_LAUNCH(fc_bwd_data_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, d);
+    else SEG_LAUNCH(fc_bwd_data_kernel<bf16_t>, g, dim3(256), 0, (hipStream_t)stream, d);
+    return seg_check_launch("fc_bwd_data");
+  }
   const int g = grid_for((int64_t)d.B * d.Hx * d.Wx * (d.x.c / 8));
   if (d.dtype == SEG_F32) SEG_LAUNCH(dconv_bwd_data_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, d);
   else SEG_LAUNCH(dconv_bwd_data_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, d);
@@ -515,6 +661,12 @@ extern "C" int seg_dconv_wgrad(const seg_dconv_desc* dp, float* dw, float* db, i
   const seg_dconv_desc& d = *dp;
   if (!dw || db_mode < 0 || db_mode > 2 || (db_mode && (!db || d.bias_n <= 0))) { seg_set_error("dconv_wgrad: bad output / bias request"); return SEG_ERR_ARG; }
   if ((db_mode == 1 && d.bias_n > d.yc) || (db_mode == 2 && d.bias_n > d.xc)) { seg_set_error("dconv_wgrad: bias_n exceeds channels"); return SEG_ERR_ARG; }
+  if (is_dense(d) && db_mode != 2) {
+    const dim3 g((d.yc + 255) / 256, (d.xc + 7) / 8);
+    if (d.dtype == SEG_F32) SEG_LAUNCH(fc_wgrad_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, d, dw, db_mode ? db : (float*)nullptr);
+    else SEG_LAUNCH(fc_wgrad_kernel<bf16_t>, g, dim3(256), 0, (hipStream_t)stream, d, dw, db_mode ? db : (float*)nullptr);
+    return seg_check_launch("fc_wgrad");
+  }
   const dim3 grid(d.KH * d.KW, (d.xc + 7) / 8, (d.yc + 7) / 8);
   if (d.dtype == SEG_F32) SEG_LAUNCH(dconv_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, d, dw, db, db_mode);
   else SEG_LAUNCH(dconv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, d, dw, db, db_mode);
