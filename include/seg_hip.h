@@ -273,7 +273,10 @@ typedef struct seg_dconv_desc {
 } seg_dconv_desc;
 int seg_dconv_fwd(const seg_dconv_desc* d, void* stream);
 int seg_dconv_bwd_data(const seg_dconv_desc* d, void* stream);
-int seg_dconv_wgrad(const seg_dconv_desc* d, float* dw, float* db, int32_t db_mode, void* stream);
+/* _wgrad: `ws` = seg_dconv_wgrad_ws_bytes(d) bytes of scratch (may be 0 / NULL): with it, layers with few (tap, k, n) tiles split
+ * their pixels over several workgroups per tile and add the partial slabs in a fixed order; without it the unsplit form runs. */
+int64_t seg_dconv_wgrad_ws_bytes(const seg_dconv_desc* d);
+int seg_dconv_wgrad(const seg_dconv_desc* d, float* dw, float* db, int32_t db_mode, float* ws, int64_t ws_bytes, void* stream);
 
 /* slim.max_pool2d(x, k, k) (kernel k, stride k, VALID; models/deconvolution.py:118,131,140: k = 2, 3, 3) on a tensor that is
  * NOT a ReLU output (it follows a batch norm): no mask fusion.  bwd routes to the first maximum in row-major window order. */

@@ -87,7 +87,7 @@ SIGNATURES = {
     'seg_cast_pad': [vp, i64, i32, PV, i32, vp],
     'seg_dconv_fwd': [C.POINTER(DconvDesc), vp],
     'seg_dconv_bwd_data': [C.POINTER(DconvDesc), vp],
-    'seg_dconv_wgrad': [C.POINTER(DconvDesc), vp, vp, i32, vp],
+    'seg_dconv_wgrad': [C.POINTER(DconvDesc), vp, vp, i32, vp, C.c_int64, vp],
     'seg_maxpool_k_fwd': [PV, PV, i32, i32, i32, i32, i32, i32, vp],
     'seg_maxpool_k_bwd': [PV, PV, PV, i32, i32, i32, i32, i32, i32, vp],
     'seg_bn_fwd': [PV, PV, vp, vp, vp, i32, f32, f32, i32, i32, i32, i32, i32, vp, i32, vp],
@@ -132,6 +132,8 @@ def load():
     lib.seg_version.argtypes = []
     lib.seg_bn_ws_bytes.restype = C.c_int64
     lib.seg_bn_ws_bytes.argtypes = [C.c_int32]
+    lib.seg_dconv_wgrad_ws_bytes.restype = C.c_int64
+    lib.seg_dconv_wgrad_ws_bytes.argtypes = [C.POINTER(DconvDesc)]
     _lib = lib
     return lib
 

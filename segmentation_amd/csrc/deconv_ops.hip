@@ -157,9 +157,11 @@ SEG_DEV float wave_sum64(float v) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void dconv_wgrad_kernel(const seg_dconv_desc d, float* dw, float* db, int db_mode) {
+__global__ __launch_bounds__(256) void dconv_wgrad_kernel(const seg_dconv_desc d, float* dw, float* db, int db_mode, int nps, float* ws) {
   __shared__ float red[4][72];
-  const int tap = blockIdx.x, u = tap / d.KW, v = tap % d.KW;
+  // nps > 1: the pixels are dealt round-robin (in runs of 256) to nps workgroups per (tap, k, n) tile; each writes its partial
+  // sums to ws[ps][tap][k][n] (+ bias partials) and dconv_wgrad_reduce_kernel adds the nps slabs in order
+  const int tap = blockIdx.x / nps, ps = blockIdx.x % nps, u = tap / d.KW, v = tap % d.KW;
   const int k8 = blockIdx.y, n8 = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float acc[8][8];
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const seg_dconv_desc d
   for (int e = 0; e < 8; ++e) accb[e] = 0.f;
   const bool bias1 = db_mode == 1 && tap == 0 && k8 == 0, bias2 = db_mode == 2 && tap == 0 && n8 == 0;
   const int64_t npix = (int64_t)d.B * d.Hy * d.Wy;
-  for (int64_t p = tid; p < npix; p += 256) {
+  for (int64_t p = (int64_t)ps * 256 + tid; p < npix; p += (int64_t)256 * nps) {
     int64_t t = p;
     const int ox = t % d.Wy; t /= d.Wy;
     const int oy = t % d.Hy; const int b = t / d.Hy;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const seg_dconv_desc d
   }
   if (bias2) {                                       // sum of x over its FULL extent (bias of a transposed convolution)
     const int64_t nx = (int64_t)d.B * d.Hx * d.Wx;
-    for (int64_t p = tid; p < nx; p += 256) {
+    for (int64_t p = (int64_t)ps * 256 + tid; p < nx; p += (int64_t)256 * nps) {
       int64_t t = p;
       const int ix = t % d.Wx; t /= d.Wx;
       const int iy = t % d.Hx; const int b = t / d.Hx;
@@ -217,7 +219,12 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const seg_dconv_desc d
   __syncthreads();
   if (tid < 72) {
     const float s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-    if (tid < 64) {
+    if (nps > 1) {
+      const int Kp = gridDim.y * 8, Np = gridDim.z * 8, NT = d.KH * d.KW;
+      if (tid < 64) ws[(((int64_t)ps * NT + tap) * Kp + k8 * 8 + tid / 8) * Np + n8 * 8 + tid % 8] = s;
+      else if (bias1) ws[(int64_t)nps * NT * Kp * Np + (int64_t)ps * (Kp > Np ? Kp : Np) + n8 * 8 + tid - 64] = s;
+      else if (bias2) ws[(int64_t)nps * NT * Kp * Np + (int64_t)ps * (Kp > Np ? Kp : Np) + k8 * 8 + tid - 64] = s;
+    } else if (tid < 64) {
       const int k = k8 * 8 + tid / 8, n = n8 * 8 + tid % 8;
       if (k < d.xc && n < d.yc) dw[u * d.w_su + v * d.w_sv + (int64_t)k * d.w_sk + n] = s;
     } else {
@@ -226,6 +233,36 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const seg_dconv_desc d
       if (bias2 && k8 * 8 + e < d.bias_n) db[k8 * 8 + e] = s;
     }
   }
+}
+
+__global__ void dconv_wgrad_reduce_kernel(const seg_dconv_desc d, float* dw, float* db, int db_mode, int nps, int Kp, int Np, const float* ws) {
+  const int NT = d.KH * d.KW;
+  const int64_t total = (int64_t)NT * Kp * Np, slab = total, i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < total) {
+    const int n = (int)(i % Np), k = (int)((i / Np) % Kp), tap = (int)(i / ((int64_t)Np * Kp));
+    if (k < d.xc && n < d.yc) {
+      float s = 0.f;
+      for (int q = 0; q < nps; ++q) s += ws[q * slab + i];
+      dw[(tap / d.KW) * d.w_su + (tap % d.KW) * d.w_sv + (int64_t)k * d.w_sk + n] = s;
+    }
+  }
+  const int M = Kp > Np ? Kp : Np;
+  if (db_mode && i < d.bias_n) {
+    float s = 0.f;
+    for (int q = 0; q < nps; ++q) s += ws[nps * slab + (int64_t)q * M + i];
+    db[i] = s;
+  }
+}
+
+// pixel splits of the filter gradient: enough workgroups to fill the chip when the (tap, k, n) tiles alone are few
+inline int dconv_wgrad_nps(const seg_dconv_desc& d) {
+  const int64_t tiles = (int64_t)d.KH * d.KW * ((d.xc + 7) / 8) * ((d.yc + 7) / 8);
+  const int64_t npix = (int64_t)d.B * d.Hy * d.Wy;
+  int64_t nps = (2048 + tiles - 1) / tiles;              // ~8 workgroups per CU
+  const int64_t cap = npix / 1024;                        // >= 4 pixels per thread
+  if (nps > cap) nps = cap;
+  if (nps > 256) nps = 256;
+  return nps < 1 ? 1 : (int)nps;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -656,7 +693,16 @@ extern "C" int seg_dconv_bwd_data(const seg_dconv_desc* dp, void* stream) {
   return seg_check_launch("dconv_bwd_data");
 }
 
-extern "C" int seg_dconv_wgrad(const seg_dconv_desc* dp, float* dw, float* db, int32_t db_mode, void* stream) {
+extern "C" int64_t seg_dconv_wgrad_ws_bytes(const seg_dconv_desc* dp) {
+  if (!dp || is_dense(*dp)) return 0;
+  const seg_dconv_desc& d = *dp;
+  const int nps = dconv_wgrad_nps(d);
+  if (nps <= 1) return 0;
+  const int64_t Kp = (d.xc + 7) / 8 * 8, Np = (d.yc + 7) / 8 * 8;
+  return (int64_t)nps * ((int64_t)d.KH * d.KW * Kp * Np + (Kp > Np ? Kp : Np)) * 4;
+}
+
+extern "C" int seg_dconv_wgrad(const seg_dconv_desc* dp, float* dw, float* db, int32_t db_mode, float* ws, int64_t ws_bytes, void* stream) {
   if (int rc = check_dconv(dp, "dconv_wgrad")) return rc;
   const seg_dconv_desc& d = *dp;
   if (!dw || db_mode < 0 || db_mode > 2 || (db_mode && (!db || d.bias_n <= 0))) { seg_set_error("dconv_wgrad: bad output / bias request"); return SEG_ERR_ARG; }
@@ -667,10 +713,21 @@ extern "C" int seg_dconv_wgrad(const seg_dconv_desc* dp, float* dw, float* db, i
     else SEG_LAUNCH(fc_wgrad_kernel<bf16_t>, g, dim3(256), 0, (hipStream_t)stream, d, dw, db_mode ? db : (float*)nullptr);
     return seg_check_launch("fc_wgrad");
   }
-  const dim3 grid(d.KH * d.KW, (d.xc + 7) / 8, (d.yc + 7) / 8);
-  if (d.dtype == SEG_F32) SEG_LAUNCH(dconv_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, d, dw, db, db_mode);
-  else SEG_LAUNCH(dconv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, d, dw, db, db_mode);
-  return seg_check_launch("dconv_wgrad");
+  // (a caller without workspace gets the unsplit form: same result up to summation order)
+  int nps = dconv_wgrad_nps(d);
+  if (nps > 1 && (!ws || ws_bytes < seg_dconv_wgrad_ws_bytes(dp))) nps = 1;
+  const int K8 = (d.xc + 7) / 8, N8 = (d.yc + 7) / 8;
+  const dim3 grid(d.KH * d.KW * nps, K8, N8);
+  if (d.dtype == SEG_F32) SEG_LAUNCH(dconv_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, d, dw, db, db_mode, nps, ws);
+  else SEG_LAUNCH(dconv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, d, dw, db, db_mode, nps, ws);
+  if (int rc = seg_check_launch("dconv_wgrad")) return rc;
+  if (nps > 1) {
+    const int64_t total = (int64_t)d.KH * d.KW * K8 * 8 * N8 * 8;
+    const int64_t n = total > d.bias_n ? total : d.bias_n;
+    SEG_LAUNCH(dconv_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d, dw, db, db_mode, nps, K8 * 8, N8 * 8, (const float*)ws);
+    return seg_check_launch("dconv_wgrad_reduce");
+  }
+  return SEG_OK;
 }
 
 extern "C" int seg_maxpool_k_fwd(const seg_view* src, const seg_view* dst, int32_t k, int32_t B, int32_t Ho, int32_t Wo, int32_t C,

@@ -796,8 +796,11 @@ class Net(object):
             mode, fl = 2, 2 * self.B * src.H * src.W * k * k * layer.cin * layer.cout
         if wgrad:
             plan.keep.append(d)
+            nb = int(self.lib.seg_dconv_wgrad_ws_bytes(C.byref(d)))       # pixel-split partial slabs (0: the layer has tiles enough)
+            ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=self.device)
+            plan.keep.append(ws)
             plan.add(layer.name + '/dw', self.lib.seg_dconv_wgrad, C.byref(d), self.store.g_ptr(layer.w_off), self.store.g_ptr(layer.b_off), mode,
-                     kernel='dconv_wgrad_kernel', flops=fl)
+                     ws.data_ptr() if nb else None, nb, kernel='dconv_wgrad_kernel', flops=fl)
             plan.flops += fl
         if dsrc is None:
             return

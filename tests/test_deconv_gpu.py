@@ -33,7 +33,10 @@ def _store(layers, dtype, rng):
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('case', [('direct', 5, 2, 'SAME', 3, 16, 21, 24, 2), ('direct', 5, 2, 'SAME', 3, 40, 16, 16, 1),
                                   ('direct', 3, 1, 'VALID', 12, 8, 9, 11, 2), ('dtrans', 5, 2, 'VALID', 24, 8, 5, 7, 2),
-                                  ('dtrans', 5, 2, 'VALID', 64, 32, 3, 3, 1), ('dtrans', 2, 2, 'VALID', 8, 3, 6, 5, 2)])
+                                  ('dtrans', 5, 2, 'VALID', 64, 32, 3, 3, 1), ('dtrans', 2, 2, 'VALID', 8, 3, 6, 5, 2),
+                                  # (enough pixels for the filter gradient to split them over several workgroups per tile)
+                                  ('direct', 5, 2, 'SAME', 3, 32, 96, 100, 2), ('dtrans', 5, 2, 'VALID', 8, 8, 40, 44, 2),
+                                  ('direct', 1, 1, 'VALID', 200, 72, 1, 1, 19)])       # dense fast path (1x1 over 1x1 maps)
 def test_direct_conv_kernels(dtype, case):
     kind, k, s, padding, cin, cout, H, W, B = case
     rng = np.random.default_rng(k * 100 + cin + cout + H)
