@@ -224,3 +224,15 @@ def test_example_unet_script_runs(tmp_path, folder):
     assert 'Done' in r.stdout and 'TEST LOSS' in r.stdout and 'infer: (2, 4, 4, 2) (2, 4, 4, 1)' in r.stdout
     snaps = os.listdir(tmp_path / 'examples' / 'unet' / 'snapshots')
     assert any(f.endswith('-4.npz') for f in snaps), snaps
+
+
+def test_example_adversarial_script_runs(tmp_path):
+    """the authored examples/example_adversarial.py (the reference's is an empty file, F1): FCN-8s with adversarial_training=True"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'examples', 'example_adversarial.py'), '--outer', '1', '--inner', '4', '--test-iter', '2']
+    r = subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'Done' in r.stdout and 'l_bce_fake_one' in r.stdout and 'infer: (4, 128, 128, 2) (4, 128, 128, 1)' in r.stdout
+    assert any(f.endswith('-4.npz') for f in os.listdir(tmp_path / 'examples' / 'fcn_adversarial' / 'snapshots'))
