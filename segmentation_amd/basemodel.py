@@ -395,14 +395,16 @@ class BaseModel(object):
         """Mean x-entropy of the most recent train_step (synchronises)."""
         return float(self.loss_buf.item())
 
-    def _attach_adversary(self, plan, logits, oh, ow, LH, LW, dlogits):
-        """adversarial_training: appends the adversary (forward on one_hot(labels) and softmax(logits), its own gradients, and the
-        adversarial term of the segmentation gradient added into `dlogits`) to the training forward plan, right behind the
-        x-entropy launch."""
+    def _attach_adversary(self, logits, oh, ow, LH, LW, dlogits):
+        """adversarial_training: builds the adversary and its plan (forward on one_hot(labels) and softmax(logits), its own
+        gradients, and the adversarial term of the segmentation gradient added into `dlogits`).  The plan runs between the
+        x-entropy launch (end of the forward plan) and the output layer's backward: _finish_training_plans puts it at the head
+        of the first backward segment, so the forward plan alone -- test() -- leaves the adversary untouched."""
         from .adversary import Adversary
         self.adversary = Adversary(self.batch_size, oh, ow, self.n_classes, self.dtype, self.device, self.store.step.data_ptr() + 8,
                                    lr=self.adversarial_lr, lam=self.adv_lambda, seed=self.seed + 2222)
-        self.adversary.emit(plan, logits, self.input_y, LH, LW, self.label_off, dlogits)
+        self.adv_plan = E.Plan('adversary')
+        self.adversary.emit(self.adv_plan, logits, self.input_y, LH, LW, self.label_off, dlogits)
 
     def last_losses(self):
         """The scalars the reference writes as summaries (models/basemodel.py:299-301,347-351), of the most recent train_step."""
@@ -514,6 +516,11 @@ class BaseModel(object):
     def _finish_training_plans(self, segs):
         """segs: [(plan, arena_end_offset)] in backward order -> bwd_segments / bwd_plan / upd_plan."""
         assert not self.net._pending_reduce, 'a backward segment was closed without flush_reduce()'
+        if self.adversary is not None:
+            head = E.Plan(segs[0][0].name)
+            head.extend(self.adv_plan)
+            head.extend(segs[0][0])
+            segs = [(head, segs[0][1])] + list(segs[1:])
         self.bwd_segments, lo = [], 0
         for plan, hi in segs:
             self.bwd_segments.append((plan, (lo, hi)))

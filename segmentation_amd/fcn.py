@@ -174,7 +174,7 @@ class FCNModel(BaseModel):
         dlog = net.act(H, W, nc, name='dlogits')
         net.softmax_xent(fwd, A['logits'], self.input_y, H, W, (0, 0), H, W, nc, self.loss_buf, dlog)
         if self.adversarial_training:
-            self._attach_adversary(fwd, A['logits'], H, W, H, W, dlog)
+            self._attach_adversary(A['logits'], H, W, H, W, dlog)
         self.dlogits = dlog
         seg = E.Plan('bwd0')
         segs = []

@@ -231,7 +231,7 @@ class UNetModel(BaseModel):
         else:
             net.softmax_xent(fwd, A['logits'], self.input_y, H, W, self.label_off, oh, ow, self.n_classes, self.loss_buf, dlog)
         if self.adversarial_training:
-            self._attach_adversary(fwd, A['logits'], oh, ow, H, W, dlog)
+            self._attach_adversary(A['logits'], oh, ow, H, W, dlog)
         self.dlogits = dlog
 
         def gz(name):

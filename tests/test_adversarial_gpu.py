@@ -294,6 +294,11 @@ def test_adversarial_training_runs_and_snapshots(tmp_path, use_graph):
     assert float((m.store.p - p0).abs().max()) > 0 and float((m.adversary.store.p - a0).abs().max()) > 0
     assert hist[-1]['adv_loss'] < hist[0]['adv_loss']
     assert m.global_step == 12
+    mv_before, l_before, g_before = m.adversary.get_moving(), m.adversary.losses.clone(), m.adversary.store.g.clone()
+    m.test()                               # a forward on a held-out batch must not touch the adversary (moving averages, losses, gradients)
+    mv_after = m.adversary.get_moving()
+    assert all(np.array_equal(mv_before[n][0], mv_after[n][0]) and np.array_equal(mv_before[n][1], mv_after[n][1]) for n in mv_before)
+    assert torch.equal(l_before, m.adversary.losses) and torch.equal(g_before, m.adversary.store.g) and m.global_step == 12
     m.snapshot()
     m2 = make(save_dir=None)
     m2.restore(m._latest_checkpoint())
