@@ -70,6 +70,11 @@ typedef struct seg_conv_desc {
                             * channels) -- slim.max_pool2d fused into the producing conv; SEG_ERR_UNSUPPORTED when the layer's
                             * tile cannot carry it (ask seg_conv2d_kernel_name first, or fall back to seg_maxpool2x2_fwd) */
   int32_t pool_h, pool_w;
+  uint32_t* signal;        /* nullable: the launch stores signal_value to *signal (system-scope relaxed store by its first workgroup)
+                            * when it STARTS.  On an in-order stream that means every earlier launch of the stream is complete and
+                            * released, so another stream can wait for it with hipStreamWaitValue32(signal >= value) -- a fork that
+                            * puts no packet on the producing stream (an event record costs it 4-7 us; tools/micro/sigwait.hip) */
+  uint32_t signal_value;
 } seg_conv_desc;
 
 /* slim.convolution2d / conv2d_transpose fwd, Conv2DBackpropInput: models/unet.py:111-166,

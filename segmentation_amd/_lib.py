@@ -28,7 +28,8 @@ class ConvDesc(C.Structure):
                 ('n_off', C.c_int32), ('n_count', C.c_int32), ('bias', C.c_void_p), ('bias_n', C.c_int32),
                 ('dst', View), ('up2', C.c_int32), ('up_cout', C.c_int32), ('mask', View), ('relu', C.c_int32),
                 ('out_f32', C.c_int32), ('dtype', C.c_int32), ('cfg', C.c_int32), ('accum', C.c_int32),
-                ('n_split', C.c_int32), ('dst1', View), ('mask1', View), ('pool', View), ('pool_h', C.c_int32), ('pool_w', C.c_int32)]
+                ('n_split', C.c_int32), ('dst1', View), ('mask1', View), ('pool', View), ('pool_h', C.c_int32), ('pool_w', C.c_int32),
+                ('signal', C.c_void_p), ('signal_value', C.c_uint32)]
 
 
 class WgradDesc(C.Structure):
@@ -162,6 +163,7 @@ def hip_runtime():
         h.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]; h.hipEventCreateWithFlags.restype = C.c_int
         h.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]; h.hipEventRecord.restype = C.c_int
         h.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]; h.hipStreamWaitEvent.restype = C.c_int
+        h.hipStreamWaitValue32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint, C.c_uint32]; h.hipStreamWaitValue32.restype = C.c_int
         _hip = h
     return _hip
 

@@ -218,6 +218,12 @@ SEG_DEV void select_dst(seg_conv_desc& d, int n0) {
   }
 }
 
+// seg_conv_desc.signal: announce "this launch has started" (hence: everything before it on its stream has finished)
+SEG_DEV void conv_signal(const seg_conv_desc& d) {
+  if (d.signal != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    __hip_atomic_store(d.signal, d.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 #ifdef SEG_ABLATE
 // Debug builds only (SEG_EXTRA_FLAGS=-DSEG_ABLATE, tools/ablate_conv.py): parts of the tiled kernel switched off one at a
 // time to see which of them its run time follows.  1 patch loads, 2 filter loads, 4 LDS reads + MFMAs, 8 epilogue,
@@ -260,6 +266,7 @@ void conv_fwd_kernel(const ConvK P) {
   float* sB = reinterpret_cast<float*>(smem + PATCH_BYTES + NT * BN * RSTR);
 
   seg_conv_desc d = P.d;
+  conv_signal(d);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -451,6 +458,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_glds_kernel(const ConvK
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   seg_conv_desc d = P.d;
+  conv_signal(d);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;

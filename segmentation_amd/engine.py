@@ -188,6 +188,25 @@ def _fork(src, dst):
     ev = torch.cuda.Event(); ev.record(src); dst.wait_event(ev)
 
 
+# Signal forks (eager launches only).  An event recorded on the main stream between two kernels costs that stream 4-7 us (a
+# barrier packet with a completion signal; tools/micro/sigwait.hip) and a backward pass forks a filter gradient off before
+# almost every data gradient: ~28 records, ~0.15 ms of a 1.17 ms step.  Instead the NEXT convolution on the main stream
+# stores a sequence number when it starts (seg_conv_desc.signal: on an in-order stream that means everything before it is
+# complete and released) and the side stream waits for that number with hipStreamWaitValue32: nothing is added to the main
+# queue.  One flag per main stream (the numbers must reach it in launch order); SEG_FORK_SIGNAL=0 falls back to events.
+_SIGNALS = {}
+_SIGNAL_ON = os.environ.get('SEG_FORK_SIGNAL', '1') != '0'
+
+
+def _signal_state(main):
+    key = (main.device.index, main.cuda_stream)
+    st = _SIGNALS.get(key)
+    if st is None:
+        st = _SIGNALS[key] = {'flag': torch.zeros(16, dtype=torch.int32, device=main.device), 'n': 0, 'hip': L.hip_runtime()}
+        torch.cuda.synchronize(main.device)
+    return st
+
+
 class Plan(object):
     """Ordered list of C-ABI launches.  Every entry is (name, fn, args-without-stream)."""
 
@@ -213,6 +232,9 @@ class Plan(object):
             for i_, (name, fn, args) in enumerate(self.ops):
                 if fn is None or name in skip or self.meta[i_].get('flavor', flavor) != flavor:
                     continue
+                d_ = self.meta[i_].get('desc')
+                if isinstance(d_, L.ConvDesc):
+                    d_.signal = None                      # (a multi-stream run of this plan may have left a signal request)
                 if dbg:
                     import sys
                     sys.stderr.write('[launch] %s/%s\n' % (self.name, name)); sys.stderr.flush()
@@ -230,10 +252,27 @@ class Plan(object):
         main_epoch, forked_at = 0, {}             # launches on the main stream so far; per side stream: the count at its last fork
         capturing = torch.cuda.is_current_stream_capturing()
         dirty = set()                             # side streams with launches the main stream has not waited for yet
+        sig = _signal_state(main) if (_SIGNAL_ON and not capturing) else None
+        sig_at = {}                               # op index of a main-stream convolution -> the number it has to announce
+        held = {}                                 # side stream id -> (op index it waits for, [(name, fn, args)] to launch behind it)
+        by_id = {id(o_): o_ for o_ in side}
+
+        def next_main_conv(i0):
+            """the next op after i0 that will launch on the main stream, if it is a convolution (it can carry a signal)"""
+            for j in range(i0 + 1, len(self.ops)):
+                nm, f_, _ = self.ops[j]
+                md = self.meta[j]
+                if nm in skip or md.get('flavor', flavor) != flavor or md.get('side', 0):
+                    continue
+                if f_ is None:
+                    return None                    # a join comes first: the launch must be on its stream before the main stream waits for it
+                return j if isinstance(md.get('desc'), L.ConvDesc) else None
+            return None
 
         def join(st_):
             # (eagerly a stream that has launched nothing since the main stream last waited for it needs no second wait)
             nonlocal main_epoch
+            assert id(st_) not in held, 'a signal fork was still pending at a join (the op it waits for lies behind the join)'
             if capturing or id(st_) in dirty:
                 fork(st_, main)
                 dirty.discard(id(st_))
@@ -274,14 +313,47 @@ class Plan(object):
                 # of step time when launched eagerly (eleven of them: 1.44 against 1.19 ms), far more than the launch it guards.
                 # Under stream capture every edge is kept: the captured graph's split into streams depends on them (1.38 against
                 # 1.25 ms without).
+                if id(st) in held:
+                    held[id(st)][1].append((name, fn, args))         # stays in order behind the held launches of its stream
+                    continue
                 if capturing or forked_at.get(id(st)) != main_epoch:
+                    j = next_main_conv(i) if sig is not None else None
+                    if j is not None:
+                        # signal fork: this launch (and what follows it on its stream) is issued right AFTER main-stream op j, which
+                        # announces its start -- the waiter is always enqueued behind its signaller, whatever hardware queue
+                        # the two streams share, so the wait cannot block the kernel it waits for
+                        if j not in sig_at:
+                            sig['n'] += 1
+                            sig_at[j] = sig['n'] & 0x7fffffff
+                        held[id(st)] = (j, [(name, fn, args)])
+                        forked_at[id(st)] = main_epoch
+                        dirty.add(id(st))
+                        continue
                     fork(main, st)
                     forked_at[id(st)] = main_epoch
                 dirty.add(id(st))
                 rc = fn(*args, C.c_void_p(st.cuda_stream))
             else:
                 main_epoch += 1
+                d_ = self.meta[i].get('desc')
+                v = None
+                if isinstance(d_, L.ConvDesc):           # (always rewritten: the descriptor is reused by every run of the plan)
+                    v = sig_at.pop(i, None)
+                    d_.signal = sig['flag'].data_ptr() if v is not None else None
+                    d_.signal_value = v or 0
                 rc = fn(*args, sp)
+                if v is not None and rc == 0:
+                    for sid_, (j, lst) in list(held.items()):
+                        if j != i:
+                            continue
+                        st_ = by_id[sid_]
+                        if sig['hip'].hipStreamWaitValue32(C.c_void_p(st_.cuda_stream), C.c_void_p(sig['flag'].data_ptr()), v, 0, 0xffffffff) != 0:   # 0 = >=
+                            raise L.SegError('hipStreamWaitValue32 failed')
+                        for nm_, f_, a_ in lst:
+                            r_ = f_(*a_, C.c_void_p(st_.cuda_stream))
+                            if r_ != 0:
+                                L.check(r_, '%s/%s' % (self.name, nm_))
+                        del held[sid_]
             if rc != 0:
                 L.check(rc, '%s/%s' % (self.name, name))
         if aux_used:
@@ -361,6 +433,9 @@ class Plan(object):
                 ev = torch_mod.cuda.Event(); ev.record(main); st.wait_event(ev)
             e0, e1 = E_(), E_()
             e0.record(st)
+            d_ = self.meta[i].get('desc')
+            if isinstance(d_, L.ConvDesc):
+                d_.signal = None                          # (forks are events here)
             rc = fn(*args, C.c_void_p(st.cuda_stream) if st is not main else sp)
             if rc != 0:
                 L.check(rc, '%s/%s' % (self.name, name))
