@@ -548,6 +548,15 @@ thread_local int32_t* g_plan_ks = nullptr;     // planning mode: report ksplit /
 thread_local int64_t* g_plan_bytes = nullptr;
 thread_local RedJob* g_job_out = nullptr;      // job-capture mode: describe the slab reduction, launch nothing
 
+// Workgroups a filter-gradient launch aims for (K splits x channel tiles).  128, half the CUs: in the train step these launches
+// share the chip with the data gradients of the critical stream, and every K split costs a partial-sum slab that the reduction
+// reads back; stand-alone a layer is fastest near 256, but the step is 4 % (256^2) / 3 % (512^2) faster at 128 and slower
+// again at 96 (profiles/r02_wgs_sweep.txt).  SEG_WGRAD_WGS overrides.
+inline int wgrad_target_wgs() {
+  static const int v = getenv("SEG_WGRAD_WGS") ? atoi(getenv("SEG_WGRAD_WGS")) : 128;
+  return v > 0 ? v : 128;
+}
+
 template <typename T, int TH, int TW, int KH, int KW, int S, int WCI, int WCO, int FCI, int FCO>
 int launch_cfg(const WgK& P0, hipStream_t st) {
   constexpr int BN = 16 * FCO * WCO, ES = sizeof(T), CIT = 16 * FCI * WCI;
@@ -569,7 +578,7 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
   // of the workgroup tile, so never more than needed and never more than there are tiles.
   const bool rs = KH > 1 && P.d.bias_mode != 2 && P.ntiles <= 64 && base < 192;
   const int wg = base * (rs ? KH : 1);
-  static const int target_wgs = getenv("SEG_WGRAD_WGS") ? atoi(getenv("SEG_WGRAD_WGS")) : 256;
+  const int target_wgs = wgrad_target_wgs();
   auto k0 = conv_wgrad_kernel<Tr<T>::DT, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, 0>;
   auto k1 = conv_wgrad_kernel<Tr<T>::DT, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, (KH > 1 ? 1 : 0)>;
   static int occ = 0;                      // resident workgroups per CU of this instance
@@ -643,6 +652,8 @@ int launch_k(const WgK& P, hipStream_t st) {
     // workgroup), so A wins on the big maps (512 x 512: 540-717 TF/s for kernel + reduction) and B / C on the small ones.
     //   cost [us] = 8 + rounds * ceil(tiles / ksplit) * t_tile + (ksplit > 1 ? 3 + ksplit * slab_bytes / 4.5 TB/s : 0)
     static const int layout = getenv("SEG_WGRAD_LAYOUT") ? atoi(getenv("SEG_WGRAD_LAYOUT")) : 2;   // 0 = r01 choice (C only), 1 = B and C
+    // (the layout choice keeps the stand-alone calibration at 256 workgroups: choosing layouts for 128 was measured slower)
+    static const int cm_wgs = getenv("SEG_WGRAD_CM_WGS") ? atoi(getenv("SEG_WGRAD_CM_WGS")) : 256;
     const bool ci64 = d.src0.c % 64 == 0 && (!d.src1.ptr || d.src1.c % 64 == 0), co64 = d.dz.c % 64 == 0;
     struct Cand { int cfg, th, tw, cit, bn, occ; double rate; };
     static const Cand cands[] = {{11, 8, 16, 64, 64, 1, 750.}, {14, 8, 8, 64, 64, 1, 750.}, {12, 8, 16, 32, 64, 2, 620.}, {15, 8, 8, 32, 64, 2, 620.},
@@ -657,7 +668,7 @@ int launch_k(const WgK& P, hipStream_t st) {
       const int base = (kin / c.cit) * (d.dz.c / c.bn);
       const bool rs = KH > 1 && d.bias_mode != 2 && ntiles <= 64 && base < 192;
       const int wg = base * (rs ? KH : 1);
-      long ks = cdiv(256, wg); if (ks > ntiles) ks = ntiles; if (ks < 1) ks = 1;
+      long ks = cdiv(cm_wgs, wg); if (ks > ntiles) ks = ntiles; if (ks < 1) ks = 1;
       const double t_tile = 2.0 * c.th * c.tw * KH * KW * c.cit * c.bn / (rs ? KH : 1) / (c.rate * 1e6 / 256.0);   // us on one CU
       const double rounds = (double)cdiv((int)(wg * ks), 256 * c.occ);
       const double slab = (double)KH * KW * c.cit * c.bn * 4.0 * base;           // bytes per K split (all output tiles)
