@@ -195,7 +195,23 @@ def _fork(src, dst):
 # complete and released) and the side stream waits for that number with hipStreamWaitValue32: nothing is added to the main
 # queue.  One flag per main stream (the numbers must reach it in launch order); SEG_FORK_SIGNAL=0 falls back to events.
 _SIGNALS = {}
-_SIGNAL_ON = os.environ.get('SEG_FORK_SIGNAL', '1') != '0'
+def _signals_allowed():
+    """Signal forks need the waiting kernel and the kernel it waits for to be free to run at the same time.  A profiler that
+    runs ONE kernel at a time (rocprofv3 --pmc: counter collection serialises dispatches across queues; thread trace and PC
+    sampling likewise; any unknown HSA tool) can pick the waiter first and then never dispatch its signaller: fall back to
+    events there.  Kernel tracing alone (ROCPROF_KERNEL_TRACE) leaves the queues concurrent."""
+    e = os.environ
+    if e.get('SEG_FORK_SIGNAL', '1') == '0':
+        return False
+    if e.get('HSA_TOOLS_LIB') or e.get('AMD_SERIALIZE_KERNEL', '0') not in ('', '0'):
+        return False
+    for k, v in e.items():
+        if k.startswith('ROCPROF_') and v not in ('', '0') and any(t in k for t in ('COUNTER', 'PMC', 'THREAD_TRACE', 'ATT', 'PC_SAMPLING', 'SERIALIZ')):
+            return False
+    return True
+
+
+_SIGNAL_ON = _signals_allowed()
 
 
 def _signal_state(main):

@@ -90,3 +90,17 @@ def test_unet_plan_geometry():
         unet_sizes(128)
     ls = unet_layers(4, 32, 3)
     assert sum(l.wsize + l.cout for l in ls) == 7760196
+
+
+def test_signal_forks_are_off_under_serialising_profilers(monkeypatch):
+    """hipStreamWaitValue32 waiters deadlock when a tool dispatches one kernel at a time (rocprofv3 --pmc): events there"""
+    from segmentation_amd import engine as E
+    for k in list(os.environ):
+        if k.startswith('ROCPROF_') or k in ('HSA_TOOLS_LIB', 'AMD_SERIALIZE_KERNEL', 'SEG_FORK_SIGNAL'):
+            monkeypatch.delenv(k, raising=False)
+    assert E._signals_allowed()
+    monkeypatch.setenv('ROCPROF_KERNEL_TRACE', '1'); assert E._signals_allowed()
+    monkeypatch.setenv('ROCPROF_COUNTER_COLLECTION', '1'); assert not E._signals_allowed()
+    monkeypatch.delenv('ROCPROF_COUNTER_COLLECTION'); monkeypatch.setenv('ROCPROF_COUNTERS', 'pmc: FETCH_SIZE'); assert not E._signals_allowed()
+    monkeypatch.delenv('ROCPROF_COUNTERS'); monkeypatch.setenv('HSA_TOOLS_LIB', 'librocprofiler64.so'); assert not E._signals_allowed()
+    monkeypatch.delenv('HSA_TOOLS_LIB'); monkeypatch.setenv('SEG_FORK_SIGNAL', '0'); assert not E._signals_allowed()
