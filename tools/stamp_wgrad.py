@@ -29,5 +29,6 @@ def run(hw, cin, cout, B=16):
         print('   tile: loads_landed  committed  prefetch_issued | next loads_landed   (ticks since start)')
         for i in range(min(n, 12)):
             print('   %2d  %7.0f %7.0f %7.0f' % (i, a[wg, 0, i] - t0, a[wg, 1, i] - t0, a[wg, 2, i] - t0))
-run(122, 64, 64)
-run(59, 128, 128)
+import sys as _s
+for _a in ([tuple(int(v) for v in x.split(",")) for x in _s.argv[1:]] or [(122, 64, 64), (59, 128, 128)]):
+    run(*_a)
