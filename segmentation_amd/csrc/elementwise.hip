@@ -211,8 +211,14 @@ __global__ void softmax_xent_kernel(seg_view lg, const uint8_t* labels, int LH, 
     const int lab = labels[((int64_t)b * LH + y + ly0) * LW + x + lx0];
     float zv[NCP];
     float m = -INFINITY;
+    // (the float logits of a pixel are read as 16-byte vectors: 32 scalar loads per thread made this kernel 3x its HBM time
+    // at 21 classes; the view is 32-byte aligned and at least NCP floats wide: checked on the host)
 #pragma unroll
-    for (int c = 0; c < NCP; ++c) { zv[c] = c < nc ? z[c] : -INFINITY; m = fmaxf(m, zv[c]); }
+    for (int c4 = 0; c4 < NCP / 4; ++c4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(z + c4 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const int c = c4 * 4 + e; zv[c] = c < nc ? v[e] : -INFINITY; m = fmaxf(m, zv[c]); }
+    }
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < NCP; ++c) { zv[c] = c < nc ? expf(zv[c] - m) : 0.f; s += zv[c]; }
@@ -677,18 +683,25 @@ __global__ void bilinear_fwd_kernel(seg_view src, int Hs, int Ws, int f, const f
   }
 }
 
-template <typename T>
+// LP lanes share one (source pixel, 8 channels): lane r takes the filter rows r, r + LP, ... and the LP partial sums meet in a
+// fixed butterfly.  (One thread per source pixel walked all k*k = 256 taps of the 8x layer alone: 131 k threads for a 134 MB
+// tensor, 146 us per FCN-8s step.)
+template <typename T, int LP>
 __global__ void bilinear_bwd_kernel(seg_view dd, int Hd, int Wd, int cy, int cx, int f, const float* filt, seg_view ds,
                                     int Hs, int Ws, int B, int C8, int dd_f32) {
   const int k = 2 * f - f % 2, pb = (k - f) / 2;
-  const int64_t total = (int64_t)B * Hs * Ws * C8;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = i;
+  const int64_t total = (int64_t)B * Hs * Ws * C8 * LP;
+  for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x; i0 < total; i0 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = i0 + threadIdx.x;                    // (blockDim.x and the grid stride are multiples of LP: a group stays together)
+    const bool on = i < total;
+    int64_t t = on ? i / LP : 0;
+    const int r = (int)(i % LP);
     const int c8 = t % C8; t /= C8;
     const int ix = t % Ws; t /= Ws;
     const int iy = t % Hs; const int b = t / Hs;
     float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int u = 0; u < k; ++u) {
+    if (on)
+    for (int u = r; u < k; u += LP) {
       const int Y = iy * f + u - pb, y = Y - cy;          // Y: position in the SAME-cropped upsampled map
       if (Y < 0 || Y >= Hs * f || y < 0 || y >= Hd) continue;
       for (int v = 0; v < k; ++v) {
@@ -700,8 +713,14 @@ __global__ void bilinear_bwd_kernel(seg_view dd, int Hd, int Wd, int cy, int cx,
         else { Vec8<T> s; s.load(reinterpret_cast<const T*>(dd.ptr) + off); for (int e = 0; e < 8; ++e) a[e] += w * s.get(e); }
       }
     }
-    Vec8<T> o; for (int e = 0; e < 8; ++e) o.set(e, a[e]);
-    o.store(reinterpret_cast<T*>(ds.ptr) + view_off(ds, b, iy, ix) + c8 * 8);
+#pragma unroll
+    for (int o = LP / 2; o > 0; o >>= 1)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += __shfl_xor(a[e], o, 64);
+    if (on && r == 0) {
+      Vec8<T> o; for (int e = 0; e < 8; ++e) o.set(e, a[e]);
+      o.store(reinterpret_cast<T*>(ds.ptr) + view_off(ds, b, iy, ix) + c8 * 8);
+    }
   }
 }
 
@@ -786,8 +805,14 @@ extern "C" int seg_softmax_xent(const seg_view* logits, const uint8_t* labels, i
   if (!logits || !logits->ptr || !labels || !loss_sum || !view_ok(dlogits, H, W, dlogits ? dlogits->c : 0)) { seg_set_error("softmax_xent: bad args"); return SEG_ERR_ARG; }
   if (n_classes < 1 || n_classes > 32 || n_classes > dlogits->c || dlogits->c % 8 || dlogits->c > 32) { seg_set_error("softmax_xent: n_classes %d unsupported (1..32)", n_classes); return SEG_ERR_UNSUPPORTED; }
   if (ly0 < 0 || lx0 < 0 || ly0 + H > LH || lx0 + W > LW) { seg_set_error("softmax_xent: label window out of range"); return SEG_ERR_ARG; }
+  {
+    const int ncp = n_classes <= 4 ? 4 : n_classes <= 8 ? 8 : n_classes <= 16 ? 16 : 32;     // floats read per pixel (16-byte vectors)
+    if (logits->cs % 4 || logits->coff % 4 || logits->coff + ncp > logits->cs || (reinterpret_cast<uintptr_t>(logits->ptr) & 15)) {
+      seg_set_error("softmax_xent: logits view must be 16-byte aligned with %d readable floats per pixel", ncp); return SEG_ERR_ARG;
+    }
+  }
   const int64_t n = (int64_t)B * H * W;
-  const int g = grid_for(n, 256, 256);
+  const int g = grid_for(n, 256, 1024);
 #define XENT_ARGS dim3(g), dim3(256), 0, ST(stream), *logits, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, grad_scale, loss_sum, *dlogits
 #define XENT_NCP(TT) do { if (n_classes <= 4) SEG_LAUNCH((softmax_xent_kernel<TT, 4>), XENT_ARGS); \
     else if (n_classes <= 8) SEG_LAUNCH((softmax_xent_kernel<TT, 8>), XENT_ARGS); \
@@ -898,8 +923,10 @@ extern "C" int seg_bilinear_up_bwd(const seg_view* ddst, int32_t Hd, int32_t Wd,
                                    void* stream) {
   if (!view_ok(ddst, Hd, Wd, C) || !view_ok(dsrc, Hs, Ws, C) || !filt || factor < 1 || C % 8) { seg_set_error("bilinear_bwd: bad args"); return SEG_ERR_ARG; }
   const int64_t n = (int64_t)B * Hs * Ws * (C / 8);
-  DISPATCH(dtype,
-           SEG_LAUNCH(bilinear_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *ddst, Hd, Wd, cy, cx, factor, filt, *dsrc, Hs, Ws, B, C / 8, ddst_f32),
-           SEG_LAUNCH(bilinear_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *ddst, Hd, Wd, cy, cx, factor, filt, *dsrc, Hs, Ws, B, C / 8, ddst_f32));
+#define BIL_BWD(TT, LP) SEG_LAUNCH((bilinear_bwd_kernel<TT, LP>), dim3(grid_for(n * LP, 256, 16384)), dim3(256), 0, ST(stream), *ddst, Hd, Wd, cy, cx, factor, filt, *dsrc, Hs, Ws, B, C / 8, ddst_f32)
+#define BIL_BWD_F(TT) do { if (factor >= 8) BIL_BWD(TT, 16); else if (factor >= 2) BIL_BWD(TT, 4); else BIL_BWD(TT, 1); } while (0)
+  DISPATCH(dtype, BIL_BWD_F(float), BIL_BWD_F(bf16_t));
+#undef BIL_BWD_F
+#undef BIL_BWD
   return seg_check_launch("bilinear_bwd");
 }
