@@ -240,6 +240,22 @@ int seg_bilinear_up_bwd(const seg_view* ddst, int32_t Hd, int32_t Wd, int32_t cy
                         int32_t factor, const float* filt, const seg_view* dsrc, int32_t Hs, int32_t Ws,
                         int32_t B, int32_t C, int32_t ddst_f32, int32_t dtype, void* stream);
 
+/* The FCN training head in one launch: logits = the (cropped) bilinear up-sampling of the score map, softmax x-entropy against
+ * the labels, dlogits -- models/fcn.py:199-218 + models/basemodel.py:59-70 -- without materialising the float logits
+ * (logits_out non-NULL: also store them, for `y_hat` / tests).  Arguments as seg_bilinear_up_fwd (src .. cy, cx) followed by
+ * those of seg_softmax_xent. */
+int seg_bilinear_xent(const seg_view* src, int32_t Hs, int32_t Ws, int32_t factor, const float* filt, int32_t cy, int32_t cx,
+                      const uint8_t* labels, int32_t LH, int32_t LW, int32_t ly0, int32_t lx0, int32_t B, int32_t H, int32_t W,
+                      int32_t n_classes, float inv_n, float grad_scale, float* loss_sum, const seg_view* dlogits,
+                      const seg_view* logits_out, int32_t dtype, void* stream);
+/* seg_bilinear_up_bwd in separable form (the tent filter bank is an outer product, utils/upsampling.py:6-24): a horizontal pass
+ * into ws (float [B][Hd][Ws][C], seg_bilinear_up_bwd_ws_bytes) and a vertical one -- 2k taps per source pixel instead of k*k.
+ * Same result up to float summation order. */
+int64_t seg_bilinear_up_bwd_ws_bytes(int32_t B, int32_t Hd, int32_t Ws, int32_t C);
+int seg_bilinear_up_bwd_sep(const seg_view* ddst, int32_t Hd, int32_t Wd, int32_t cy, int32_t cx, int32_t factor, const float* filt,
+                            const seg_view* dsrc, int32_t Hs, int32_t Ws, int32_t B, int32_t C, int32_t ddst_f32, float* ws,
+                            int64_t ws_bytes, int32_t dtype, void* stream);
+
 /* out = a * (relu_mask>0) elementwise over a [B,H,W,C] window (ReLU-grad where no conv epilogue can do it). */
 int seg_relu_grad(const seg_view* dy, const seg_view* y_act, const seg_view* dz,
                   int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);

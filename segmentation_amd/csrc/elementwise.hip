@@ -724,6 +724,137 @@ __global__ void bilinear_bwd_kernel(seg_view dd, int Hd, int Wd, int cy, int cx,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// FCN head, fused: logits = crop(bilinear_up_f(score))  ->  softmax x-entropy  ->  dlogits, without the float logits
+// tensor in between (models/fcn.py:199-218 + models/basemodel.py:59-70).  At 512^2 x 21 classes (padded 32) the separate
+// launches wrote and re-read 268 MB of float logits per step (bilinear_fwd 89 us + softmax_xent 116 us of a 1.09 ms step);
+// the score map is L2-resident, so the fused form moves only the labels and the dlogits.  LPX lanes share a pixel (4
+// channels each): every access is one contiguous run per pixel, max / sum go through LPX-wide butterflies.
+// logits_out (nullable): also store the float logits (tests, `y_hat`).
+// ------------------------------------------------------------------------------------------
+template <typename T, int LPX, int F>       // F: the factor at compile time (8 / 16 / 32: shifts instead of integer divisions), 0 = run time
+__global__ void bilinear_xent_kernel(seg_view src, int Hs, int Ws, int f_rt, const float* filt, int cy, int cx, const uint8_t* labels, int LH, int LW,
+                                     int ly0, int lx0, int B, int H, int W, int nc, float inv_n, float gscale, float* loss_sum, seg_view dl,
+                                     seg_view lo) {
+  const int f = F ? F : f_rt;
+  const int k = 2 * f - f % 2, pb = (k - f) / 2;
+  // blockIdx.x: a 256-thread run of one image row (x = column, r = channel quad); blockIdx.y strides over the B*H rows: no
+  // 64-bit divisions per pixel (they were most of this kernel's instructions)
+  float local = 0.f;
+  const int xi = blockIdx.x * blockDim.x + threadIdx.x;
+  const int x = xi / LPX, r = xi % LPX;
+  for (int row = blockIdx.y; row < B * H; row += gridDim.y) {
+    const int b = row / H, y = row - b * H;
+    const bool on = x < W;
+    float zv[4] = {0.f, 0.f, 0.f, 0.f};
+    const int Y = y + cy, X = x + cx;
+    if (on && Y >= 0 && Y < Hs * f && X >= 0 && X < Ws * f) {
+      for (int u = (Y + pb) % f; u < k; u += f) {
+        const int iy = (Y + pb - u) / f;
+        if (iy < 0 || iy >= Hs) continue;
+        for (int v = (X + pb) % f; v < k; v += f) {
+          const int ix = (X + pb - v) / f;
+          if (ix < 0 || ix >= Ws) continue;
+          const float w = filt[u * k + v];
+          const T* sp = reinterpret_cast<const T*>(src.ptr) + view_off(src, b, iy, ix) + r * 4;
+          if constexpr (sizeof(T) == 2) {                 // the lane's 4 channels in ONE 8-byte load (4 scalar loads made this kernel load-issue-bound)
+            const bf16x4 v4 = *reinterpret_cast<const bf16x4*>(sp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) zv[e] += w * (float)v4[e];
+          } else {
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(sp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) zv[e] += w * v4[e];
+          }
+        }
+      }
+    }
+    if (on && lo.ptr != nullptr) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(lo.ptr) + view_off(lo, b, y, x) + r * 4) = f32x4{zv[0], zv[1], zv[2], zv[3]};
+    float m = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { if (r * 4 + e >= nc) zv[e] = -INFINITY; m = fmaxf(m, zv[e]); }
+#pragma unroll
+    for (int o = LPX / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float ev[4], s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ev[e] = r * 4 + e < nc ? (sizeof(T) == 2 ? __expf(zv[e] - m) : expf(zv[e] - m)) : 0.f; s += ev[e]; }
+#pragma unroll
+    for (int o = LPX / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const int lab = on ? labels[((int64_t)b * LH + y + ly0) * LW + x + lx0] : 255;
+    const bool valid = lab < nc;
+    if (on && valid && lab / 4 == r) local += (sizeof(T) == 2 ? __logf(s) : logf(s)) - (zv[lab % 4] - m);
+    if (on) {
+      const float kk = inv_n * gscale, rs = 1.f / s;
+      T* op = reinterpret_cast<T*>(dl.ptr) + view_off(dl, b, y, x) + r * 4;
+      if (r * 4 < dl.c) {
+        float gv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = r * 4 + e;
+          gv[e] = (c < nc && valid) ? (ev[e] * rs - (c == lab ? 1.f : 0.f)) * kk : 0.f;
+        }
+        if constexpr (sizeof(T) == 2) *reinterpret_cast<bf16x4*>(op) = bf16x4{(bf16_t)gv[0], (bf16_t)gv[1], (bf16_t)gv[2], (bf16_t)gv[3]};
+        else *reinterpret_cast<f32x4*>(op) = f32x4{gv[0], gv[1], gv[2], gv[3]};
+      }
+    }
+  }
+  __shared__ float wsum[4];
+  local = wave_sum(local);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss_sum, (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_n);
+}
+
+// adjoint of the bilinear up-sampling, separable: the tent filter bank is an outer product (utils/upsampling.py:6-24), so the
+// k x k gather becomes a horizontal pass (dd -> tmp[b][y][ix][c], float) and a vertical one (tmp -> ds): 2k taps instead of
+// k*k per source pixel and every dd element read once instead of four times.  Row / column weights: filt[c0*k + j] / sqrt(filt[c0*k + c0]).
+template <typename T>
+__global__ void bilinear_bwd_h_kernel(seg_view dd, int Hd, int Wd, int cx, int f, const float* filt, float* tmp, int Ws, int B, int C8, int dd_f32) {
+  const int k = 2 * f - f % 2, pb = (k - f) / 2, c0 = (k - 1) / 2;
+  const float nrm = rsqrtf(filt[c0 * k + c0]);
+  const int64_t total = (int64_t)B * Hd * Ws * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int c8 = t % C8; t /= C8;
+    const int ix = t % Ws; t /= Ws;
+    const int y = t % Hd; const int b = t / Hd;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int v = 0; v < k; ++v) {
+      const int X = ix * f + v - pb, x = X - cx;
+      if (X < 0 || X >= Ws * f || x < 0 || x >= Wd) continue;
+      const float w = filt[c0 * k + v] * nrm;
+      const int64_t off = view_off(dd, b, y, x) + c8 * 8;
+      if (dd_f32) { Vec8<float> s; s.load(reinterpret_cast<const float*>(dd.ptr) + off); for (int e = 0; e < 8; ++e) a[e] += w * s.get(e); }
+      else { Vec8<T> s; s.load(reinterpret_cast<const T*>(dd.ptr) + off); for (int e = 0; e < 8; ++e) a[e] += w * s.get(e); }
+    }
+    Vec8<float> o; for (int e = 0; e < 8; ++e) o.set(e, a[e]);
+    o.store(tmp + (((int64_t)b * Hd + y) * Ws + ix) * (C8 * 8) + c8 * 8);
+  }
+}
+
+template <typename T>
+__global__ void bilinear_bwd_v_kernel(const float* tmp, int Hd, int cy, int f, const float* filt, seg_view ds, int Hs, int Ws, int B, int C8) {
+  const int k = 2 * f - f % 2, pb = (k - f) / 2, c0 = (k - 1) / 2;
+  const float nrm = rsqrtf(filt[c0 * k + c0]);
+  const int64_t total = (int64_t)B * Hs * Ws * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = i;
+    const int c8 = t % C8; t /= C8;
+    const int ix = t % Ws; t /= Ws;
+    const int iy = t % Hs; const int b = t / Hs;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int u = 0; u < k; ++u) {
+      const int Y = iy * f + u - pb, y = Y - cy;
+      if (Y < 0 || Y >= Hs * f || y < 0 || y >= Hd) continue;
+      const float w = filt[u * k + c0] * nrm;
+      Vec8<float> s; s.load(tmp + (((int64_t)b * Hd + y) * Ws + ix) * (C8 * 8) + c8 * 8);
+      for (int e = 0; e < 8; ++e) a[e] += w * s.get(e);
+    }
+    Vec8<T> o; for (int e = 0; e < 8; ++e) o.set(e, a[e]);
+    o.store(reinterpret_cast<T*>(ds.ptr) + view_off(ds, b, iy, ix) + c8 * 8);
+  }
+}
+
 seg_view null_view() { seg_view v; memset(&v, 0, sizeof(v)); return v; }
 
 }  // namespace
@@ -929,4 +1060,49 @@ extern "C" int seg_bilinear_up_bwd(const seg_view* ddst, int32_t Hd, int32_t Wd,
 #undef BIL_BWD_F
 #undef BIL_BWD
   return seg_check_launch("bilinear_bwd");
+}
+
+extern "C" int seg_bilinear_xent(const seg_view* src, int32_t Hs, int32_t Ws, int32_t factor, const float* filt, int32_t cy, int32_t cx,
+                                 const uint8_t* labels, int32_t LH, int32_t LW, int32_t ly0, int32_t lx0, int32_t B, int32_t H, int32_t W,
+                                 int32_t n_classes, float inv_n, float grad_scale, float* loss_sum, const seg_view* dlogits,
+                                 const seg_view* logits_out, int32_t dtype, void* stream) {
+  if (!src || !labels || !loss_sum || !filt || factor < 1 || !view_ok(dlogits, H, W, dlogits ? dlogits->c : 0) || !view_ok(src, Hs, Ws, src->c)) { seg_set_error("bilinear_xent: bad args"); return SEG_ERR_ARG; }
+  if (n_classes < 1 || n_classes > 32 || n_classes > dlogits->c || dlogits->c % 8 || dlogits->c > 32 || src->c < n_classes) { seg_set_error("bilinear_xent: n_classes %d unsupported (1..32)", n_classes); return SEG_ERR_UNSUPPORTED; }
+  if (ly0 < 0 || lx0 < 0 || ly0 + H > LH || lx0 + W > LW) { seg_set_error("bilinear_xent: label window out of range"); return SEG_ERR_ARG; }
+  const int ncp = n_classes <= 4 ? 4 : n_classes <= 8 ? 8 : n_classes <= 16 ? 16 : 32;
+  if (src->c < ncp && src->c % 8) { seg_set_error("bilinear_xent: score map narrower than %d channels", ncp); return SEG_ERR_ARG; }
+  seg_view lov = null_view();
+  if (logits_out && logits_out->ptr) {
+    if (!view_ok(logits_out, H, W, logits_out->c) || logits_out->c < ncp || (reinterpret_cast<uintptr_t>(logits_out->ptr) & 15) || logits_out->cs % 4 || logits_out->coff % 4) { seg_set_error("bilinear_xent: bad logits_out view"); return SEG_ERR_ARG; }
+    lov = *logits_out;
+  }
+  const int lpx = ncp / 4;
+  const int gx = (W * lpx + 255) / 256;
+  int gy = 4096 / gx; if (gy > B * H) gy = B * H; if (gy < 1) gy = 1;      // ~4096 workgroups (one atomic each), rows strided
+#define BX_ARGS dim3(gx, gy), dim3(256), 0, ST(stream), *src, Hs, Ws, factor, filt, cy, cx, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, grad_scale, loss_sum, *dlogits, lov
+#define BX_F(TT, LL) do { if (factor == 8) SEG_LAUNCH((bilinear_xent_kernel<TT, LL, 8>), BX_ARGS); else if (factor == 16) SEG_LAUNCH((bilinear_xent_kernel<TT, LL, 16>), BX_ARGS); \
+    else if (factor == 32) SEG_LAUNCH((bilinear_xent_kernel<TT, LL, 32>), BX_ARGS); else SEG_LAUNCH((bilinear_xent_kernel<TT, LL, 0>), BX_ARGS); } while (0)
+#define BX_L(TT) do { if (lpx == 1) BX_F(TT, 1); else if (lpx == 2) BX_F(TT, 2); else if (lpx == 4) BX_F(TT, 4); else BX_F(TT, 8); } while (0)
+  DISPATCH(dtype, BX_L(float), BX_L(bf16_t));
+#undef BX_L
+#undef BX_F
+#undef BX_ARGS
+  return seg_check_launch("bilinear_xent");
+}
+
+extern "C" int64_t seg_bilinear_up_bwd_ws_bytes(int32_t B, int32_t Hd, int32_t Ws, int32_t C) { return (int64_t)B * Hd * Ws * C * 4; }
+
+extern "C" int seg_bilinear_up_bwd_sep(const seg_view* ddst, int32_t Hd, int32_t Wd, int32_t cy, int32_t cx, int32_t factor, const float* filt,
+                                       const seg_view* dsrc, int32_t Hs, int32_t Ws, int32_t B, int32_t C, int32_t ddst_f32, float* ws,
+                                       int64_t ws_bytes, int32_t dtype, void* stream) {
+  if (!view_ok(ddst, Hd, Wd, C) || !view_ok(dsrc, Hs, Ws, C) || !filt || factor < 1 || C % 8 || !ws || ws_bytes < seg_bilinear_up_bwd_ws_bytes(B, Hd, Ws, C)) { seg_set_error("bilinear_bwd_sep: bad args / workspace"); return SEG_ERR_ARG; }
+  const int64_t n1 = (int64_t)B * Hd * Ws * (C / 8), n2 = (int64_t)B * Hs * Ws * (C / 8);
+  DISPATCH(dtype,
+           SEG_LAUNCH(bilinear_bwd_h_kernel<float>, dim3(grid_for(n1, 256, 16384)), dim3(256), 0, ST(stream), *ddst, Hd, Wd, cx, factor, filt, ws, Ws, B, C / 8, ddst_f32),
+           SEG_LAUNCH(bilinear_bwd_h_kernel<bf16_t>, dim3(grid_for(n1, 256, 16384)), dim3(256), 0, ST(stream), *ddst, Hd, Wd, cx, factor, filt, ws, Ws, B, C / 8, ddst_f32));
+  if (int rc = seg_check_launch("bilinear_bwd_h")) return rc;
+  DISPATCH(dtype,
+           SEG_LAUNCH(bilinear_bwd_v_kernel<float>, dim3(grid_for(n2, 256, 16384)), dim3(256), 0, ST(stream), (const float*)ws, Hd, cy, factor, filt, *dsrc, Hs, Ws, B, C / 8),
+           SEG_LAUNCH(bilinear_bwd_v_kernel<bf16_t>, dim3(grid_for(n2, 256, 16384)), dim3(256), 0, ST(stream), (const float*)ws, Hd, cy, factor, filt, *dsrc, Hs, Ws, B, C / 8));
+  return seg_check_launch("bilinear_bwd_v");
 }

@@ -825,8 +825,29 @@ class Net(object):
         cx = (Ws * factor - Wd) // 2 if Ws * factor >= Wd else -((Wd - Ws * factor) // 2)
         gv, sv = ddst.view(), dsrc.view()
         plan.keep += [gv, sv, filt]
+        if factor >= 4:
+            # big factors: separable form (2k instead of k*k taps, the gradient map read once instead of four times)
+            nb = int(self.lib.seg_bilinear_up_bwd_ws_bytes(self.B, Hd, Ws, dsrc.Cp))
+            ws = torch.empty(nb // 4, dtype=torch.float32, device=self.device)
+            plan.keep.append(ws)
+            plan.add('bilinear_up%d/bwd' % factor, self.lib.seg_bilinear_up_bwd_sep, C.byref(gv), Hd, Wd, cy, cx, factor, filt.data_ptr(),
+                     C.byref(sv), Hs, Ws, self.B, dsrc.Cp, 0, ws.data_ptr(), nb, self.dtype, kernel='bilinear_bwd_h_kernel')
+            return
         plan.add('bilinear_up%d/bwd' % factor, self.lib.seg_bilinear_up_bwd, C.byref(gv), Hd, Wd, cy, cx, factor, filt.data_ptr(),
                  C.byref(sv), Hs, Ws, self.B, dsrc.Cp, 0, self.dtype, kernel='bilinear_bwd_kernel')
+
+    def bilinear_xent(self, plan, src, Hs, Ws, factor, filt, labels_u8, LH, LW, loff, H, W, n_classes, loss_buf, dlogits, logits=None):
+        """logits = crop_or_pad(up_factor(src), H, W); mean softmax x-entropy; dlogits -- one launch (seg_bilinear_xent).  logits:
+        float Act to ALSO receive the logits (None: they are never stored)."""
+        cy = (Hs * factor - H) // 2 if Hs * factor >= H else -((H - Hs * factor) // 2)
+        cx = (Ws * factor - W) // 2 if Ws * factor >= W else -((W - Ws * factor) // 2)
+        sv, dv = src.view(), dlogits.view()
+        lv = logits.view() if logits is not None else None
+        plan.keep += [sv, dv, lv, filt]
+        inv_n = 1.0 / float(self.B * H * W)
+        plan.add('up%d+xent' % factor, self.lib.seg_bilinear_xent, C.byref(sv), Hs, Ws, factor, filt.data_ptr(), cy, cx, labels_u8.data_ptr(), LH, LW,
+                 loff[0], loff[1], self.B, H, W, n_classes, inv_n, 1.0, loss_buf.data_ptr(), C.byref(dv), C.byref(lv) if lv is not None else None,
+                 self.dtype, kernel='bilinear_xent_kernel')
 
     # ---------------- DeconvModel ops (models/deconvolution.py:101-178) ----------------
     def _dconv_desc(self, layer, big, small, mask=None, bias=False, relu=False):

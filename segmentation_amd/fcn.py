@@ -102,7 +102,7 @@ class FCNModel(BaseModel):
         return self.fwd_plan
 
     # ---- forward graph ----
-    def _emit_forward(self, net, plan, x_in, H, W):
+    def _emit_forward(self, net, plan, x_in, H, W, final_up=True):
         Ly, nc = self.store.layers, self.n_classes
         A = {}
         h, w = H, W
@@ -128,11 +128,14 @@ class FCNModel(BaseModel):
             A[name] = net.act(h, w, Ly[name].cout, name=name)
             net.conv_fwd(plan, Ly[name], [(prev, 0, 0)], h, w, A[name])
             prev = A[name]
-        A['logits'] = net.act(H, W, nc, f32=True, name='logits')
+        # final_up=False (training): the last up-sampling is fused with the loss (Net.bilinear_xent); geo['final'] names its input
+        if final_up or self.keep_logits:
+            A['logits'] = net.act(H, W, nc, f32=True, name='logits')
         geo = {}                                        # (src name, Hs, Ws, factor, dst name, Hd, Wd)
         fr = A['conv_fr']
         if self.fcn_type == '32s':
-            net.bilinear_fwd(plan, fr, fr.H, fr.W, 32, self._filt(32), None, A['logits'], H, W, dst_f32=True)
+            if final_up:
+                net.bilinear_fwd(plan, fr, fr.H, fr.W, 32, self._filt(32), None, A['logits'], H, W, dst_f32=True)
             geo['final'] = ('conv_fr', 32)
         else:
             p4 = A['pool4']
@@ -144,7 +147,8 @@ class FCNModel(BaseModel):
             A['fuse4'] = net.act(p4.H, p4.W, nc, name='fuse4')
             net.bilinear_fwd(plan, fr, fr.H, fr.W, 2, self._filt(2), A['pool4_score'], A['fuse4'], p4.H, p4.W)
             if self.fcn_type == '16s':
-                net.bilinear_fwd(plan, A['fuse4'], p4.H, p4.W, 16, self._filt(16), None, A['logits'], H, W, dst_f32=True)
+                if final_up:
+                    net.bilinear_fwd(plan, A['fuse4'], p4.H, p4.W, 16, self._filt(16), None, A['logits'], H, W, dst_f32=True)
                 geo['final'] = ('fuse4', 16)
             else:
                 p3 = A['pool3']
@@ -152,7 +156,8 @@ class FCNModel(BaseModel):
                 net.conv_fwd(plan, Ly['pool3_score'], [(p3, 0, 0)], p3.H, p3.W, A['pool3_score'])
                 A['fuse3'] = net.act(p3.H, p3.W, nc, name='fuse3')
                 net.bilinear_fwd(plan, A['fuse4'], p4.H, p4.W, 2, self._filt(2), A['pool3_score'], A['fuse3'], p3.H, p3.W)
-                net.bilinear_fwd(plan, A['fuse3'], p3.H, p3.W, 8, self._filt(8), None, A['logits'], H, W, dst_f32=True)
+                if final_up:
+                    net.bilinear_fwd(plan, A['fuse3'], p3.H, p3.W, 8, self._filt(8), None, A['logits'], H, W, dst_f32=True)
                 geo['final'] = ('fuse3', 8)
         return A, geo
 
@@ -167,12 +172,20 @@ class FCNModel(BaseModel):
         net.step_begin(fwd, self.loss_buf)     # aux stream: global_step += 1, loss accumulator = 0
         net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1
         col = net.first_im2col(fwd, Ly['conv1'], self.input_x, H, W)         # side stream, overlaps the forward pass
-        A, geo = self._emit_forward(net, fwd, self.input_x, H, W)
+        # The last up-sampling, the loss and dlogits are ONE launch (no 268 MB float logits tensor at 512^2 x 21 classes); the
+        # adversary needs the logits as a tensor and keeps the separate launches; keep_logits=True also stores them (y_hat, tests).
+        fused_head = not self.adversarial_training and os.environ.get('SEG_FUSE_HEAD', '1') != '0'
+        A, geo = self._emit_forward(net, fwd, self.input_x, H, W, final_up=not fused_head)
         self.acts = A
         self.out_hw = (H, W)
         self.label_off = (0, 0)
         dlog = net.act(H, W, nc, name='dlogits')
-        net.softmax_xent(fwd, A['logits'], self.input_y, H, W, (0, 0), H, W, nc, self.loss_buf, dlog)
+        if fused_head:
+            src = A[geo['final'][0]]
+            net.bilinear_xent(fwd, src, src.H, src.W, geo['final'][1], self._filt(geo['final'][1]), self.input_y, H, W, (0, 0), H, W, nc,
+                              self.loss_buf, dlog, logits=A.get('logits'))
+        else:
+            net.softmax_xent(fwd, A['logits'], self.input_y, H, W, (0, 0), H, W, nc, self.loss_buf, dlog)
         if self.adversarial_training:
             self._attach_adversary(A['logits'], H, W, H, W, dlog)
         self.dlogits = dlog
@@ -238,7 +251,7 @@ class FCNModel(BaseModel):
         net.flush_reduce(seg)
         segs.append((seg, l.b_off + l.nbias))
         self._finish_training_plans(segs)
-        self.y_hat = A['logits']
+        self.y_hat = A.get('logits')          # None unless keep_logits / adversarial training (the fused head does not store them)
 
     def _build_infer(self, B, H, W, Cin):
         if Cin != self.input_channel:

@@ -75,6 +75,7 @@ def _unet(x, y, nc, S, dtype, **kw):
 
 def _fcn8s(x, y, nc, S, dtype, **kw):
     kw.setdefault('learning_rate', 1e-3)
+    kw.setdefault('keep_logits', True)
     return FCNModel(sess=None, dataset=ArrayDataSet(x, y), n_classes=nc, input_dims=S, fcn_type='8s', n_kernels=32,
                     log_dir=None, save_dir=None, load_snapshot=False, dtype=dtype, seed=5555, **kw)
 

@@ -17,6 +17,7 @@ def _data(B, S, nc, seed=5555):
 
 
 def _model(x, y, nc, S, fcn_type, dtype, nk=16, **kw):
+    kw.setdefault('keep_logits', True)          # (the fused training head does not store the logits otherwise)
     return FCNModel(sess=None, dataset=ArrayDataSet(x, y), n_classes=nc, input_dims=S, fcn_type=fcn_type, n_kernels=nk,
                     learning_rate=1e-3, log_dir=None, save_dir=None, load_snapshot=False, dtype=dtype, autoencoder=False, **kw)
 
@@ -90,3 +91,22 @@ def test_fcn_odd_input_size_crop_or_pad():
     g = m.store.get_grads()
     ref = g_ref['conv_fr']['weights']
     assert np.abs(g['conv_fr']['weights'] - ref).max() / (np.abs(ref).max() + 1e-20) < 3e-4
+
+
+def test_fcn_fused_head_equals_separate_launches(monkeypatch):
+    """the fused up-sampling + x-entropy head (default) against bilinear_fwd + softmax_xent (SEG_FUSE_HEAD=0): same loss and
+    gradients; without keep_logits the float logits are never stored (y_hat is None)"""
+    B, S, nc = 2, 96, 5
+    x, y = _data(B, S, nc)
+    res = []
+    for fuse in ('1', '0'):
+        monkeypatch.setenv('SEG_FUSE_HEAD', fuse)
+        m = _model(x, y, nc, S, '8s', 'f32', use_graph=False, keep_logits=False)
+        assert (m.y_hat is None) == (fuse == '1')
+        names = [o[0] for o in m.fwd_plan.ops]
+        assert ('up8+xent' in names) == (fuse == '1') and ('xent' in names) == (fuse == '0')
+        m._load_batch(m.dataset, m.input_x, m.input_y)
+        m._run_fwd_bwd(); torch.cuda.synchronize()
+        res.append((m.last_loss(), m.store.g.clone()))
+    assert abs(res[0][0] - res[1][0]) < 1e-6
+    assert float((res[0][1] - res[1][1]).abs().max()) < 2e-6 * float(res[1][1].abs().max())

@@ -440,6 +440,44 @@ def test_bilinear_up(dtype, f, Hs, Hd, add):
     U.sync()
     gref = ops.conv2d_transpose_dgrad(ops.crop_or_pad_bwd(gv, (Hs * f, Hs * f)), ops.bilinear_upsample_weights(f, Cc), (Hs, Hs), f, 'SAME')
     assert U.rel_err(U.read_act(dsa), gref) < U.tol(dtype, 1e-6, 1e-2)
+    # the separable form of the adjoint (horizontal pass into a float workspace, then vertical)
+    nb = int(lib.seg_bilinear_up_bwd_ws_bytes(B, Hd, Hs, sa.Cp))
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=U.dev())
+    dsa.t.fill_(3.0)
+    L.check(lib.seg_bilinear_up_bwd_sep(C.byref(g_v), Hd, Hd, cy, cy, f, ft.data_ptr(), C.byref(ds_v), Hs, Hs, B, sa.Cp, 0, ws.data_ptr(), nb, dtype, U.stream()))
+    U.sync()
+    assert U.rel_err(U.read_act(dsa), gref) < U.tol(dtype, 2e-6, 1e-2) and U.pad_channels_zero(dsa)
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('f,Hs,Hd,nc,keep', [(8, 4, 30, 21, True), (8, 5, 40, 3, False), (32, 2, 60, 2, True), (16, 3, 50, 11, False)])
+def test_bilinear_xent_fused_head(dtype, f, Hs, Hd, nc, keep):
+    """seg_bilinear_xent = seg_bilinear_up_fwd (float logits) + seg_softmax_xent, in one launch"""
+    B = 2
+    rng = np.random.default_rng(f * 7 + nc)
+    lib = L.load()
+    net = E.Net(None, B, dtype, U.dev())
+    sa = net.act(Hs, Hs, nc); sv = U.round_dtype(rng.standard_normal((B, Hs, Hs, nc)) * 2, dtype); U.fill_act(sa, sv)
+    filt = ops.upsample_filt(ops.get_kernel_size(f)).astype(np.float32)
+    ft = torch.from_numpy(filt).to(U.dev())
+    logits_ref = ops.crop_or_pad(ops.conv2d_transpose(sv, ops.bilinear_upsample_weights(f, nc), None, f, 'SAME'), Hd, Hd)
+    LH, LW, off = Hd + 3, Hd + 2, (2, 1)
+    y = rng.integers(0, nc, (B, LH, LW, 1)).astype(np.uint8)
+    yd = torch.from_numpy(y).to(U.dev())
+    loss_ref, _, d_ref = ops.softmax_xent(logits_ref, y[:, off[0]:off[0] + Hd, off[1]:off[1] + Hd])
+    cy = (Hs * f - Hd) // 2 if Hs * f >= Hd else -((Hd - Hs * f) // 2)
+    dl = net.act(Hd, Hd, nc); dl.t.fill_(0.0)
+    lo = net.act(Hd, Hd, nc, f32=True) if keep else None
+    loss = torch.zeros(1, device=U.dev())
+    s_v, d_v = sa.view(), dl.view()
+    l_v = lo.view() if keep else None
+    L.check(lib.seg_bilinear_xent(C.byref(s_v), Hs, Hs, f, ft.data_ptr(), cy, cy, yd.data_ptr(), LH, LW, off[0], off[1], B, Hd, Hd, nc,
+                                  1.0 / (B * Hd * Hd), 1.0, loss.data_ptr(), C.byref(d_v), C.byref(l_v) if keep else None, dtype, U.stream()))
+    U.sync()
+    assert abs(float(loss) - loss_ref) < (1e-5 if dtype == L.SEG_F32 else 1e-4) * max(1.0, abs(loss_ref))
+    assert np.abs(U.read_act(dl) - d_ref).max() < (1e-6 if dtype == L.SEG_F32 else 1e-2) * np.abs(d_ref).max() and U.pad_channels_zero(dl)
+    if keep:
+        assert np.abs(U.read_act(lo) - logits_ref).max() < 1e-5 * max(1.0, np.abs(logits_ref).max())
 
 
 def test_error_paths():
