@@ -69,16 +69,17 @@ __global__ void im2col3x3_kernel(const float* x, int B, int H, int W, int cin, i
   const int64_t total = (int64_t)B * Ho * Wo * 4;
   const int nk = 9 * cin;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int piece = i & 3; int64_t t = i >> 2;
-    const int ox = t % Wo; t /= Wo;
-    const int oy = t % Ho; const int b = t / Ho;
+    const int piece = i & 3;
+    int ox, oy, b;
+    if (i <= 0x7fffffff) { unsigned t = (unsigned)(i >> 2); ox = t % (unsigned)Wo; t /= (unsigned)Wo; oy = t % (unsigned)Ho; b = t / (unsigned)Ho; }   // (32-bit divisions)
+    else { int64_t t = i >> 2; ox = t % Wo; t /= Wo; oy = t % Ho; b = (int)(t / Ho); }
     Vec8<T> o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = piece * 8 + e;
       float v = 0.f;
       if (k < nk) {
-        const int tap = k / cin, c = k - tap * cin;
+        const int tap = cin == 3 ? k / 3 : k / cin, c = k - tap * cin;
         const int iy = oy - pad + tap / 3, ix = ox - pad + tap % 3;
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((int64_t)b * H + iy) * W + ix) * cin + c];
       }

@@ -29,6 +29,23 @@ SEG_DEV float wave_sum(float v) {
   return v;
 }
 
+// (b, y, x[, c8]) of a flat element index.  The element counts of this path fit 32 bits; 64-bit divisions by run-time extents
+// are ~100 instructions each and were a third of the byte-moving kernels' issue time.
+struct Idx3 { int x, y, b; };
+SEG_DEV Idx3 split3(int64_t i, int W, int H) {
+  Idx3 r;
+  if (i <= 0x7fffffff) { unsigned t = (unsigned)i; r.x = t % (unsigned)W; t /= (unsigned)W; r.y = t % (unsigned)H; r.b = t / (unsigned)H; }
+  else { int64_t t = i; r.x = t % W; t /= W; r.y = t % H; r.b = (int)(t / H); }
+  return r;
+}
+struct Idx4 { int c8, x, y, b; };
+SEG_DEV Idx4 split4(int64_t i, int C8, int W, int H) {
+  Idx4 r;
+  if (i <= 0x7fffffff) { unsigned t = (unsigned)i; r.c8 = t % (unsigned)C8; t /= (unsigned)C8; r.x = t % (unsigned)W; t /= (unsigned)W; r.y = t % (unsigned)H; r.b = t / (unsigned)H; }
+  else { int64_t t = i; r.c8 = t % C8; t /= C8; r.x = t % W; t /= W; r.y = t % H; r.b = (int)(t / H); }
+  return r;
+}
+
 inline int grid_for(int64_t n, int per_block = 256, int cap = 8192) {
   int64_t g = (n + per_block - 1) / per_block;
   if (g > cap) g = cap;
@@ -48,10 +65,8 @@ template <typename T>
 __global__ void maxpool_fwd_kernel(seg_view src, seg_view dst, uint8_t* idx, int B, int Ho, int Wo, int C8) {
   const int64_t total = (int64_t)B * Ho * Wo * C8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = i;
-    const int c8 = t % C8; t /= C8;
-    const int ox = t % Wo; t /= Wo;
-    const int oy = t % Ho; const int b = t / Ho;
+    const Idx4 q_ = split4(i, C8, Wo, Ho);
+    const int c8 = q_.c8, ox = q_.x, oy = q_.y, b = q_.b;
     const T* sp = reinterpret_cast<const T*>(src.ptr);
     Vec8<T> v[4];
 #pragma unroll
@@ -81,10 +96,8 @@ __global__ void maxpool_bwd_kernel(seg_view yact, seg_view dpool, seg_view add, 
   const int Hw = (H + 1) / 2, Ww = (W + 1) / 2, Ho = H / 2, Wo = W / 2;
   const int64_t total = (int64_t)B * Hw * Ww * C8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = i;
-    const int c8 = t % C8; t /= C8;
-    const int wx = t % Ww; t /= Ww;
-    const int wy = t % Hw; const int b = t / Hw;
+    const Idx4 q_ = split4(i, C8, Ww, Hw);
+    const int c8 = q_.c8, wx = q_.x, wy = q_.y, b = q_.b;
     const bool full = wy < Ho && wx < Wo;
     Vec8<T> y[4];
     bool ok[4];
@@ -136,10 +149,8 @@ template <typename T>
 __global__ void relu_grad_kernel(seg_view dy, seg_view yact, seg_view dz, int B, int H, int W, int C8) {
   const int64_t total = (int64_t)B * H * W * C8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = i;
-    const int c8 = t % C8; t /= C8;
-    const int x = t % W; t /= W;
-    const int y = t % H; const int b = t / H;
+    const Idx4 q_ = split4(i, C8, W, H);
+    const int c8 = q_.c8, x = q_.x, y = q_.y, b = q_.b;
     Vec8<T> g, a, o;
     g.load(reinterpret_cast<const T*>(dy.ptr) + view_off(dy, b, y, x) + c8 * 8);
     a.load(reinterpret_cast<const T*>(yact.ptr) + view_off(yact, b, y, x) + c8 * 8);
@@ -180,10 +191,8 @@ __global__ void dropout_kernel(seg_view xin, seg_view yout, int B, int H, int W,
   const uint32_t thr = (uint32_t)(keep * 4294967295.0);
   const uint64_t key = splitmix64(seed);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = i;
-    const int c8 = t % C8; t /= C8;
-    const int x = t % W; t /= W;
-    const int y = t % H; const int b = t / H;
+    const Idx4 q_ = split4(i, C8, W, H);
+    const int c8 = q_.c8, x = q_.x, y = q_.y, b = q_.b;
     Vec8<T> v, o;
     v.load(reinterpret_cast<const T*>(xin.ptr) + view_off(xin, b, y, x) + c8 * 8);
 #pragma unroll
@@ -204,9 +213,8 @@ __global__ void softmax_xent_kernel(seg_view lg, const uint8_t* labels, int LH, 
   const int64_t total = (int64_t)B * H * W;
   float local = 0.f;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = i;
-    const int x = t % W; t /= W;
-    const int y = t % H; const int b = t / H;
+    const Idx3 q_ = split3(i, W, H);
+    const int x = q_.x, y = q_.y, b = q_.b;
     const float* z = reinterpret_cast<const float*>(lg.ptr) + view_off(lg, b, y, x);
     const int lab = labels[((int64_t)b * LH + y + ly0) * LW + x + lx0];
     float zv[NCP];
@@ -267,9 +275,8 @@ __global__ __launch_bounds__(256) void head_xent_kernel(seg_view act, const floa
   const int64_t total = (int64_t)B * H * W;
   float local = 0.f;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = i;
-    const int x = t % W; t /= W;
-    const int y = t % H; const int b = t / H;
+    const Idx3 q_ = split3(i, W, H);
+    const int x = q_.x, y = q_.y, b = q_.b;
     const T* ap = reinterpret_cast<const T*>(act.ptr) + view_off(act, b, y, x);
     float a[CINP];
 #pragma unroll
@@ -339,9 +346,8 @@ __global__ __launch_bounds__(256) void head_xent_kernel(seg_view act, const floa
 __global__ void sigmoid_argmax_kernel(seg_view lg, int B, int H, int W, int nc, float* sig, float* out) {
   const int64_t total = (int64_t)B * H * W;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = i;
-    const int x = t % W; t /= W;
-    const int y = t % H; const int b = t / H;
+    const Idx3 q_ = split3(i, W, H);
+    const int x = q_.x, y = q_.y, b = q_.b;
     const float* z = reinterpret_cast<const float*>(lg.ptr) + view_off(lg, b, y, x);
     float best = -1.f; int bi = 0;
     for (int c = 0; c < nc; ++c) {
@@ -652,10 +658,8 @@ __global__ void bilinear_fwd_kernel(seg_view src, int Hs, int Ws, int f, const f
   const int k = 2 * f - f % 2, pb = (k - f) / 2;
   const int64_t total = (int64_t)B * Hd * Wd * C8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = i;
-    const int c8 = t % C8; t /= C8;
-    const int x = t % Wd; t /= Wd;
-    const int y = t % Hd; const int b = t / Hd;
+    const Idx4 q_ = split4(i, C8, Wd, Hd);
+    const int c8 = q_.c8, x = q_.x, y = q_.y, b = q_.b;
     float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int Y = y + cy, X = x + cx;
     if (Y >= 0 && Y < Hs * f && X >= 0 && X < Ws * f) {
@@ -814,10 +818,8 @@ __global__ void bilinear_bwd_h_kernel(seg_view dd, int Hd, int Wd, int cx, int f
   const float nrm = rsqrtf(filt[c0 * k + c0]);
   const int64_t total = (int64_t)B * Hd * Ws * C8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = i;
-    const int c8 = t % C8; t /= C8;
-    const int ix = t % Ws; t /= Ws;
-    const int y = t % Hd; const int b = t / Hd;
+    const Idx4 q_ = split4(i, C8, Ws, Hd);
+    const int c8 = q_.c8, ix = q_.x, y = q_.y, b = q_.b;
     float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int v = 0; v < k; ++v) {
       const int X = ix * f + v - pb, x = X - cx;
@@ -838,10 +840,8 @@ __global__ void bilinear_bwd_v_kernel(const float* tmp, int Hd, int cy, int f, c
   const float nrm = rsqrtf(filt[c0 * k + c0]);
   const int64_t total = (int64_t)B * Hs * Ws * C8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = i;
-    const int c8 = t % C8; t /= C8;
-    const int ix = t % Ws; t /= Ws;
-    const int iy = t % Hs; const int b = t / Hs;
+    const Idx4 q_ = split4(i, C8, Ws, Hs);
+    const int c8 = q_.c8, ix = q_.x, iy = q_.y, b = q_.b;
     float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int u = 0; u < k; ++u) {
       const int Y = iy * f + u - pb, y = Y - cy;
