@@ -268,7 +268,7 @@ class Plan(object):
         main_epoch, forked_at = 0, {}             # launches on the main stream so far; per side stream: the count at its last fork
         capturing = torch.cuda.is_current_stream_capturing()
         dirty = set()                             # side streams with launches the main stream has not waited for yet
-        sig = _signal_state(main) if (_SIGNAL_ON and not capturing) else None
+        sig = _signal_state(main) if (_SIGNAL_ON and not capturing and not _SIGNALS.get('off')) else None
         sig_at = {}                               # op index of a main-stream convolution -> the number it has to announce
         held = {}                                 # side stream id -> (op index it waits for, [(name, fn, args)] to launch behind it)
         by_id = {id(o_): o_ for o_ in side}
@@ -364,7 +364,10 @@ class Plan(object):
                             continue
                         st_ = by_id[sid_]
                         if sig['hip'].hipStreamWaitValue32(C.c_void_p(st_.cuda_stream), C.c_void_p(sig['flag'].data_ptr()), v, 0, 0xffffffff) != 0:   # 0 = >=
-                            raise L.SegError('hipStreamWaitValue32 failed')
+                            # (a runtime without stream memory operations: an event recorded now orders the held launches just as
+                            # well -- op i is already on the main stream -- and later forks of this process use events)
+                            _SIGNALS['off'] = True
+                            fork(main, st_)
                         for nm_, f_, a_ in lst:
                             r_ = f_(*a_, C.c_void_p(st_.cuda_stream))
                             if r_ != 0:
