@@ -170,7 +170,7 @@ def cpu_baseline(args):
                       % (n, what, bs, args.size, args.size, args.classes, ', loss and TF-Adam' if args.mode == 'train' else '')}
 
 
-def roofline_report(agg, ops, reps, dtype, total_steps_ms):
+def roofline_report(agg, ops, reps, dtype, total_steps_ms, pmc_tag=None):
     """roofline of the dominant kernel instance + the per-layer table (every launch that does arithmetic)."""
     peak = BF16_DENSE_PEAK_TFLOPS if dtype == 'bf16' else F32_MFMA_PEAK_TFLOPS
     fam = {}
@@ -185,12 +185,15 @@ def roofline_report(agg, ops, reps, dtype, total_steps_ms):
     avg_ms = a['ms'] / a['launches']
     ach = a['flops'] / a['launches'] / (avg_ms * 1e-3) / 1e12
     traffic, tsrc = None, None
-    pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
-    if os.path.exists(pmc):
+    # HBM bytes per launch come from the committed rocprofv3 --pmc passes OF THIS WORKLOAD (tools/collect_profiles.sh); a workload
+    # without a committed counter file reports null rather than another workload's number
+    pmc_file = 'pmc_summary.json' if pmc_tag == '' else ('r02_%s_pmc_summary.json' % pmc_tag if pmc_tag else None)
+    pmc = os.path.join(ROOT, 'profiles', pmc_file) if pmc_file else None
+    if pmc and os.path.exists(pmc):
         try:
             j = json.load(open(pmc))
             traffic = j.get(name, {}).get('hbm_bytes_per_launch')
-            tsrc = 'profiles/pmc_summary.json@%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)' % j.get('_commit', 'r01')
+            tsrc = 'profiles/%s@%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)' % (pmc_file, j.get('_commit', 'r01'))
         except Exception:
             traffic = None
     total_ms = sum(v['ms'] for v in agg.values())
@@ -391,7 +394,16 @@ def main():
                 ent[5].value = 1 << 40
                 return ent[0].run_profiled(stream, torch, None) + ent[1].run_profiled(stream, torch, None)
         agg, ops, reps = kernel_table(run)
-        out['roofline'] = roofline_report(agg, ops, reps, args.dtype, dt / args.steps * 1e3)
+        # which committed counter file describes this command line ('' = the headline)
+        tag = None
+        if args.mode == 'train' and not args.adversarial and args.dtype == 'bf16' and args.nk == 32 and not args.host_data:
+            if args.model == 'unet' and args.classes == 4 and args.batch == 16:
+                tag = '' if args.size == 256 else ('c4' if args.size == 512 else None)
+            elif args.model == 'fcn8s' and (args.size, args.classes, args.batch) == (512, 21, 8):
+                tag = 'c3'
+        elif args.mode == 'mc' and args.model == 'unet' and (args.size, args.batch, args.classes) == (256, 32, 4):
+            tag = 'c5'
+        out['roofline'] = roofline_report(agg, ops, reps, args.dtype, dt / args.steps * 1e3, pmc_tag=tag)
         if args.per_op:
             for op, kern, ms_, fl, by in ops:
                 sys.stderr.write('%-16s %-52s %9.2f us %8.1f TF/s %8.1f GB/s\n' % (op, kern, ms_ * 1e3, fl / (ms_ * 1e-3) / 1e12 if fl else 0, by / (ms_ * 1e-3) / 1e9 if by else 0))
