@@ -50,6 +50,11 @@ class BaseModel(object):
         self.autoencoder = autoencoder
         self.learning_rate = learning_rate
         self.input_channel = input_channel
+        # limits of the device path, refused HERE (the constructor is the boundary), not somewhere inside a plan build
+        if not 1 <= int(input_channel) <= 3:
+            raise Exception('input_channel must be 1..3: the first layer reads the raw image (its filter gradient gathers 9*C <= 32 columns)')
+        if n_classes is not None and not 1 <= int(n_classes) <= 32:
+            raise Exception('n_classes must be 1..32 (one 32-channel block of logits per pixel)')
         self.adversarial_training = adversarial_training
         # adversarial training (models/basemodel.py:215-355; broken at HEAD in the reference, SURVEY F9: rebuilt to its intended
         # construction, segmentation_amd/adversary.py).  `adversarial_lr` is read but never set by the reference's seg models.

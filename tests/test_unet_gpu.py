@@ -209,3 +209,14 @@ def test_unet_ragged_shapes_f32(B, H, W, cin, nk, nc):
 def test_unet_rejects_non_square_like_the_reference():
     with pytest.raises(Exception):
         UNetModel(sess=None, dataset=SyntheticDataSet(1, 188, 2), n_classes=2, input_dims=[188, 220], save_dir=None, load_snapshot=False)
+
+
+def test_limits_are_refused_at_the_constructor():
+    """n_classes > 32 and input_channel > 3 are limits of the device path: the model constructors say so, no plan is built"""
+    x = np.zeros((1, 2, 188, 188, 3), np.float32); y = np.zeros((1, 2, 188, 188, 1), np.uint8)
+    from segmentation_amd.fcn import FCNModel
+    for cls in (UNetModel, FCNModel):
+        with pytest.raises(Exception, match='n_classes must be 1..32'):
+            cls(sess=None, dataset=ArrayDataSet(x, y), n_classes=33, input_dims=188, log_dir=None, save_dir=None, load_snapshot=False)
+        with pytest.raises(Exception, match='input_channel must be 1..3'):
+            cls(sess=None, dataset=ArrayDataSet(x, y), n_classes=2, input_dims=188, input_channel=4, log_dir=None, save_dir=None, load_snapshot=False)
