@@ -169,12 +169,18 @@ int seg_softmax_xent(const seg_view* logits, const uint8_t* labels, int32_t LH, 
 
 /* Fused U-Net training head: the 1x1 'output' convolution (models/unet.py:166; float32 logits), the per-pixel softmax
  * cross-entropy + gradient above, and the 1x1 convolution's input gradient masked by its input's ReLU (dact), in one
- * pass.  act: the conv's input (32 or 64 padded channels, `cin` logical); w_hwio: its fp32 filter [cin][n_classes];
- * dlogits feeds the filter gradient (seg_conv2d_wgrad) exactly as after seg_softmax_xent. */
+ * pass.  act: the conv's input (32 or 64 padded channels, `cin` logical); w_hwio: its fp32 filter [cin][n_classes].
+ * dw_ws == NULL: dlogits is written and feeds the filter gradient (seg_conv2d_wgrad) exactly as after seg_softmax_xent.
+ * dw_ws != NULL (n_classes <= 8; seg_head_xent_ws_bytes of device memory): the filter and bias gradients of the 1x1
+ * convolution are accumulated in the same pass as per-workgroup partial sums, dlogits is not written (its view may
+ * carry a NULL ptr), and seg_head_dw_reduce -- same shape arguments -- finishes them into dw [cin][n_classes] / db. */
+int64_t seg_head_xent_ws_bytes(int32_t B, int32_t H, int32_t W, int32_t cin_pad, int32_t n_classes);   /* 0: not covered */
 int seg_head_xent(const seg_view* act, const float* w_hwio, const float* bias, int32_t cin, const uint8_t* labels,
                   int32_t LH, int32_t LW, int32_t ly0, int32_t lx0, int32_t B, int32_t H, int32_t W, int32_t n_classes,
                   float inv_n, float* loss_sum, const seg_view* logits, const seg_view* dlogits, const seg_view* dact,
-                  int32_t dtype, void* stream);
+                  void* dw_ws, int64_t dw_ws_bytes, int32_t dtype, void* stream);
+int seg_head_dw_reduce(const void* dw_ws, int64_t dw_ws_bytes, int32_t B, int32_t H, int32_t W, int32_t cin_pad,
+                       int32_t cin, int32_t n_classes, float* dw, float* db, void* stream);
 
 /* tf.nn.sigmoid + tf.argmax(axis=3) + expand_dims + cast: models/unet.py:75-79, models/fcn.py:74-78.
  * sig: dense float32 [B,H,W,n_classes]; out: dense float32 [B,H,W,1]; argmax taken over the float32

@@ -73,7 +73,8 @@ SIGNATURES = {
     'seg_maxpool2x2_fwd': [PV, PV, vp, i32, i32, i32, i32, i32, vp],
     'seg_maxpool2x2_bwd': [PV, PV, PV, i32, i32, i32, i32, PV, i32, i32, i32, i32, i32, vp],
     'seg_softmax_xent': [PV, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, PV, i32, vp],
-    'seg_head_xent': [PV, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, PV, PV, PV, i32, vp],
+    'seg_head_xent': [PV, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, PV, PV, PV, vp, i64, i32, vp],
+    'seg_head_dw_reduce': [vp, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     'seg_sigmoid_argmax': [PV, i32, i32, i32, i32, vp, vp, vp],
     'seg_bias_grad': [PV, i32, i32, i32, i32, vp, i32, vp],
     'seg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp],
@@ -137,6 +138,8 @@ def load():
     lib.seg_bn_ws_bytes.argtypes = [C.c_int32]
     lib.seg_dconv_wgrad_ws_bytes.restype = C.c_int64
     lib.seg_dconv_wgrad_ws_bytes.argtypes = [C.POINTER(DconvDesc)]
+    lib.seg_head_xent_ws_bytes.restype = C.c_int64
+    lib.seg_head_xent_ws_bytes.argtypes = [C.c_int32] * 5
     lib.seg_bilinear_up_bwd_ws_bytes.restype = C.c_int64
     lib.seg_bilinear_up_bwd_ws_bytes.argtypes = [C.c_int32] * 4
     _lib = lib

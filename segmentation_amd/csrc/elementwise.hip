@@ -260,42 +260,81 @@ __global__ void softmax_xent_kernel(seg_view lg, const uint8_t* labels, int LH, 
 
 // ------------------------------------------------------------------------------------------
 // Fused segmentation head of the U-Net train step: 1x1 'output' conv (logits) + softmax cross-entropy + the 1x1 conv's
-// input gradient (with the ReLU-grad mask of its input), one thread per pixel -- three launches of ~6 us each on the
-// critical path become one.  w is the fp32 HWIO filter [cin][nc] (models/unet.py:166,171-174, basemodel.py:59-70).
+// input gradient (with the ReLU-grad mask of its input) -- three launches of ~6 us each on the critical path become
+// one.  CINP/8 lanes share a pixel: lane j holds input channels [8j, 8j+8), so a wave's loads and stores of the
+// activation, its gradient and dlogits are contiguous 16-byte pieces; the class sums are completed with a butterfly
+// over those lanes.  w is the fp32 HWIO filter [cin][nc] (models/unet.py:166,171-174, basemodel.py:59-70).
 // ------------------------------------------------------------------------------------------
-template <typename T, int NCP, int CINP>
+//
+// DW: the 1x1 conv's filter and bias gradients are accumulated here as well -- lane j keeps the 8 x NCP products of its
+// channels with the class gradients -- and leave as one row of partial sums per workgroup ([CINP*NCP] dW then [NCP] db,
+// summed in a fixed order by head_dw_reduce_kernel).  dlogits is then not written at all: it had no other reader, and at
+// 32 padded channels it was as large as the activation gradient.
+template <typename T, int NCP, int CINP, bool DW>
 __global__ __launch_bounds__(256) void head_xent_kernel(seg_view act, const float* w, const float* bias, int cin, const uint8_t* labels,
                                                         int LH, int LW, int ly0, int lx0, int B, int H, int W, int nc, float inv_n,
-                                                        float* loss_sum, seg_view lg, seg_view dl, seg_view dact) {
+                                                        float* loss_sum, seg_view lg, seg_view dl, seg_view dact, float* dw_part) {
+  constexpr int LP = CINP / 8;              // lanes per pixel
+  constexpr bool WREG = false;              // true: the lane's 8 x NCP filter slice in registers (no faster, 50 VGPRs more)
   __shared__ float sw[CINP * NCP];
   __shared__ float sb[NCP];
   for (int i = threadIdx.x; i < CINP * NCP; i += 256) { const int k = i / NCP, c = i % NCP; sw[i] = (k < cin && c < nc) ? w[(int64_t)k * nc + c] : 0.f; }
   if (threadIdx.x < NCP) sb[threadIdx.x] = (bias && (int)threadIdx.x < nc) ? bias[threadIdx.x] : 0.f;
   __syncthreads();
-  const int64_t total = (int64_t)B * H * W;
+  const int j = threadIdx.x % LP;
+  const float* swj = sw + j * 8 * NCP;
+  float wr[WREG ? 8 * NCP : 1];
+  if constexpr (WREG) {
+#pragma unroll
+    for (int i = 0; i < 8 * NCP; ++i) wr[i] = swj[i];
+  }
+  auto wgt = [&](int e, int c) -> float { if constexpr (WREG) return wr[e * NCP + c]; else return swj[e * NCP + c]; };
+  const int total = B * H * W;              // < 2^31 pixels (checked by the host)
+  constexpr int PPB = 256 / LP;
+  const int stride = gridDim.x * PPB;
   float local = 0.f;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const Idx3 q_ = split3(i, W, H);
-    const int x = q_.x, y = q_.y, b = q_.b;
-    const T* ap = reinterpret_cast<const T*>(act.ptr) + view_off(act, b, y, x);
-    float a[CINP];
+  // one 16-byte load per lane and pixel is too little in flight to cover the HBM latency: the next pixel's activation
+  // and label are requested before this pixel's arithmetic starts
+  float dwa[DW ? 8 * NCP : 1], dba[DW ? NCP : 1];
+  if constexpr (DW) {
 #pragma unroll
-    for (int k8 = 0; k8 < CINP / 8; ++k8) {
-      Vec8<T> v; v.load(ap + k8 * 8);
+    for (int t = 0; t < 8 * NCP; ++t) dwa[t] = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a[k8 * 8 + e] = v.get(e);
-    }
+    for (int c = 0; c < NCP; ++c) dba[c] = 0.f;
+  }
+  Vec8<T> v_next; int lab_next = 0; Idx3 q_next = {0, 0, 0};
+  auto request = [&](int i) {
+    q_next = split3(i, W, H);
+    v_next.load(reinterpret_cast<const T*>(act.ptr) + view_off(act, q_next.b, q_next.y, q_next.x) + j * 8);
+    lab_next = labels[((int64_t)q_next.b * LH + q_next.y + ly0) * LW + q_next.x + lx0];
+  };
+  int i = blockIdx.x * PPB + threadIdx.x / LP;
+  if (i < total) request(i);
+  for (; i < total; i += stride) {
+    if constexpr (!WREG) asm volatile("" ::: "memory");     // keep the filter in LDS: hoisted out of the loop it would not fit the registers
+    const Vec8<T> v = v_next;
+    const int lab = lab_next;
+    const int x = q_next.x, y = q_next.y, b = q_next.b;
+    if (i + stride < total) request(i + stride);
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = v.get(e);
     float zv[NCP];
 #pragma unroll
-    for (int c = 0; c < NCP; ++c) zv[c] = sb[c];
+    for (int c = 0; c < NCP; ++c) zv[c] = 0.f;
 #pragma unroll
-    for (int k = 0; k < CINP; ++k)
+    for (int e = 0; e < 8; ++e)
 #pragma unroll
-      for (int c = 0; c < NCP; ++c) zv[c] = fmaf(a[k], sw[k * NCP + c], zv[c]);
+      for (int c = 0; c < NCP; ++c) zv[c] = fmaf(a[e], wgt(e, c), zv[c]);
+#pragma unroll
+    for (int c = 0; c < NCP; ++c) {
+#pragma unroll
+      for (int m_ = 1; m_ < LP; m_ <<= 1) zv[c] += __shfl_xor(zv[c], m_);
+      zv[c] += sb[c];
+    }
     float* zo = reinterpret_cast<float*>(lg.ptr) + view_off(lg, b, y, x);
 #pragma unroll
-    for (int c = 0; c < NCP; ++c) if (c < nc) zo[c] = zv[c];
-    const int lab = labels[((int64_t)b * LH + y + ly0) * LW + x + lx0];
+    for (int c = 0; c < NCP; ++c) if (c % LP == j && c < nc) zo[c] = zv[c];
     float m = -INFINITY;
 #pragma unroll
     for (int c = 0; c < NCP; ++c) { if (c >= nc) zv[c] = -INFINITY; m = fmaxf(m, zv[c]); }
@@ -303,44 +342,98 @@ __global__ __launch_bounds__(256) void head_xent_kernel(seg_view act, const floa
     float zl = 0.f, s_ = 0.f;
 #pragma unroll
     for (int c = 0; c < NCP; ++c) { if (c == lab) zl = zv[c]; zv[c] = c < nc ? expf(zv[c] - m) : 0.f; s_ += zv[c]; }
-    if (valid) local += (logf(s_) - (zl - m));
+    if (valid && j == 0) local += (logf(s_) - (zl - m));
     const float rs = 1.f / s_;
     float g[NCP];
 #pragma unroll
     for (int c = 0; c < NCP; ++c) g[c] = (c < nc && valid) ? (zv[c] * rs - (c == lab ? 1.f : 0.f)) * inv_n : 0.f;
-    T* o = reinterpret_cast<T*>(dl.ptr) + view_off(dl, b, y, x);
-#pragma unroll
-    for (int c8 = 0; c8 < 4; ++c8) {
-      if (c8 * 8 >= dl.c) break;
+    // lane j writes channel group j of dlogits (real classes first, zero padding behind them)
+    if (dl.ptr != nullptr && j * 8 < dl.c) {
+      T* o = reinterpret_cast<T*>(dl.ptr) + view_off(dl, b, y, x) + j * 8;
       Vec8<T> ov;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const int c = c8 * 8 + e; ov.set(e, c < NCP ? g[c < NCP ? c : 0] : 0.f); }
-      ov.store(o + c8 * 8);
+      for (int e = 0; e < 8; ++e) {
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) if (c == j * 8 + e) v = g[c];
+        ov.set(e, v);
+      }
+      ov.store(o);
     }
     // gradient of the 1x1 conv's input, masked by that input's ReLU.  dlogits is what the filter gradient reads, so the
     // same (dtype-rounded) values are used here as the separate dgrad launch would see.
 #pragma unroll
     for (int c = 0; c < NCP; ++c) { Vec8<T> r; r.set(0, g[c]); g[c] = r.get(0); }
-    T* da = reinterpret_cast<T*>(dact.ptr) + view_off(dact, b, y, x);
+    if constexpr (DW) {
 #pragma unroll
-    for (int k8 = 0; k8 < CINP / 8; ++k8) {
-      Vec8<T> ov;
+      for (int e = 0; e < 8; ++e)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = k8 * 8 + e;
-        float acc = 0.f;
+        for (int c = 0; c < NCP; ++c) dwa[e * NCP + c] = fmaf(a[e], g[c], dwa[e * NCP + c]);
 #pragma unroll
-        for (int c = 0; c < NCP; ++c) acc = fmaf(g[c], sw[k * NCP + c], acc);
-        ov.set(e, a[k] > 0.f ? acc : 0.f);
-      }
-      ov.store(da + k8 * 8);
+      for (int c = 0; c < NCP; ++c) dba[c] += g[c];
     }
+    T* da = reinterpret_cast<T*>(dact.ptr) + view_off(dact, b, y, x) + j * 8;
+    Vec8<T> ov;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCP; ++c) acc = fmaf(g[c], wgt(e, c), acc);
+      ov.set(e, a[e] > 0.f ? acc : 0.f);
+    }
+    ov.store(da);
   }
   __shared__ float wsum[4];
   local = wave_sum(local);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = local;
-  __syncthreads();
+  if constexpr (DW) {
+    // lanes with the same j across the wave, then the four waves through LDS, then one row of the workspace
+    constexpr int ROW = CINP * NCP + NCP;
+    __shared__ float part[4][ROW];
+#pragma unroll
+    for (int t = 0; t < 8 * NCP; ++t)
+#pragma unroll
+      for (int m_ = LP; m_ < 64; m_ <<= 1) dwa[t] += __shfl_xor(dwa[t], m_);
+#pragma unroll
+    for (int c = 0; c < NCP; ++c)
+#pragma unroll
+      for (int m_ = LP; m_ < 64; m_ <<= 1) dba[c] += __shfl_xor(dba[c], m_);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane < LP) {
+#pragma unroll
+      for (int t = 0; t < 8 * NCP; ++t) part[wv][lane * 8 * NCP + t] = dwa[t];
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) part[wv][CINP * NCP + c] = dba[c];
+      }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ROW; t += 256)
+      dw_part[(int64_t)blockIdx.x * ROW + t] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+  } else {
+    __syncthreads();
+  }
   if (threadIdx.x == 0) atomicAdd(loss_sum, (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_n);
+}
+
+// Sums the workgroup rows of head_xent_kernel<.., DW> in row order (one workgroup per output element) into the fp32 HWIO
+// filter gradient [cin][nc] and the bias gradient [nc].
+__global__ __launch_bounds__(256) void head_dw_reduce_kernel(const float* __restrict__ part, int rows, int ncp, int cinp, int cin, int nc,
+                                                             float* __restrict__ dw, float* __restrict__ db) {
+  const int o = blockIdx.x, row = cinp * ncp + ncp;
+  float s = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 256) s += part[(int64_t)r * row + o];
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (o < cinp * ncp) { const int k = o / ncp, c = o % ncp; if (k < cin && c < nc) dw[k * nc + c] = red[0]; }
+    else { const int c = o - cinp * ncp; if (c < nc && db) db[c] = red[0]; }
+  }
 }
 
 __global__ void sigmoid_argmax_kernel(seg_view lg, int B, int H, int W, int nc, float* sig, float* out) {
@@ -971,24 +1064,67 @@ extern "C" int seg_softmax_xent(const seg_view* logits, const uint8_t* labels, i
   return seg_check_launch("softmax_xent");
 }
 
+// Workgroups of a seg_head_xent launch (its grid is a function of the shape only, so the partial-sum workspace can be sized
+// and reduced without the launch being replayed).
+static int head_xent_grid(int64_t B, int64_t H, int64_t W, int cpad) {
+  static const int cap_ = getenv("SEG_HEAD_CAP") ? atoi(getenv("SEG_HEAD_CAP")) : 2048;
+  static const int it_ = getenv("SEG_HEAD_ITERS") ? atoi(getenv("SEG_HEAD_ITERS")) : 4;
+  const int64_t px_per_wg = 256 / (cpad / 8) * (int64_t)(it_ > 0 ? it_ : 1);
+  return grid_for(B * H * W, (int)px_per_wg, cap_ > 0 ? cap_ : 2048);
+}
+static int head_ncp(int n_classes) { return n_classes <= 4 ? 4 : n_classes <= 8 ? 8 : n_classes <= 16 ? 16 : 32; }
+
+extern "C" int64_t seg_head_xent_ws_bytes(int32_t B, int32_t H, int32_t W, int32_t cin_pad, int32_t n_classes) {
+  if (n_classes < 1 || n_classes > 8 || (cin_pad != 32 && cin_pad != 64) || B < 1 || H < 1 || W < 1) return 0;   // fused filter gradient: <= 8 classes
+  const int ncp = head_ncp(n_classes);
+  return (int64_t)head_xent_grid(B, H, W, cin_pad) * (cin_pad * ncp + ncp) * (int64_t)sizeof(float);
+}
+
 extern "C" int seg_head_xent(const seg_view* act, const float* w_hwio, const float* bias, int32_t cin, const uint8_t* labels, int32_t LH, int32_t LW,
                              int32_t ly0, int32_t lx0, int32_t B, int32_t H, int32_t W, int32_t n_classes, float inv_n, float* loss_sum,
-                             const seg_view* logits, const seg_view* dlogits, const seg_view* dact, int32_t dtype, void* stream) {
-  if (!act || !act->ptr || !w_hwio || !labels || !loss_sum || !logits || !logits->ptr || !view_ok(dlogits, H, W, dlogits ? dlogits->c : 0) ||
+                             const seg_view* logits, const seg_view* dlogits, const seg_view* dact, void* dw_ws, int64_t dw_ws_bytes,
+                             int32_t dtype, void* stream) {
+  if (!act || !act->ptr || !w_hwio || !labels || !loss_sum || !logits || !logits->ptr || !dlogits ||
       !view_ok(dact, H, W, dact ? dact->c : 0) || !view_ok(act, H, W, act->c)) { seg_set_error("head_xent: bad args"); return SEG_ERR_ARG; }
-  if (n_classes < 1 || n_classes > 32 || n_classes > dlogits->c || dlogits->c % 8 || dlogits->c > 32 || n_classes > logits->cs) { seg_set_error("head_xent: n_classes %d unsupported (1..32)", n_classes); return SEG_ERR_UNSUPPORTED; }
+  const bool fused_dw = dw_ws != nullptr;
+  if (!fused_dw && !view_ok(dlogits, H, W, dlogits->c)) { seg_set_error("head_xent: dlogits is required when the filter gradient is not fused"); return SEG_ERR_ARG; }
+  if (dlogits->ptr && !view_ok(dlogits, H, W, dlogits->c)) { seg_set_error("head_xent: bad dlogits view"); return SEG_ERR_ARG; }
+  if (n_classes < 1 || n_classes > 32 || n_classes > logits->cs || (dlogits->ptr && (n_classes > dlogits->c || dlogits->c % 8 || dlogits->c > 32))) {
+    seg_set_error("head_xent: n_classes %d unsupported (1..32)", n_classes); return SEG_ERR_UNSUPPORTED; }
   if ((act->c != 32 && act->c != 64) || dact->c != act->c || cin < 1 || cin > act->c) { seg_set_error("head_xent: input channels %d unsupported (32 or 64 padded)", act->c); return SEG_ERR_UNSUPPORTED; }
   if (ly0 < 0 || lx0 < 0 || ly0 + H > LH || lx0 + W > LW) { seg_set_error("head_xent: label window out of range"); return SEG_ERR_ARG; }
   const int64_t n = (int64_t)B * H * W;
-  const int g = grid_for(n, 256, 512);
-#define HEAD_ARGS dim3(g), dim3(256), 0, ST(stream), *act, w_hwio, bias, cin, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, loss_sum, *logits, *dlogits, *dact
-#define HEAD_C(TT, NCP) do { if (act->c == 32) SEG_LAUNCH((head_xent_kernel<TT, NCP, 32>), HEAD_ARGS); else SEG_LAUNCH((head_xent_kernel<TT, NCP, 64>), HEAD_ARGS); } while (0)
-#define HEAD_NCP(TT) do { if (n_classes <= 4) HEAD_C(TT, 4); else if (n_classes <= 8) HEAD_C(TT, 8); else if (n_classes <= 16) HEAD_C(TT, 16); else HEAD_C(TT, 32); } while (0)
+  if (n >= (int64_t)1 << 31) { seg_set_error("head_xent: %lld pixels exceed the 32-bit index range", (long long)n); return SEG_ERR_UNSUPPORTED; }
+  if (fused_dw) {
+    const int64_t need = seg_head_xent_ws_bytes(B, H, W, act->c, n_classes);
+    if (need == 0) { seg_set_error("head_xent: the fused filter gradient covers 1..8 classes (got %d)", n_classes); return SEG_ERR_UNSUPPORTED; }
+    if (dw_ws_bytes < need) { seg_set_error("head_xent: workspace of %lld bytes, %lld needed", (long long)dw_ws_bytes, (long long)need); return SEG_ERR_ARG; }
+  }
+  const int g = head_xent_grid(B, H, W, act->c);
+  seg_view dlv = *dlogits;
+  if (fused_dw) dlv.ptr = nullptr;
+  float* part = reinterpret_cast<float*>(dw_ws);
+#define HEAD_ARGS dim3(g), dim3(256), 0, ST(stream), *act, w_hwio, bias, cin, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, loss_sum, *logits, dlv, *dact, part
+#define HEAD_C(TT, NCP, DW) do { if (act->c == 32) SEG_LAUNCH((head_xent_kernel<TT, NCP, 32, DW>), HEAD_ARGS); else SEG_LAUNCH((head_xent_kernel<TT, NCP, 64, DW>), HEAD_ARGS); } while (0)
+#define HEAD_NCP(TT) do { if (fused_dw) { if (n_classes <= 4) HEAD_C(TT, 4, true); else HEAD_C(TT, 8, true); } \
+    else if (n_classes <= 4) HEAD_C(TT, 4, false); else if (n_classes <= 8) HEAD_C(TT, 8, false); else if (n_classes <= 16) HEAD_C(TT, 16, false); else HEAD_C(TT, 32, false); } while (0)
   DISPATCH(dtype, HEAD_NCP(float), HEAD_NCP(bf16_t));
 #undef HEAD_NCP
 #undef HEAD_C
 #undef HEAD_ARGS
   return seg_check_launch("head_xent");
+}
+
+// The second half of the fused filter gradient: workspace rows -> dw [cin][n_classes] (fp32 HWIO) and db [n_classes].  Same
+// shape arguments as the seg_head_xent launch that filled the workspace.
+extern "C" int seg_head_dw_reduce(const void* dw_ws, int64_t dw_ws_bytes, int32_t B, int32_t H, int32_t W, int32_t cin_pad, int32_t cin,
+                                  int32_t n_classes, float* dw, float* db, void* stream) {
+  const int64_t need = seg_head_xent_ws_bytes(B, H, W, cin_pad, n_classes);
+  if (!dw_ws || !dw || need == 0 || dw_ws_bytes < need || cin < 1 || cin > cin_pad) { seg_set_error("head_dw_reduce: bad args"); return SEG_ERR_ARG; }
+  const int ncp = head_ncp(n_classes), rows = head_xent_grid(B, H, W, cin_pad);
+  SEG_LAUNCH(head_dw_reduce_kernel, dim3(cin_pad * ncp + ncp), dim3(256), 0, ST(stream), reinterpret_cast<const float*>(dw_ws), rows, ncp, cin_pad, cin,
+             n_classes, dw, db);
+  return seg_check_launch("head_dw_reduce");
 }
 
 extern "C" int seg_sigmoid_argmax(const seg_view* logits, int32_t B, int32_t H, int32_t W, int32_t n_classes, float* sig, float* out,

@@ -998,17 +998,38 @@ class Net(object):
         plan.add('xent', self.lib.seg_softmax_xent, C.byref(lv), labels_u8.data_ptr(), LH, LW, loff[0], loff[1], self.B, H, W,
                  n_classes, inv_n, 1.0, loss_buf.data_ptr(), C.byref(dv), self.dtype, kernel='softmax_xent_kernel')
 
-    def head_xent(self, plan, layer, act, labels_u8, LH, LW, loff, H, W, n_classes, loss_buf, logits, dlogits, dact):
-        """Fused 1x1 output conv + softmax x-entropy + the conv's masked input gradient (seg_head_xent)."""
+    def head_xent(self, plan, layer, act, labels_u8, LH, LW, loff, H, W, n_classes, loss_buf, logits, dlogits, dact, fuse_dw=True):
+        """Fused 1x1 output conv + softmax x-entropy + the conv's masked input gradient (seg_head_xent).  fuse_dw (<= 8
+        classes): the conv's filter / bias gradient is accumulated in the same pass and dlogits is not written; returns
+        the partial-sum workspace for head_dw_reduce (None when the filter gradient stays a separate launch)."""
         av, lv, dv, gv = act.view(), logits.view(), dlogits.view(), dact.view()
         plan.keep += [av, lv, dv, gv]
         inv_n = 1.0 / float(self.B * H * W)
         fl = 2 * 2 * self.B * H * W * layer.cin * layer.cout          # forward + input gradient
-        plan.add(layer.name + '+xent+dx', self.lib.seg_head_xent, C.byref(av), self.store.p_ptr(layer.w_off), self.store.p_ptr(layer.b_off),
+        by = self.B * H * W * (2 * layer.cin * self.es + n_classes * (4 + self.es) + 1)
+        ws, nbytes = None, int(self.lib.seg_head_xent_ws_bytes(self.B, H, W, act.Cp, n_classes)) if fuse_dw else 0
+        if nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            plan.keep.append(ws)
+            fl += 2 * self.B * H * W * layer.cin * layer.cout          # + filter gradient
+            by = self.B * H * W * (2 * layer.cin * self.es + n_classes * 4 + 1)
+        plan.add(layer.name + '+xent+dx' + ('+dw' if ws is not None else ''), self.lib.seg_head_xent, C.byref(av),
+                 self.store.p_ptr(layer.w_off), self.store.p_ptr(layer.b_off),
                  layer.cin, labels_u8.data_ptr(), LH, LW, loff[0], loff[1], self.B, H, W, n_classes, inv_n, loss_buf.data_ptr(),
-                 C.byref(lv), C.byref(dv), C.byref(gv), self.dtype, kernel='head_xent_kernel', flops=fl,
-                 bytes=self.B * H * W * (2 * layer.cin * self.es + n_classes * (4 + self.es) + 1))
+                 C.byref(lv), C.byref(dv), C.byref(gv), ws.data_ptr() if ws is not None else None, nbytes, self.dtype,
+                 kernel='head_xent_kernel', flops=fl, bytes=by)
         plan.flops += fl
+        return ws
+
+    def head_dw_reduce(self, plan, layer, ws, H, W, cin_pad, n_classes):
+        """Workspace rows of head_xent(fuse_dw) -> the output layer's filter and bias gradient; a side stream, like the
+        filter gradients it replaces."""
+        sid = 1 + self._wg_rr % self.n_wgrad_streams
+        self._wg_rr += 1
+        if not self.side_enabled:
+            sid = 0
+        plan.add(layer.name + '/dw', self.lib.seg_head_dw_reduce, ws.data_ptr(), ws.numel(), self.B, H, W, cin_pad, layer.cin, n_classes,
+                 self.store.g_ptr(layer.w_off), self.store.g_ptr(layer.b_off), kernel='head_dw_reduce_kernel', side=sid)
 
     def sigmoid_argmax(self, plan, logits, H, W, n_classes, sig, out):
         lv = logits.view()

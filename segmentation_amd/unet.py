@@ -226,8 +226,8 @@ class UNetModel(BaseModel):
             # 1x1 output conv + loss + its input gradient in one launch
             a92 = A['conv9_2']
             G['conv9_2'] = net.act(a92.H, a92.W, a92.C, name='dconv9_2')
-            net.head_xent(fwd, Ly['output'], a92, self.input_y, H, W, self.label_off, oh, ow, self.n_classes, self.loss_buf,
-                          A['logits'], dlog, G['conv9_2'])
+            head_ws = net.head_xent(fwd, Ly['output'], a92, self.input_y, H, W, self.label_off, oh, ow, self.n_classes, self.loss_buf,
+                                    A['logits'], dlog, G['conv9_2'], fuse_dw=os.environ.get('SEG_FUSE_HEAD_DW', '1') != '0')
         else:
             net.softmax_xent(fwd, A['logits'], self.input_y, H, W, self.label_off, oh, ow, self.n_classes, self.loss_buf, dlog)
         if self.adversarial_training:
@@ -267,8 +267,11 @@ class UNetModel(BaseModel):
             seg = E.Plan('bwd%d' % len(segs))
 
         # output layer
-        net.conv_bwd(seg, Ly['output'], [(A['conv9_2'], 0, 0)], A['conv9_2'].H, A['conv9_2'].W, dlog,
-                     [None if fuse_head else (gz('conv9_2'), (0, 0), A['conv9_2'], (0, 0))])
+        if fuse_head and head_ws is not None:
+            net.head_dw_reduce(seg, Ly['output'], head_ws, oh, ow, A['conv9_2'].Cp, self.n_classes)     # the gradient itself came with the head
+        else:
+            net.conv_bwd(seg, Ly['output'], [(A['conv9_2'], 0, 0)], A['conv9_2'].H, A['conv9_2'].W, dlog,
+                         [None if fuse_head else (gz('conv9_2'), (0, 0), A['conv9_2'], (0, 0))])
         close_segment('output')
         dskip = {}
         prev_of = {'upconv1': 'conv5_2', 'upconv2': 'conv6_2', 'upconv3': 'conv7_2', 'upconv4': 'conv8_2'}

@@ -220,3 +220,31 @@ def test_limits_are_refused_at_the_constructor():
             cls(sess=None, dataset=ArrayDataSet(x, y), n_classes=33, input_dims=188, log_dir=None, save_dir=None, load_snapshot=False)
         with pytest.raises(Exception, match='input_channel must be 1..3'):
             cls(sess=None, dataset=ArrayDataSet(x, y), n_classes=2, input_dims=188, input_channel=4, log_dir=None, save_dir=None, load_snapshot=False)
+
+
+@pytest.mark.parametrize('nc,nk,dtype', [(4, 32, 'f32'), (6, 32, 'f32'), (3, 64, 'f32'), (4, 32, 'bf16')])
+def test_unet_head_forms_agree(monkeypatch, nc, nk, dtype):
+    """the three forms of the segmentation head -- one launch incl. the output layer's filter gradient (default), one launch
+    with the filter gradient left to seg_conv2d_wgrad (SEG_FUSE_HEAD_DW=0), separate conv / x-entropy / dgrad launches
+    (SEG_FUSE_HEAD=0) -- give the same loss and the same gradients of every layer"""
+    B, S = 2, 188
+    x, y = _data(B, S, nc)
+    res = []
+    for fuse, dw in (('1', '1'), ('1', '0'), ('0', '0')):
+        monkeypatch.setenv('SEG_FUSE_HEAD', fuse)
+        monkeypatch.setenv('SEG_FUSE_HEAD_DW', dw)
+        m = _model(B, S, nc, dtype, x, y, use_graph=False, n_kernels=nk)
+        names = [o[0] for o in m.fwd_plan.ops]
+        assert ('output+xent+dx+dw' in names) == (fuse == '1' and dw == '1')
+        assert ('output+xent+dx' in names) == (fuse == '1' and dw == '0')
+        m._load_batch(m.dataset, m.input_x, m.input_y)
+        m._run_fwd_bwd(); torch.cuda.synchronize()
+        res.append((m.last_loss(), m.store.get_grads()))
+    tol = 2e-5 if dtype == 'f32' else 2e-2
+    for loss, g in res[1:]:
+        assert abs(loss - res[0][0]) < (1e-6 if dtype == 'f32' else 1e-3)
+        for n in g:
+            for k in ('weights', 'biases'):
+                ref = g[n][k]
+                err = np.abs(res[0][1][n][k] - ref).max() / (np.abs(ref).max() + 1e-20)
+                assert err < tol, (n, k, err)
