@@ -111,6 +111,13 @@ typedef struct seg_wgrad_desc {
   float* db;
   int32_t bias_n;
   int32_t phase;                  /* 0 = partial sums + reduce (two launches); 1 = partial sums only; 2 = reduce only */
+  /* First layer (models/unet.py:111 conv1_1, models/fcn.py:110 conv1): im2col_x != NULL makes src0 VIRTUAL -- the 3x3
+   * im2col of this dense float32 NHWC image [B, im2col_h, im2col_w, im2col_cin], gathered while the tiles are staged
+   * (channel tap*cin + ci of output pixel (y,x) = image[b, y+u-pad, x+v-pad, ci], zero outside).  Then KH = KW = 1,
+   * src0.c = 32, src0_clog = 9*cin, Hi = Ho, Wi = Wo; src0.ptr is not dereferenced (any non-NULL value) and dw comes
+   * out as the [3][3][cin][n] HWIO filter gradient. */
+  const float* im2col_x;
+  int32_t im2col_h, im2col_w, im2col_cin, im2col_pad;
 } seg_wgrad_desc;
 int seg_conv2d_wgrad(const seg_wgrad_desc* d, void* stream);
 int seg_conv2d_wgrad_plan(const seg_wgrad_desc* d, int32_t* ksplit, int64_t* ws_bytes);

@@ -38,7 +38,9 @@ class WgradDesc(C.Structure):
                 ('stride', C.c_int32), ('pad_t', C.c_int32), ('pad_l', C.c_int32), ('Ho', C.c_int32), ('Wo', C.c_int32),
                 ('dz', View), ('n_log', C.c_int32), ('dw', C.c_void_p), ('dtype', C.c_int32), ('cfg', C.c_int32),
                 ('ws', C.c_void_p), ('ws_bytes', C.c_int64), ('ksplit', C.c_int32), ('bias_mode', C.c_int32),
-                ('db', C.c_void_p), ('bias_n', C.c_int32), ('phase', C.c_int32)]
+                ('db', C.c_void_p), ('bias_n', C.c_int32), ('phase', C.c_int32),
+                ('im2col_x', C.c_void_p), ('im2col_h', C.c_int32), ('im2col_w', C.c_int32), ('im2col_cin', C.c_int32),
+                ('im2col_pad', C.c_int32)]
 
 
 class DconvDesc(C.Structure):

@@ -56,12 +56,38 @@ template <> struct TrRead<bf16_t> {
   }
 };
 
+// On-the-fly im2col of the first layer (IMC = input channels 1..3): raw-image loads of N dwords.
+typedef __attribute__((ext_vector_type(3))) uint32_t u32x3;
+template <int N> struct XVsel { typedef uint32_t type; };
+template <> struct XVsel<2> { typedef u32x2 type; };
+template <> struct XVsel<3> { typedef u32x3 type; };
+template <int N> SEG_DEV uint32_t xv_get(const typename XVsel<N>::type& r, int i) { if constexpr (N == 1) return r; else return r[i]; }
+template <int N, int IMM> SEG_DEV void xload_s(typename XVsel<N>::type& r, unsigned voff, uint64_t sbase) {
+  if constexpr (N == 3) asm volatile("global_load_dwordx3 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+  else if constexpr (N == 2) asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+  else asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+template <int N> SEG_DEV void xload_p(typename XVsel<N>::type& r, const float* ptr) {
+  if constexpr (N == 3) asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+  else if constexpr (N == 2) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+  else asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+}
+
 // RS = 1: "row split" -- blockIdx.z selects one filter row u, the workgroup keeps only KW taps in registers.
 // Used for the deep layers (few pixel tiles, big filters) where splitting K cannot create enough workgroups:
 // it multiplies the workgroup count by KH without any partial-sum traffic.
-template <int DT, int TH, int TW, int KH, int KW, int S, int WCI, int WCO, int FCI, int FCO, int RS>
+//
+// IMC > 0 (first layer, models/unet.py:111 conv1_1 / models/fcn.py:110 conv1): src0 is VIRTUAL -- the 3x3 im2col of the dense
+// float32 input image (d.im2col_*), channel tap*IMC + ci of output pixel (y,x) = image[b, y+u-pad, x+v-pad, ci] (zero outside).
+// The 1x1 walk over 256-pixel tiles stays as it is; only the staging differs: thread q of the workgroup gathers the 9*IMC
+// values of tile pixel q straight from the image (nine loads of IMC dwords: neighbours overlap in cache, the image is read
+// from HBM once), rounds them to T and writes the pixel's 32-channel row of the LDS patch.  The [B,Ho,Wo,32] im2col tensor
+// (as large as the layer's output) is never written or read back.
+template <int DT, int TH, int TW, int KH, int KW, int S, int WCI, int WCO, int FCI, int FCO, int RS, int IMC = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   using T = typename DtSel<DT>::type;
+  constexpr bool IM = IMC > 0;
+  using XV = typename XVsel<IM ? IMC : 1>::type;
   constexpr int BM = TH * TW;
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW, NPIX = PH * PW;
   constexpr int NU = RS ? 1 : KH;
@@ -86,6 +112,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   constexpr int KS = BM / 32;
   static_assert(WCI * WCO == 4 && (CIT == 32 || CIT == 64), "wave layout");
   static_assert(BM % 32 == 0, "tile pixels");
+  static_assert(!IM || (KH == 1 && KW == 1 && S == 1 && BM == 256 && CIT == 32 && IMC <= 3), "im2col staging: one tile pixel per thread");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sP = smem;
@@ -151,10 +178,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   // the loop back-edge and falls back to vmcnt(0), which would drain the other set's prefetch at every commit.
   // Every load is issued unconditionally (clamped address; a bit mask remembers which pieces to zero), so each
   // prefetch is exactly NLD wave-instructions and "the other set is younger" is vmcnt(NLD).
-  constexpr int NLD = NPP + NZP;
+  constexpr int NXL = IM ? 9 : NPP;               // loads per thread for the X side of a tile
+  constexpr int NLD = NXL + NZP;
   static_assert(NLD <= 60, "vmcnt range / mask bits");
   constexpr bool DUAL = sizeof(T) == 2;              // f32 (parity mode) keeps one set: twice the registers per piece
   u32x4 rpA[NPP], rzA[NZP], rpB[DUAL ? NPP : 1], rzB[DUAL ? NZP : 1];
+  XV xA[IM ? 9 : 1], xB[IM && DUAL ? 9 : 1];
   uint64_t okA = 0, okB = 0;
   auto gload = [&](u32x4& r, const T* ptr) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory"); };
   // interior tiles: wave-uniform 64-bit base in SGPRs + the thread's constant 32-bit byte offset (no per-load 64-bit VALU)
@@ -175,7 +204,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
 #pragma unroll
   for (int i = 0; i < NPP; ++i) { sp_boff[i] = sp_lds[i] >= 0 ? (unsigned)sp_off[i] * ES : 0u; full |= (uint64_t)(sp_lds[i] >= 0 ? 1 : 0) << i; }
 #pragma unroll
-  for (int i = 0; i < NZP; ++i) { sz_boff[i] = sz_lds[i] >= 0 ? (unsigned)sz_off[i] * ES : 0u; full |= (uint64_t)(sz_lds[i] >= 0 ? 1 : 0) << (NPP + i); }
+  for (int i = 0; i < NZP; ++i) { sz_boff[i] = sz_lds[i] >= 0 ? (unsigned)sz_off[i] * ES : 0u; full |= (uint64_t)(sz_lds[i] >= 0 ? 1 : 0) << (NXL + i); }
+  if constexpr (IM) full |= 0x1ffull;
   // tile coordinates advance incrementally (no divisions in the walk): a stride of `step` tiles = (sb_, sy_, sx_)
   struct TileIt { int b, ty, tx; };
   auto tile_decode = [&](int t) { TileIt it; it.tx = t % P.tiles_x; t /= P.tiles_x; it.ty = t % P.tiles_y; it.b = t / P.tiles_y; return it; };
@@ -213,10 +243,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
     for (int i = 0; i < NZP; ++i) {
       const int mm = (tid + i * 256) / ZPIECES;
       const bool ok = sz_lds[i] >= 0 && oy0 + mm / TW < d.Ho && ox0 + mm % TW < d.Wo;
-      m |= (uint64_t)(ok ? 1 : 0) << (NPP + i);
+      m |= (uint64_t)(ok ? 1 : 0) << (NXL + i);
       gload(rz[i], ok ? zb + sz_off[i] : dzp);
     }
     okm = m;
+  };
+  // im2col staging: tile pixel q = tid; image offsets of its three filter rows relative to the tile's first input pixel
+  const float* imx = d.im2col_x;
+  const int imH = d.im2col_h, imW = d.im2col_w, impad = d.im2col_pad;
+  unsigned x_boff[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) x_boff[u] = (unsigned)(((tid / TW + u) * imW + tid % TW) * (IM ? IMC : 1) * 4);
+  auto prefetch_im = [&](const TileIt& it, XV (&xr)[IM ? 9 : 1], u32x4 (&rz)[NZP], uint64_t& okm) {
+    if constexpr (IM) {
+      const int b = __builtin_amdgcn_readfirstlane(it.b), ty = __builtin_amdgcn_readfirstlane(it.ty), tx = __builtin_amdgcn_readfirstlane(it.tx);
+      const int oy0 = ty * TH, ox0 = tx * TW;
+      const int iy0 = oy0 - impad, ix0 = ox0 - impad;
+      const float* xb = imx + (((int64_t)b * imH + iy0) * imW + ix0) * IMC;
+      const T* zb = dzp + (int64_t)b * d.dz.H * d.dz.W * d.dz.cs + d.dz.coff + n0 + ((int64_t)(oy0 + d.dz.oy) * d.dz.W + ox0 + d.dz.ox) * d.dz.cs;
+      const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + TH + 2 <= imH && ix0 + TW + 2 <= imW && oy0 + TH <= d.Ho && ox0 + TW <= d.Wo;
+      if (interior) {
+        const uint64_t xbu = uniform64(xb), zbu = uniform64(zb);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          xload_s<IMC, 0>(xr[u * 3 + 0], x_boff[u], xbu);
+          xload_s<IMC, IMC * 4>(xr[u * 3 + 1], x_boff[u], xbu);
+          xload_s<IMC, IMC * 8>(xr[u * 3 + 2], x_boff[u], xbu);
+        }
+#pragma unroll
+        for (int i = 0; i < NZP; ++i) gload_s(rz[i], sz_boff[i], zbu);
+        okm = full;
+        return;
+      }
+      uint64_t m = 0;
+      const int oy = oy0 + tid / TW, ox = ox0 + tid % TW;
+      const bool pix = oy < d.Ho && ox < d.Wo;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = oy - impad + t / 3, ix = ox - impad + t % 3;
+        const bool ok = pix && iy >= 0 && iy < imH && ix >= 0 && ix < imW;
+        m |= (uint64_t)(ok ? 1 : 0) << t;
+        xload_p<IMC>(xr[t], ok ? imx + (((int64_t)b * imH + iy) * imW + ix) * IMC : imx);
+      }
+#pragma unroll
+      for (int i = 0; i < NZP; ++i) {
+        const int mm = (tid + i * 256) / ZPIECES;
+        const bool ok = sz_lds[i] >= 0 && oy0 + mm / TW < d.Ho && ox0 + mm % TW < d.Wo;
+        m |= (uint64_t)(ok ? 1 : 0) << (NXL + i);
+        gload(rz[i], ok ? zb + sz_off[i] : dzp);
+      }
+      okm = m;
+    }
   };
   // waits until this set's loads have landed; `younger` = the other set's prefetch was issued after them
   auto wait_set = [&](u32x4 (&rp)[NPP], u32x4 (&rz)[NZP], bool younger) {
@@ -227,13 +304,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
 #pragma unroll
     for (int i = 0; i < NZP; ++i) asm volatile("" : "+v"(rz[i]));
   };
+  auto commit_z = [&](const u32x4 (&rz)[NZP], uint64_t okm) {
+#pragma unroll
+    for (int i = 0; i < NZP; ++i)
+      if (sz_lds[i] >= 0) *reinterpret_cast<u32x4*>(sZ + sz_lds[i]) = ((okm >> (NXL + i)) & 1) ? rz[i] : u32x4{0, 0, 0, 0};
+  };
   auto commit = [&](const u32x4 (&rp)[NPP], const u32x4 (&rz)[NZP], uint64_t okm) {
 #pragma unroll
     for (int i = 0; i < NPP; ++i)
       if (sp_lds[i] >= 0) *reinterpret_cast<u32x4*>(sP + sp_lds[i]) = ((okm >> i) & 1) ? rp[i] : u32x4{0, 0, 0, 0};
+    commit_z(rz, okm);
+  };
+  auto wait_set_im = [&](XV (&xr)[IM ? 9 : 1], u32x4 (&rz)[NZP], bool younger) {
+    if (younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < NZP; ++i)
-      if (sz_lds[i] >= 0) *reinterpret_cast<u32x4*>(sZ + sz_lds[i]) = ((okm >> (NPP + i)) & 1) ? rz[i] : u32x4{0, 0, 0, 0};
+    for (int i = 0; i < (IM ? 9 : 1); ++i) asm volatile("" : "+v"(xr[i]));
+#pragma unroll
+    for (int i = 0; i < NZP; ++i) asm volatile("" : "+v"(rz[i]));
+  };
+  auto commit_im = [&](const XV (&xr)[IM ? 9 : 1], const u32x4 (&rz)[NZP], uint64_t okm) {
+    if constexpr (IM) {
+      // the pixel's 32-channel row: k = tap * IMC + ci (the HWIO order of the filter gradient), zeros behind 9 * IMC
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        Vec8<T> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = h * 8 + e;
+          float v = 0.f;
+          if (k < 9 * IMC) { const int t = k / IMC, ci = k % IMC; v = ((okm >> t) & 1) ? __builtin_bit_cast(float, xv_get<IMC>(xr[t], ci)) : 0.f; }
+          o.set(e, v);
+        }
+        o.store(sP + tid * RSP + h * 8 * ES);
+      }
+      commit_z(rz, okm);
+    }
   };
 
   // ---- per-lane fragment addresses ----
@@ -319,6 +425,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  auto prefetchA = [&](const TileIt& it) { if constexpr (IM) prefetch_im(it, xA, rzA, okA); else prefetch(it, rpA, rzA, okA); };
+  auto prefetchB = [&](const TileIt& it) { if constexpr (DUAL) { if constexpr (IM) prefetch_im(it, xB, rzB, okB); else prefetch(it, rpB, rzB, okB); } };
+  auto waitA = [&](bool younger) { if constexpr (IM) wait_set_im(xA, rzA, younger); else wait_set(rpA, rzA, younger); };
+  auto waitB = [&](bool younger) { if constexpr (DUAL) { if constexpr (IM) wait_set_im(xB, rzB, younger); else wait_set(rpB, rzB, younger); } };
+  auto commitA = [&]() { if constexpr (IM) commit_im(xA, rzA, okA); else commit(rpA, rzA, okA); };
+  auto commitB = [&]() { if constexpr (DUAL) { if constexpr (IM) commit_im(xB, rzB, okB); else commit(rpB, rzB, okB); } };
   int tile = blockIdx.y;
   const int ks_ = P.ksplit;
 #ifdef SEG_STAMPS
@@ -327,35 +439,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
 #endif
   WSTAMP(3, 0);
   TileIt itA = tile_decode(tile < P.ntiles ? tile : 0);
-  if (tile < P.ntiles) prefetch(itA, rpA, rzA, okA);
+  if (tile < P.ntiles) prefetchA(itA);
   if constexpr (DUAL) {
     const TileIt st2 = tile_decode(2 * ks_);            // each set strides by two splits
     TileIt itB = tile_decode(tile + ks_ < P.ntiles ? tile + ks_ : 0);
     bool youngerB = tile + ks_ < P.ntiles;              // set B was issued after the pending set A
-    if (youngerB) prefetch(itB, rpB, rzB, okB);
+    if (youngerB) prefetchB(itB);
     for (; tile < P.ntiles; tile += 2 * ks_) {
-      wait_set(rpA, rzA, youngerB);
+      waitA(youngerB);
       WSTAMP(0, it_);
       lds_barrier();                                     // previous tile's LDS reads are done
-      commit(rpA, rzA, okA);
+      commitA();
       lds_barrier();
       WSTAMP(1, it_);
       const bool moreA = tile + 2 * ks_ < P.ntiles;
-      if (moreA) { tile_advance(itA, st2); prefetch(itA, rpA, rzA, okA); }
+      if (moreA) { tile_advance(itA, st2); prefetchA(itA); }
       WSTAMP(2, it_);
       compute();
 #ifdef SEG_STAMPS
       ++it_;
 #endif
       if (tile + ks_ >= P.ntiles) break;
-      wait_set(rpB, rzB, moreA);
+      waitB(moreA);
       WSTAMP(0, it_);
       lds_barrier();
-      commit(rpB, rzB, okB);
+      commitB();
       lds_barrier();
       WSTAMP(1, it_);
       youngerB = tile + 3 * ks_ < P.ntiles;
-      if (youngerB) { tile_advance(itB, st2); prefetch(itB, rpB, rzB, okB); }
+      if (youngerB) { tile_advance(itB, st2); prefetchB(itB); }
       WSTAMP(2, it_);
       compute();
 #ifdef SEG_STAMPS
@@ -365,11 +477,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   } else {
     const TileIt st1 = tile_decode(ks_);
     for (; tile < P.ntiles; tile += ks_) {
-      wait_set(rpA, rzA, false);
+      waitA(false);
       lds_barrier();
-      commit(rpA, rzA, okA);
+      commitA();
       lds_barrier();
-      if (tile + ks_ < P.ntiles) { tile_advance(itA, st1); prefetch(itA, rpA, rzA, okA); }
+      if (tile + ks_ < P.ntiles) { tile_advance(itA, st1); prefetchA(itA); }
       compute();
     }
   }
@@ -557,7 +669,7 @@ inline int wgrad_target_wgs() {
   return v > 0 ? v : 128;
 }
 
-template <typename T, int TH, int TW, int KH, int KW, int S, int WCI, int WCO, int FCI, int FCO>
+template <typename T, int TH, int TW, int KH, int KW, int S, int WCI, int WCO, int FCI, int FCO, int IMC = 0>
 int launch_cfg(const WgK& P0, hipStream_t st) {
   constexpr int BN = 16 * FCO * WCO, ES = sizeof(T), CIT = 16 * FCI * WCI;
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
@@ -579,8 +691,8 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
   const bool rs = KH > 1 && P.d.bias_mode != 2 && P.ntiles <= 64 && base < 192;
   const int wg = base * (rs ? KH : 1);
   const int target_wgs = wgrad_target_wgs();
-  auto k0 = conv_wgrad_kernel<Tr<T>::DT, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, 0>;
-  auto k1 = conv_wgrad_kernel<Tr<T>::DT, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, (KH > 1 ? 1 : 0)>;
+  auto k0 = conv_wgrad_kernel<Tr<T>::DT, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, 0, IMC>;
+  auto k1 = conv_wgrad_kernel<Tr<T>::DT, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, (KH > 1 ? 1 : 0), IMC>;
   static int occ = 0;                      // resident workgroups per CU of this instance
   if (occ == 0) {
     if (LDS > 48 * 1024) {
@@ -608,7 +720,8 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
   const int64_t bias_len = P.k_pad > P.n_pad ? P.k_pad : P.n_pad;
   P.slab = (int64_t)KH * KW * P.k_pad * P.n_pad + bias_len;
   if (g_wname_out) {
-    snprintf(g_wname_out, g_wname_cap, "conv_wgrad_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", ES == 2 ? "bf16" : "f32", TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, rs ? 1 : 0);
+    if (IMC) snprintf(g_wname_out, g_wname_cap, "conv_wgrad_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", ES == 2 ? "bf16" : "f32", TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, rs ? 1 : 0, IMC);
+    else snprintf(g_wname_out, g_wname_cap, "conv_wgrad_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", ES == 2 ? "bf16" : "f32", TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, rs ? 1 : 0);
     return SEG_OK;
   }
   if (g_plan_ks) { *g_plan_ks = ks; *g_plan_bytes = P.direct ? 0 : P.slab * ks * 4; return SEG_OK; }
@@ -642,6 +755,15 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
 template <typename T, int KH, int KW, int S>
 int launch_k(const WgK& P, hipStream_t st) {
   const seg_wgrad_desc& d = P.d;
+  if constexpr (KH == 1 && KW == 1 && S == 1) {
+    if (d.im2col_x) {                       // first layer: virtual im2col source, 256-pixel tiles, 32 x 32 channels
+      switch (d.im2col_cin) {
+        case 1: return launch_cfg<T, 16, 16, 1, 1, 1, 2, 2, 1, 1, 1>(P, st);
+        case 2: return launch_cfg<T, 16, 16, 1, 1, 1, 2, 2, 1, 1, 2>(P, st);
+        default: return launch_cfg<T, 16, 16, 1, 1, 1, 2, 2, 1, 1, 3>(P, st);
+      }
+    }
+  }
   int cfg = d.cfg;
   const bool small = (long)cdiv(d.Ho, 8) * 8 * cdiv(d.Wo, 8) * 8 < (long)cdiv(d.Ho, 8) * 8 * cdiv(d.Wo, 16) * 16;
   if (cfg == 0 && sizeof(T) == 2) {
@@ -738,6 +860,13 @@ extern "C" int seg_conv2d_wgrad(const seg_wgrad_desc* dp, void* stream) {
   if (!dp) { seg_set_error("wgrad: null descriptor"); return SEG_ERR_ARG; }
   const seg_wgrad_desc& d = *dp;
   if (!d.src0.ptr || !d.dz.ptr || !d.dw) { seg_set_error("wgrad: null pointer"); return SEG_ERR_ARG; }
+  if (d.im2col_x) {
+    if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.pad_t || d.pad_l || d.src1.ptr || d.src0.c != 32 || d.im2col_cin < 1 || d.im2col_cin > 3 ||
+        d.src0_clog != 9 * d.im2col_cin || d.im2col_pad < 0 || d.im2col_pad > 1 || d.Hi != d.Ho || d.Wi != d.Wo ||
+        d.Ho != d.im2col_h + 2 * d.im2col_pad - 2 || d.Wo != d.im2col_w + 2 * d.im2col_pad - 2) {
+      seg_set_error("wgrad: inconsistent im2col source (1x1 walk over [B,Ho,Wo,32], 9*cin logical channels, cin 1..3)"); return SEG_ERR_ARG;
+    }
+  }
   if (d.bias_mode < 0 || d.bias_mode > 2 || (d.bias_mode && (!d.db || d.bias_n <= 0))) { seg_set_error("wgrad: bad bias request"); return SEG_ERR_ARG; }
   if ((d.bias_mode == 1 && d.bias_n > d.dz.c) || (d.bias_mode == 2 && d.bias_n > d.src0.c)) { seg_set_error("wgrad: bias_n exceeds channels"); return SEG_ERR_ARG; }
   if (d.src0.c <= 0 || d.src0.c % 32 || (d.src1.ptr && (d.src1.c <= 0 || d.src1.c % 32)) || d.dz.c <= 0 || d.dz.c % 32) {

@@ -650,11 +650,15 @@ class Net(object):
                      kernel='wgrad_reduce_batch_kernel', side=sid, flavor='batched')          # sid 0 = main stream
 
     def first_im2col(self, plan, layer, x_f32, H, W):
-        """im2col of the raw input (27 -> 32 channels) for the first layer's filter gradient.  It depends only on the
-        input batch, so the models emit it at the START of the forward plan on a side stream (off the critical path)."""
-        Ho, Wo = H + 2 * layer.pad - 2, W + 2 * layer.pad - 2
+        """im2col of the raw input (27 -> 32 channels) for the first layer's filter gradient as a tensor of its own
+        (SEG_FIRST_IM2COL=1: the r01 form; by default the filter gradient gathers the im2col rows itself while it stages
+        its tiles and this returns None).  It depends only on the input batch, so the models emit it at the START of the
+        forward plan on a side stream (off the critical path)."""
         if layer.cin > 3:
             raise L.SegError('first-layer gradient supports input_channel <= 3')
+        if os.environ.get('SEG_FIRST_IM2COL', '0') != '1':
+            return None
+        Ho, Wo = H + 2 * layer.pad - 2, W + 2 * layer.pad - 2
         col = self.act(Ho, Wo, 9 * layer.cin, name='im2col')
         cv = col.view()
         plan.keep.append(cv)
@@ -664,12 +668,19 @@ class Net(object):
 
     def first_bwd(self, plan, layer, x_f32, H, W, dz, col=None, same_stream=True):
         """First-layer filter/bias gradient = the generic 1x1 MFMA wgrad over the im2col'd input; the [1][9*cin][cout]
-        result is exactly the HWIO filter gradient."""
+        result is exactly the HWIO filter gradient.  col=None: the im2col rows are gathered from the float image inside the
+        filter-gradient kernel (seg_wgrad_desc.im2col_x); else `col` is the tensor first_im2col wrote."""
         Ho, Wo = H + 2 * layer.pad - 2, W + 2 * layer.pad - 2
-        if col is None:
-            col = self.first_im2col(plan, layer, x_f32, H, W)
+        if layer.cin > 3:
+            raise L.SegError('first-layer gradient supports input_channel <= 3')
         w = L.WgradDesc()
-        w.src0 = col.view(); w.src1 = L.null_view(); w.src0_clog = 9 * layer.cin; w.src1_clog = 0
+        if col is None:
+            # virtual source: a dense [B,Ho,Wo,32] window description whose pointer is never dereferenced
+            w.src0 = L.View(ptr=x_f32.data_ptr(), H=Ho, W=Wo, cs=32, oy=0, ox=0, coff=0, c=32)
+            w.im2col_x = x_f32.data_ptr(); w.im2col_h, w.im2col_w, w.im2col_cin, w.im2col_pad = H, W, layer.cin, layer.pad
+        else:
+            w.src0 = col.view()
+        w.src1 = L.null_view(); w.src0_clog = 9 * layer.cin; w.src1_clog = 0
         w.B, w.Hi, w.Wi = self.B, Ho, Wo
         w.KH = w.KW = 1; w.stride = 1; w.pad_t = w.pad_l = 0
         w.Ho, w.Wo = Ho, Wo
@@ -683,7 +694,7 @@ class Net(object):
         # backward back to back needs no join of the side streams in between
         # (same_stream=False: the data-parallel plans, which join the side streams after the forward anyway, keep the
         # alternating assignment -- pinning changed the shape of their captured segment graph and made it 20 % slower)
-        self._add_wgrad(plan, layer.name + '/dw', w, fl, sid=1 if same_stream else None)
+        self._add_wgrad(plan, layer.name + '/dw', w, fl, sid=1 if (same_stream and col is not None) else None)
         plan.flops += fl
 
     def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0):

@@ -220,7 +220,7 @@ def test_upconv_fwd_bwd(dtype, case):
 
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('pad,cin,cout,H', [(0, 3, 32, 21), (1, 3, 16, 18), (0, 1, 40, 33), (1, 2, 64, 20), (0, 3, 32, 64)])
-def test_conv_first(dtype, pad, cin, cout, H):
+def test_conv_first(dtype, pad, cin, cout, H, monkeypatch):
     B, W = 2, H + 3
     rng = np.random.default_rng(cout + H)
     layer = E.Layer('f', 'first', 3, [cin], cout, 'VALID' if pad == 0 else 'SAME', True)
@@ -253,6 +253,14 @@ def test_conv_first(dtype, pad, cin, cout, H):
         # bf16 mode rounds the im2col'd input to bf16 (the MFMA operand type)
         assert U.rel_err(g['weights'], dw_ref) < U.tol(dtype, 2e-5, 1e-2)
         assert U.rel_err(g['biases'], db_ref) < U.tol(dtype, 2e-5, 1e-2)
+        assert [o[0] for o in bp.ops if o[1] is not None][0] == 'f/dw'          # no im2col launch: the rows are gathered while staging
+        # the explicit form (im2col tensor + the same 1x1 walk): the same rounded operands, another summation order at most
+        monkeypatch.setenv('SEG_FIRST_IM2COL', '1')
+        store.g.zero_()
+        bp2 = E.Plan('b2'); col = net.first_im2col(bp2, layer, xt, H, W); assert col is not None
+        net.first_bwd(bp2, layer, xt, H, W, dz, col=col); net.flush_reduce(bp2); bp2.run(U.stream()); U.sync()
+        g2 = store.get_grads()['f']
+        assert U.rel_err(g2['weights'], g['weights']) < 2e-5 and U.rel_err(g2['biases'], g['biases']) < 2e-5
 
 
 @pytest.mark.parametrize('dtype', DT)
