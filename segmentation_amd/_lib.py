@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libseg_hip.so')
+LIB_PATH = os.environ.get('SEG_LIB_PATH') or os.path.join(HERE, 'libseg_hip.so')     # (SEG_LIB_PATH: debug builds, tools/wgrad_ablate.sh)
 
 SEG_F32, SEG_BF16 = 0, 1
 PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_UP_FWD, PACK_UP_DGRAD = 0, 1, 2, 3

@@ -25,6 +25,18 @@ struct WgK {
   int direct;                    // ksplit == 1: store straight into dw/db, no reduce pass
 };
 
+// Debug builds only (SEG_EXTRA_FLAGS=-DSEG_WABL=bits, tools/wgrad_ablate.sh): parts of the tile walk compiled out one at a
+// time to see which of them the run time follows.  1 MFMAs, 2 LDS fragment reads, 4 LDS commits, 8 global loads.
+// Results are garbage with any bit set.
+#ifndef SEG_WABL
+#define SEG_WABL 0
+#endif
+
+SEG_DEV void frag_keep(const Frag<bf16_t>& f) { asm volatile("" :: "v"(f.v)); }
+SEG_DEV void frag_keep(const Frag<float>& f) { asm volatile("" :: "v"(f.lo), "v"(f.hi)); }
+SEG_DEV void frag_undef(Frag<bf16_t>& f) { asm volatile("" : "=v"(f.v)); }
+SEG_DEV void frag_undef(Frag<float>& f) { asm volatile("" : "=v"(f.lo), "=v"(f.hi)); }
+
 #ifdef SEG_STAMPS
 __device__ long long* g_wstamps = nullptr;     // debug builds only: [workgroup][4 rows][32] s_memtime stamps of wave 0
 #define WSTAMP(row, idx) do { if (wstp && (idx) < 32) wstp[(row) * 32 + (idx)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -214,13 +226,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
     it.ty += st.ty; if (it.ty >= P.tiles_y) { it.ty -= P.tiles_y; ++it.b; }
     it.b += st.b;
   };
-  auto prefetch = [&](const TileIt& it, u32x4 (&rp)[NPP], u32x4 (&rz)[NZP], uint64_t& okm) {
+  // tile (b, ty, tx) -> first element of its patch / dZ window: base + b * image + ty * tile-row step + tx * tile-column step.
+  // The steps are hoisted (an image plane is < 2^31 elements, checked by the host): per tile two 32-bit products and one
+  // 64 x 32 one per pointer instead of a chain of 64-bit multiplies -- the scalar address arithmetic was a third of the
+  // non-MFMA instructions of a tile (r02 counters: 44 % of a lone workgroup's cycles in the MFMAs, 31 % issuing other work).
+  const int s_ty = TH * S * sv.W * sv.cs, s_tx = TW * S * sv.cs, z_ty = TH * d.dz.W * d.dz.cs, z_tx = TW * d.dz.cs;
+  const int64_t s_img = (int64_t)sv.H * sv.W * sv.cs, z_img = (int64_t)d.dz.H * d.dz.W * d.dz.cs;
+  const T* const s_base = srcp + sv.coff + cbase + ((int64_t)(sv.oy - d.pad_t) * sv.W + (sv.ox - d.pad_l)) * sv.cs;
+  const T* const z_base = dzp + d.dz.coff + n0 + ((int64_t)d.dz.oy * d.dz.W + d.dz.ox) * d.dz.cs;
+  auto prefetch = [&](const TileIt& it, u32x4 (&rp)[NPP], u32x4 (&rz)[NZP], uint64_t& okm, bool& inter) {
     const int b = __builtin_amdgcn_readfirstlane(it.b), ty = __builtin_amdgcn_readfirstlane(it.ty), tx = __builtin_amdgcn_readfirstlane(it.tx);
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * S - d.pad_t, ix0 = ox0 * S - d.pad_l;
-    const T* sb = srcp + (int64_t)b * sv.H * sv.W * sv.cs + sv.coff + cbase + ((int64_t)(iy0 + sv.oy) * sv.W + ix0 + sv.ox) * sv.cs;
-    const T* zb = dzp + (int64_t)b * d.dz.H * d.dz.W * d.dz.cs + d.dz.coff + n0 + ((int64_t)(oy0 + d.dz.oy) * d.dz.W + ox0 + d.dz.ox) * d.dz.cs;
+    const T* sb = s_base + b * s_img + (ty * s_ty + tx * s_tx);
+    const T* zb = z_base + b * z_img + (ty * z_ty + tx * z_tx);
     const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + PH <= d.Hi && ix0 + PW <= d.Wi && oy0 + TH <= d.Ho && ox0 + TW <= d.Wo;
+    inter = interior;
     if (interior) {
       const uint64_t sbu = uniform64(sb), zbu = uniform64(zb);
 #pragma unroll
@@ -254,14 +275,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   unsigned x_boff[3];
 #pragma unroll
   for (int u = 0; u < 3; ++u) x_boff[u] = (unsigned)(((tid / TW + u) * imW + tid % TW) * (IM ? IMC : 1) * 4);
-  auto prefetch_im = [&](const TileIt& it, XV (&xr)[IM ? 9 : 1], u32x4 (&rz)[NZP], uint64_t& okm) {
+  auto prefetch_im = [&](const TileIt& it, XV (&xr)[IM ? 9 : 1], u32x4 (&rz)[NZP], uint64_t& okm, bool& inter) {
     if constexpr (IM) {
       const int b = __builtin_amdgcn_readfirstlane(it.b), ty = __builtin_amdgcn_readfirstlane(it.ty), tx = __builtin_amdgcn_readfirstlane(it.tx);
       const int oy0 = ty * TH, ox0 = tx * TW;
       const int iy0 = oy0 - impad, ix0 = ox0 - impad;
       const float* xb = imx + (((int64_t)b * imH + iy0) * imW + ix0) * IMC;
-      const T* zb = dzp + (int64_t)b * d.dz.H * d.dz.W * d.dz.cs + d.dz.coff + n0 + ((int64_t)(oy0 + d.dz.oy) * d.dz.W + ox0 + d.dz.ox) * d.dz.cs;
+      const T* zb = z_base + b * z_img + (ty * z_ty + tx * z_tx);
       const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + TH + 2 <= imH && ix0 + TW + 2 <= imW && oy0 + TH <= d.Ho && ox0 + TW <= d.Wo;
+      inter = interior;
       if (interior) {
         const uint64_t xbu = uniform64(xb), zbu = uniform64(zb);
 #pragma unroll
@@ -304,16 +326,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
 #pragma unroll
     for (int i = 0; i < NZP; ++i) asm volatile("" : "+v"(rz[i]));
   };
-  auto commit_z = [&](const u32x4 (&rz)[NZP], uint64_t okm) {
+  // inter (wave-uniform): the tile was interior, every piece this thread owns is valid -- plain stores, no selects
+  auto commit_z = [&](const u32x4 (&rz)[NZP], uint64_t okm, bool inter) {
+    if (inter) {
+#pragma unroll
+      for (int i = 0; i < NZP; ++i)
+        if (sz_lds[i] >= 0) *reinterpret_cast<u32x4*>(sZ + sz_lds[i]) = rz[i];
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NZP; ++i)
       if (sz_lds[i] >= 0) *reinterpret_cast<u32x4*>(sZ + sz_lds[i]) = ((okm >> (NXL + i)) & 1) ? rz[i] : u32x4{0, 0, 0, 0};
   };
-  auto commit = [&](const u32x4 (&rp)[NPP], const u32x4 (&rz)[NZP], uint64_t okm) {
+  auto commit = [&](const u32x4 (&rp)[NPP], const u32x4 (&rz)[NZP], uint64_t okm, bool inter) {
+    if (inter) {
 #pragma unroll
-    for (int i = 0; i < NPP; ++i)
-      if (sp_lds[i] >= 0) *reinterpret_cast<u32x4*>(sP + sp_lds[i]) = ((okm >> i) & 1) ? rp[i] : u32x4{0, 0, 0, 0};
-    commit_z(rz, okm);
+      for (int i = 0; i < NPP; ++i)
+        if (sp_lds[i] >= 0) *reinterpret_cast<u32x4*>(sP + sp_lds[i]) = rp[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPP; ++i)
+        if (sp_lds[i] >= 0) *reinterpret_cast<u32x4*>(sP + sp_lds[i]) = ((okm >> i) & 1) ? rp[i] : u32x4{0, 0, 0, 0};
+    }
+    commit_z(rz, okm, inter);
   };
   auto wait_set_im = [&](XV (&xr)[IM ? 9 : 1], u32x4 (&rz)[NZP], bool younger) {
     if (younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
@@ -323,7 +358,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
 #pragma unroll
     for (int i = 0; i < NZP; ++i) asm volatile("" : "+v"(rz[i]));
   };
-  auto commit_im = [&](const XV (&xr)[IM ? 9 : 1], const u32x4 (&rz)[NZP], uint64_t okm) {
+  auto commit_im = [&](const XV (&xr)[IM ? 9 : 1], const u32x4 (&rz)[NZP], uint64_t okm, bool inter) {
     if constexpr (IM) {
       // the pixel's 32-channel row: k = tap * IMC + ci (the HWIO order of the filter gradient), zeros behind 9 * IMC
 #pragma unroll
@@ -333,12 +368,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
         for (int e = 0; e < 8; ++e) {
           const int k = h * 8 + e;
           float v = 0.f;
-          if (k < 9 * IMC) { const int t = k / IMC, ci = k % IMC; v = ((okm >> t) & 1) ? __builtin_bit_cast(float, xv_get<IMC>(xr[t], ci)) : 0.f; }
+          if (k < 9 * IMC) { const int t = k / IMC, ci = k % IMC; v = (inter || ((okm >> t) & 1)) ? __builtin_bit_cast(float, xv_get<IMC>(xr[t], ci)) : 0.f; }
           o.set(e, v);
         }
         o.store(sP + tid * RSP + h * 8 * ES);
       }
-      commit_z(rz, okm);
+      commit_z(rz, okm, inter);
     }
   };
 
@@ -366,7 +401,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   const int z_ch = (wco * FCO) * 16 * ES;
 
   auto read_frag = [&](const char* base, const int* addr, int off) -> Frag<T> {
-    if constexpr (BF) {
+    if constexpr ((SEG_WABL & 2) != 0) { Frag<T> f; frag_undef(f); return f; }
+    else if constexpr (BF) {
       return TrRead<bf16_t>::read(base + addr[0] + off, base + addr[1] + off);
     } else {
       Frag<float> f;
@@ -387,7 +423,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
     // the transposed reads of step s+LA are issued before the MFMA(s) of step s.  Left to itself the scheduler
     // batches reads far ahead (204 VGPRs -> 2 waves/SIMD) and still waits on LDS before most MFMAs.
     constexpr int NSTEP = KS * NT;
-    constexpr int LA = 3;                                  // X fragments in flight (steps ahead)
+    // X fragments in flight (steps ahead).  A step is FCI*FCO MFMAs = 16*FCI*FCO cycles of matrix-core time and a transposed
+    // LDS read under four waves' traffic takes ~250-300 cycles to return (s_memtime stamps, r02: with 3 steps ahead the
+    // 64 x 64 layout waited ~30 cycles on lgkmcnt at EVERY step), so the look-ahead is sized in cycles, not in steps.
+#ifndef SEG_WGRAD_LA_CLK
+#define SEG_WGRAD_LA_CLK 320
+#endif
+    constexpr int LA0 = (SEG_WGRAD_LA_CLK + 16 * FCI * FCO - 1) / (16 * FCI * FCO);
+    constexpr int LA = LA0 < 3 ? 3 : (LA0 > 12 ? 12 : LA0);
     constexpr int ZLA = NT >= LA ? 1 : LA;                 // dZ fragments in flight (K steps ahead)
     Frag<T> fx[LA + 1][FCI], fz[ZLA + 1][FCO];
     const int rs_off = u0 * PW * RSP;
@@ -414,23 +457,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
       if (tap == 0 && ks + ZLA < KS) issue_z(ks + ZLA);
       if (!B2 && tap == 0) {
 #pragma unroll
-        for (int c = 0; c < FCO; ++c) mma32(accb1[c], ones, fz[ks % (ZLA + 1)][c]);
+        for (int c = 0; c < FCO; ++c) if (!(SEG_WABL & 1)) mma32(accb1[c], ones, fz[ks % (ZLA + 1)][c]);
       }
 #pragma unroll
       for (int a = 0; a < FCI; ++a) {
 #pragma unroll
-        for (int c = 0; c < FCO; ++c) mma32(acc[tap][a][c], fx[st % (LA + 1)][a], fz[ks % (ZLA + 1)][c]);
-        if (B2) mma32(accb2[a], fx[st % (LA + 1)][a], ones);
+        for (int c = 0; c < FCO; ++c) {
+          if (!(SEG_WABL & 1)) mma32(acc[tap][a][c], fx[st % (LA + 1)][a], fz[ks % (ZLA + 1)][c]);
+          else { frag_keep(fx[st % (LA + 1)][a]); frag_keep(fz[ks % (ZLA + 1)][c]); }       // (the reads stay live)
+        }
+        if (B2 && !(SEG_WABL & 1)) mma32(accb2[a], fx[st % (LA + 1)][a], ones);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto prefetchA = [&](const TileIt& it) { if constexpr (IM) prefetch_im(it, xA, rzA, okA); else prefetch(it, rpA, rzA, okA); };
-  auto prefetchB = [&](const TileIt& it) { if constexpr (DUAL) { if constexpr (IM) prefetch_im(it, xB, rzB, okB); else prefetch(it, rpB, rzB, okB); } };
+  bool intA = false, intB = false;
+  auto prefetchA = [&](const TileIt& it) { if constexpr ((SEG_WABL & 8) != 0) { okA = full; } else if constexpr (IM) prefetch_im(it, xA, rzA, okA, intA); else prefetch(it, rpA, rzA, okA, intA); };
+  auto prefetchB = [&](const TileIt& it) { if constexpr ((SEG_WABL & 8) != 0) { okB = full; } else if constexpr (DUAL) { if constexpr (IM) prefetch_im(it, xB, rzB, okB, intB); else prefetch(it, rpB, rzB, okB, intB); } };
   auto waitA = [&](bool younger) { if constexpr (IM) wait_set_im(xA, rzA, younger); else wait_set(rpA, rzA, younger); };
   auto waitB = [&](bool younger) { if constexpr (DUAL) { if constexpr (IM) wait_set_im(xB, rzB, younger); else wait_set(rpB, rzB, younger); } };
-  auto commitA = [&]() { if constexpr (IM) commit_im(xA, rzA, okA); else commit(rpA, rzA, okA); };
-  auto commitB = [&]() { if constexpr (DUAL) { if constexpr (IM) commit_im(xB, rzB, okB); else commit(rpB, rzB, okB); } };
+  auto commitA = [&]() { if constexpr ((SEG_WABL & 4) != 0) { asm volatile("" :: "v"(rpA[0]), "v"(rzA[0])); } else if constexpr (IM) commit_im(xA, rzA, okA, intA); else commit(rpA, rzA, okA, intA); };
+  auto commitB = [&]() { if constexpr ((SEG_WABL & 4) != 0) { asm volatile("" :: "v"(rpB[0]), "v"(rzB[0])); } else if constexpr (DUAL) { if constexpr (IM) commit_im(xB, rzB, okB, intB); else commit(rpB, rzB, okB, intB); } };
   int tile = blockIdx.y;
   const int ks_ = P.ksplit;
 #ifdef SEG_STAMPS
@@ -454,8 +501,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
       WSTAMP(1, it_);
       const bool moreA = tile + 2 * ks_ < P.ntiles;
       if (moreA) { tile_advance(itA, st2); prefetchA(itA); }
-      WSTAMP(2, it_);
       compute();
+      WSTAMP(2, it_);
 #ifdef SEG_STAMPS
       ++it_;
 #endif
@@ -468,8 +515,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
       WSTAMP(1, it_);
       youngerB = tile + 3 * ks_ < P.ntiles;
       if (youngerB) { tile_advance(itB, st2); prefetchB(itB); }
-      WSTAMP(2, it_);
       compute();
+      WSTAMP(2, it_);
 #ifdef SEG_STAMPS
       ++it_;
 #endif
@@ -876,6 +923,10 @@ extern "C" int seg_conv2d_wgrad(const seg_wgrad_desc* dp, void* stream) {
     seg_set_error("wgrad: logical channels exceed padded"); return SEG_ERR_ARG;
   }
   if (d.B <= 0 || d.Ho <= 0 || d.Wo <= 0 || d.Hi <= 0 || d.Wi <= 0) { seg_set_error("wgrad: empty extent"); return SEG_ERR_ARG; }
+  if ((int64_t)d.src0.H * d.src0.W * d.src0.cs >= ((int64_t)1 << 31) || (int64_t)d.dz.H * d.dz.W * d.dz.cs >= ((int64_t)1 << 31) ||
+      (d.src1.ptr && (int64_t)d.src1.H * d.src1.W * d.src1.cs >= ((int64_t)1 << 31))) {
+    seg_set_error("wgrad: an image plane of 2^31 elements or more is not supported"); return SEG_ERR_UNSUPPORTED;
+  }
   if (d.src0.oy + d.Hi > d.src0.H || d.src0.ox + d.Wi > d.src0.W || d.src0.coff + d.src0.c > d.src0.cs ||
       (d.src1.ptr && (d.src1.oy + d.Hi > d.src1.H || d.src1.ox + d.Wi > d.src1.W || d.src1.coff + d.src1.c > d.src1.cs)) ||
       d.dz.oy + d.Ho > d.dz.H || d.dz.ox + d.Wo > d.dz.W || d.dz.coff + d.dz.c > d.dz.cs) {

@@ -7,7 +7,7 @@ shift
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc "${ctrs[@]}" --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/tools/conv_micro.py "$@" > $out/run.log 2>&1
+rocprofv3 --pmc "${ctrs[@]}" --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/tools/${PMC_TOOL:-conv_micro.py} "$@" > $out/run.log 2>&1
 python3 - <<PY
 import csv,glob,collections
 f=glob.glob("$out/*/*counter_collection.csv")
@@ -17,7 +17,7 @@ for fn in f:
         k=r['Kernel_Name'][:60]
         agg[k][r['Counter_Name']]+=float(r['Counter_Value']); cnt[(k,r['Counter_Name'])]+=1
 for k,v in agg.items():
-    if 'conv' in k:
+    if 'conv' in k or 'head' in k or 'pool' in k:
         print(k, {c: round(x/cnt[(k,c)],1) for c,x in v.items()})
 PY
 tail -1 $out/run.log

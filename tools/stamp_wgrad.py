@@ -26,9 +26,15 @@ def run(hw, cin, cout, B=16):
         t0 = a[wg, 3, 0]
         n = int((a[wg, 0] > 0).sum())
         print(' split', wg, 'tiles', n, 'lifetime %.0f' % (a[wg, 3, 1] - t0))
-        print('   tile: loads_landed  committed  prefetch_issued | next loads_landed   (ticks since start)')
-        for i in range(min(n, 12)):
+        print('   tile: loads_landed  committed  computed   (ticks since start)')
+        for i in range(min(n, 6)):
             print('   %2d  %7.0f %7.0f %7.0f' % (i, a[wg, 0, i] - t0, a[wg, 1, i] - t0, a[wg, 2, i] - t0))
+        m = min(n, 32)
+        if m > 3:
+            wait = np.mean([a[wg, 0, i + 1] - a[wg, 2, i] for i in range(1, m - 1)])
+            commit = np.mean([a[wg, 1, i] - a[wg, 0, i] for i in range(1, m - 1)])
+            comp = np.mean([a[wg, 2, i] - a[wg, 1, i] for i in range(1, m - 1)])
+            print('   mean per tile: wait for loads %.0f, barrier+commit+barrier %.0f, prefetch issue + MFMA loop %.0f ticks' % (wait, commit, comp))
 import sys as _s
 for _a in ([tuple(int(v) for v in x.split(",")) for x in _s.argv[1:]] or [(122, 64, 64), (59, 128, 128)]):
     run(*_a)
