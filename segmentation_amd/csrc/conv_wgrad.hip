@@ -423,14 +423,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
     // the transposed reads of step s+LA are issued before the MFMA(s) of step s.  Left to itself the scheduler
     // batches reads far ahead (204 VGPRs -> 2 waves/SIMD) and still waits on LDS before most MFMAs.
     constexpr int NSTEP = KS * NT;
-    // X fragments in flight (steps ahead).  A step is FCI*FCO MFMAs = 16*FCI*FCO cycles of matrix-core time and a transposed
-    // LDS read under four waves' traffic takes ~250-300 cycles to return (s_memtime stamps, r02: with 3 steps ahead the
-    // 64 x 64 layout waited ~30 cycles on lgkmcnt at EVERY step), so the look-ahead is sized in cycles, not in steps.
-#ifndef SEG_WGRAD_LA_CLK
-#define SEG_WGRAD_LA_CLK 320
-#endif
-    constexpr int LA0 = (SEG_WGRAD_LA_CLK + 16 * FCI * FCO - 1) / (16 * FCI * FCO);
-    constexpr int LA = LA0 < 3 ? 3 : (LA0 > 12 ? 12 : LA0);
+    // X fragments in flight (steps ahead).  Deeper look-ahead (sized in cycles: 5 steps for the 64 x 64 layout, 12 for 32 x 32)
+    // was measured in r02: no change of the tile time on the s_memtime stamps -- the LDS latency is not what the loop waits
+    // for -- and in the f32 256-pixel-tile kernel the extra fragments pushed the register allocator past 256 VGPRs, where it
+    // parks values in AGPRs: a copy of a staging register made BEFORE the manual vmcnt wait captures a load that has not
+    // landed (conv3_2's f32 gradient came out as garbage).  The staging registers must stay where the asm loads put them,
+    // so the register budget of these kernels is part of their correctness: keep it small.
+    constexpr int LA = 3;
     constexpr int ZLA = NT >= LA ? 1 : LA;                 // dZ fragments in flight (K steps ahead)
     Frag<T> fx[LA + 1][FCI], fz[ZLA + 1][FCO];
     const int rs_off = u0 * PW * RSP;

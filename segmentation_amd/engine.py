@@ -391,7 +391,20 @@ class Plan(object):
             where = sites.pop(old, None)
             if where is None:
                 where = [(i, j) for i, (_, _, args) in enumerate(self.ops) for j, a in enumerate(args) if isinstance(a, int) and a == old]
-            for i, j in where:
+                # ... and the descriptors that carry the pointer inside (the first layer's filter gradient reads the input image
+                # through seg_wgrad_desc.im2col_x)
+                seen = set()
+                for _, _, args in self.ops:
+                    for a in args:
+                        d_ = getattr(a, '_obj', None)
+                        if isinstance(d_, L.WgradDesc) and id(d_) not in seen and d_.im2col_x == old:
+                            seen.add(id(d_)); where.append(('desc', d_))
+            for site in where:
+                if site[0] == 'desc':
+                    site[1].im2col_x = new; site[1].src0.ptr = new
+                    n += 1
+                    continue
+                i, j = site
                 name, fn, args = self.ops[i]
                 self.ops[i] = (name, fn, args[:j] + (new,) + args[j + 1:])
                 n += 1
