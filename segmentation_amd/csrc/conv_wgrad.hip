@@ -844,24 +844,23 @@ int launch_k(const WgK& P, hipStream_t st) {
       if (cost < best) { best = cost; cfg = c.cfg; }
     }
   } else if (cfg == 0) {
-    cfg = small ? 6 : 3;                                                                 // f32 (parity mode): 32 ci x 32 co
-    // large maps: 256-pixel tiles halve the barriers / staging rounds per MFMA (measured +5-8 % at >= 59x59)
-    if (!small && d.Ho >= 48 && d.Wo >= 48 && S == 1) cfg += 6;
+    cfg = (small || S == 2) ? 6 : 3;                                                     // f32 (parity mode): 32 ci x 32 co, 128 / 64 pixels
   }
-  if (S != 1 && (cfg == 8 || cfg == 9)) { seg_set_error("wgrad: 256-pixel tiles are stride-1 only (cfg %d)", cfg); return SEG_ERR_UNSUPPORTED; }
+  // The tile loads of this kernel are inline asm waited for by hand one or two tiles later: a staging register that the
+  // register allocator parks somewhere else in between (an AGPR copy, a scratch spill) captures a load that has not landed,
+  // and the register itself may be reused and then overwritten when the load does land (garbage gradients / a memory fault;
+  // both seen in r02 on instances that needed ~256 architectural VGPRs).  Only instances that stay well below 256 are
+  // offered -- tests/test_build.py checks the compiled ISA of every one -- which leaves out the r01 layouts with two X
+  // fragments per wave (cfg 1, 2, 4, 5, 8) and, for f32, the 256-pixel tile.
+  if (S != 1 && cfg == 9) { seg_set_error("wgrad: 256-pixel tiles are stride-1 only (cfg %d)", cfg); return SEG_ERR_UNSUPPORTED; }
   switch (cfg) {
-    case 1: return launch_cfg<T, 8, 16, KH, KW, S, 1, 4, 2, 2>(P, st);   // 128 px, 32 ci x 128 co
-    case 2: return launch_cfg<T, 8, 16, KH, KW, S, 1, 4, 2, 1>(P, st);   // 128 px, 32 ci x 64 co
-    case 3: return launch_cfg<T, 8, 16, KH, KW, S, 2, 2, 1, 1>(P, st);   // 128 px, 32 ci x 32 co
-    case 4: return launch_cfg<T, 8, 8, KH, KW, S, 1, 4, 2, 2>(P, st);    //  64 px
-    case 5: return launch_cfg<T, 8, 8, KH, KW, S, 1, 4, 2, 1>(P, st);
-    case 6: return launch_cfg<T, 8, 8, KH, KW, S, 2, 2, 1, 1>(P, st);
-    case 8: return launch_cfg<T, 16, 16, KH, KW, S, 1, 4, 2, 1>(P, st);  // 256 px, 32 ci x 64 co
-    case 9: return launch_cfg<T, 16, 16, KH, KW, S, 2, 2, 1, 1>(P, st);  // 256 px, 32 ci x 32 co
+    case 3: if constexpr (sizeof(T) == 2 || S == 1) return launch_cfg<T, 8, 16, KH, KW, S, 2, 2, 1, 1>(P, st); else break;   // 128 px, 32 ci x 32 co
+    case 6: return launch_cfg<T, 8, 8, KH, KW, S, 2, 2, 1, 1>(P, st);    //  64 px
     default: break;
   }
   if constexpr (sizeof(T) == 2) {
-    switch (cfg) {      // bf16 register-reuse layouts: a wave owns 16 ci x (16 FCO) co for all taps
+    switch (cfg) {      // bf16 only: the 256-pixel tile and the register-reuse layouts (a wave owns 16 ci x (16 FCO) co for all taps)
+      case 9: if constexpr (S == 1) return launch_cfg<T, 16, 16, KH, KW, S, 2, 2, 1, 1>(P, st); else break;  // 256 px, 32 ci x 32 co
       case 11: if constexpr (S == 1) return launch_cfg<T, 8, 16, KH, KW, S, 4, 1, 1, 4>(P, st); else break;  // 128 px, 64 ci x 64 co
       case 12: return launch_cfg<T, 8, 16, KH, KW, S, 2, 2, 1, 2>(P, st);  // 128 px, 32 ci x 64 co
       case 14: if constexpr (S == 1) return launch_cfg<T, 8, 8, KH, KW, S, 4, 1, 1, 4>(P, st); else break;   //  64 px, 64 ci x 64 co
@@ -869,7 +868,7 @@ int launch_k(const WgK& P, hipStream_t st) {
       default: break;
     }
   }
-  seg_set_error("wgrad: unknown cfg %d", cfg); return SEG_ERR_ARG;
+  seg_set_error("wgrad: layout cfg %d is not offered for this kernel / dtype (3, 6; bf16: 9, 11, 12, 14, 15)", cfg); return SEG_ERR_UNSUPPORTED;
 }
 
 template <typename T>

@@ -710,7 +710,7 @@ class Net(object):
         self._add_wgrad(plan, layer.name + '/dw', w, fl, sid=1 if (same_stream and col is not None) else None)
         plan.flops += fl
 
-    def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0):
+    def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0, ksplit=0):
         """Filter + bias gradient, then one dgrad launch per entry of dsrcs.
         dsrcs: list aligned with srcs; each None (no input gradient wanted) or
         (dst_act, (oy,ox), mask_act_or_None, (moy,mox))."""
@@ -726,7 +726,7 @@ class Net(object):
         w.dz = dz.view(dz_off[0], dz_off[1]); w.n_log = layer.cout
         w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = wcfg
         w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
-        self._wgrad_ws(w, plan)
+        self._wgrad_ws(w, plan, ksplit)
         fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
         self._wg_bytes = self.B * (Hi * Wi * layer.cin + Ho * Wo * layer.cout) * self.es + k * k * layer.cin * layer.cout * 4
         self._add_wgrad(plan, layer.name + '/dw', w, fl)
@@ -780,7 +780,7 @@ class Net(object):
                 plan.flops += fl
             n_off += layer.cin_p[i]
 
-    def up_bwd(self, plan, layer, src, Hi, Wi, dzu, dsrc, mask, cfg=0, wcfg=0):
+    def up_bwd(self, plan, layer, src, Hi, Wi, dzu, dsrc, mask, cfg=0, wcfg=0, ksplit=0):
         """src: input Act [Hi,Wi,cin]; dzu: masked grad of the upsampled output [2Hi,2Wi,cout]."""
         w = L.WgradDesc()
         w.src0 = dzu.view(); w.src1 = L.null_view(); w.src0_clog = layer.cout; w.src1_clog = 0
@@ -790,7 +790,7 @@ class Net(object):
         w.dz = src.view(); w.n_log = layer.cin
         w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = wcfg
         w.bias_mode = 2; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
-        self._wgrad_ws(w, plan)
+        self._wgrad_ws(w, plan, ksplit)
         fl = 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
         self._wg_bytes = self.B * Hi * Wi * (layer.cin + 4 * layer.cout) * self.es + 4 * layer.cin * layer.cout * 4
         self._add_wgrad(plan, layer.name + '/dw', w, fl)

@@ -219,6 +219,63 @@ def test_upconv_fwd_bwd(dtype, case):
 
 
 @pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('kind', ['conv3', 'conv1', 'up2'])
+@pytest.mark.parametrize('wcfg', [3, 6, 9, 11, 12, 14, 15])
+def test_wgrad_every_instance_on_a_long_tile_walk(dtype, kind, wcfg):
+    """Every instantiated filter-gradient layout, both dtypes, with few K splits so that each workgroup walks > 10 tiles:
+    the kernel keeps one or two tiles of asm-issued global loads in flight across its MFMA section and waits for them by
+    hand, so a register-allocation accident (a staging register parked elsewhere before the wait -- seen once with a
+    deeper LDS look-ahead in the f32 256-pixel kernel) shows up as a garbage gradient in exactly this situation."""
+    if wcfg >= 9 and dtype != L.SEG_BF16:
+        pytest.skip('bf16-only layouts')
+    B, H, W, cin, cout = 2, 70, 66, 64, 128
+    rng = np.random.default_rng(wcfg * 17 + len(kind))
+    store_g = None
+    if kind == 'up2':
+        layer = E.Layer('u', 'up', 2, [cin], cout, 'VALID', True)
+        p = {'u': _rand_params(layer, rng, dtype)}
+        store = U.make_store([layer], dtype, p)
+        net = E.Net(store, B, dtype, U.dev())
+        Hs, Ws = H // 2, W // 2
+        xa = net.act(Hs, Ws, cin); xv = U.round_dtype(rng.standard_normal((B, Hs, Ws, cin)), dtype); U.fill_act(xa, xv)
+        dzv = U.round_dtype(rng.standard_normal((B, 2 * Hs, 2 * Ws, cout)) * 0.5, dtype)
+        dz = net.act(2 * Hs, 2 * Ws, cout); U.fill_act(dz, dzv)
+        dx = net.act(Hs, Ws, cin)
+        bplan = E.Plan('b')
+        try:
+            net.up_bwd(bplan, layer, xa, Hs, Ws, dz, dx, xa, wcfg=wcfg, ksplit=2)
+        except L.SegError as e:
+            pytest.skip('layout not offered for this kernel: %s' % e)
+        dw_ref, db_ref = ops.conv2d_transpose_wgrad(xv, dzv, (2, 2), 2, 'VALID')
+        key = 'u'
+    else:
+        k = 3 if kind == 'conv3' else 1
+        layer = E.Layer('c', 'conv', k, [cin], cout, 'VALID', True)
+        p = {'c': _rand_params(layer, rng, dtype)}
+        store = U.make_store([layer], dtype, p)
+        net = E.Net(store, B, dtype, U.dev())
+        a = net.act(H, W, cin); xv = U.round_dtype(rng.standard_normal((B, H, W, cin)), dtype); U.fill_act(a, xv)
+        Ho, Wo = H - k + 1, W - k + 1
+        dzv = U.round_dtype(rng.standard_normal((B, Ho, Wo, cout)) * 0.5, dtype)
+        dz = net.act(Ho, Wo, cout); U.fill_act(dz, dzv)
+        bplan = E.Plan('b')
+        try:
+            net.conv_bwd(bplan, layer, [(a, 0, 0)], H, W, dz, [None], wcfg=wcfg, ksplit=2)
+        except L.SegError as e:
+            pytest.skip('layout not offered for this kernel: %s' % e)
+        dw_ref, db_ref = ops.conv2d_wgrad(xv, dzv, (k, k), 'VALID', 1)
+        key = 'c'
+    net.flush_reduce(bplan)
+    store.g.fill_(float('nan'))
+    bplan.run(U.stream()); U.sync()
+    g = store.get_grads()[key]
+    name = bplan.kernel_name(0)
+    assert np.isfinite(g['weights']).all() and np.isfinite(g['biases']).all(), name
+    assert U.rel_err(g['weights'], dw_ref) < U.tol(dtype, 5e-5, 1e-2), 'wgrad ' + name
+    assert U.rel_err(g['biases'], db_ref) < U.tol(dtype, 5e-5, 1e-2), 'bias grad ' + name
+
+
+@pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('pad,cin,cout,H', [(0, 3, 32, 21), (1, 3, 16, 18), (0, 1, 40, 33), (1, 2, 64, 20), (0, 3, 32, 64)])
 def test_conv_first(dtype, pad, cin, cout, H, monkeypatch):
     B, W = 2, H + 3
