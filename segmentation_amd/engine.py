@@ -223,6 +223,20 @@ def _signal_state(main):
     return st
 
 
+_CFG_OV = None
+
+
+def _cfg_overrides():
+    global _CFG_OV
+    if _CFG_OV is None:
+        _CFG_OV = {}
+        for kv in os.environ.get('SEG_CFG_OVERRIDE', '').split(','):
+            if '=' in kv:
+                k, v = kv.split('=')
+                _CFG_OV[k.strip()] = int(v)
+    return _CFG_OV
+
+
 class Plan(object):
     """Ordered list of C-ABI launches.  Every entry is (name, fn, args-without-stream)."""
 
@@ -234,6 +248,9 @@ class Plan(object):
         self.flops = 0
 
     def add(self, name, fn, *args, **meta):
+        ov = _cfg_overrides()
+        if ov and name in ov and meta.get('desc') is not None:
+            meta['desc'].cfg = ov[name]                   # (tile-choice experiments: SEG_CFG_OVERRIDE="conv5_1/dx0=1,conv5_2=11")
         self.ops.append((name, fn, args))
         self.meta.append(meta)
 
