@@ -230,6 +230,11 @@ def main():
             raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
         spawn_ranks(args)                          # does not return
 
+    # stdout carries exactly ONE line, the JSON record: whatever the library prints while it builds the model (the reference's
+    # own 'Training from scratch...' notice among it) goes to stderr
+    json_out = sys.stdout
+    sys.stdout = sys.stderr
+
     import numpy as np
     import torch
     torch.cuda.set_device(local)
@@ -412,7 +417,8 @@ def main():
     elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = None                  # (the torch-CPU stepper covers the U-Net graph only)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out)
+        json_out.flush()
     if world > 1 or args.force_dist:
         torch.distributed.destroy_process_group()
 

@@ -766,8 +766,7 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
   const int64_t bias_len = P.k_pad > P.n_pad ? P.k_pad : P.n_pad;
   P.slab = (int64_t)KH * KW * P.k_pad * P.n_pad + bias_len;
   if (g_wname_out) {
-    if (IMC) snprintf(g_wname_out, g_wname_cap, "conv_wgrad_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", ES == 2 ? "bf16" : "f32", TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, rs ? 1 : 0, IMC);
-    else snprintf(g_wname_out, g_wname_cap, "conv_wgrad_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", ES == 2 ? "bf16" : "f32", TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, rs ? 1 : 0);
+    snprintf(g_wname_out, g_wname_cap, "conv_wgrad_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", ES == 2 ? "bf16" : "f32", TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, rs ? 1 : 0, IMC);
     return SEG_OK;
   }
   if (g_plan_ks) { *g_plan_ks = ks; *g_plan_bytes = P.direct ? 0 : P.slab * ks * 4; return SEG_OK; }

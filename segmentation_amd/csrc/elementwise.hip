@@ -1067,10 +1067,10 @@ extern "C" int seg_softmax_xent(const seg_view* logits, const uint8_t* labels, i
 // Workgroups of a seg_head_xent launch (its grid is a function of the shape only, so the partial-sum workspace can be sized
 // and reduced without the launch being replayed).
 static int head_xent_grid(int64_t B, int64_t H, int64_t W, int cpad) {
-  static const int cap_ = getenv("SEG_HEAD_CAP") ? atoi(getenv("SEG_HEAD_CAP")) : 2048;
-  static const int it_ = getenv("SEG_HEAD_ITERS") ? atoi(getenv("SEG_HEAD_ITERS")) : 4;
-  const int64_t px_per_wg = 256 / (cpad / 8) * (int64_t)(it_ > 0 ? it_ : 1);
-  return grid_for(B * H * W, (int)px_per_wg, cap_ > 0 ? cap_ : 2048);
+  // >= 4 pixels per lane group (a 68 x 68 map: 289 workgroups), at most 2048 workgroups (512 x 512: ~13 pixels each): the
+  // per-workgroup partial row and the loss atomic stay cheap (16 k workgroups doubled the kernel time on the atomic alone)
+  const int64_t px_per_wg = 256 / (cpad / 8) * 4;
+  return grid_for(B * H * W, (int)px_per_wg, 2048);
 }
 static int head_ncp(int n_classes) { return n_classes <= 4 ? 4 : n_classes <= 8 ? 8 : n_classes <= 16 ? 16 : 32; }
 
