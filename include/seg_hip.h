@@ -249,9 +249,13 @@ int seg_pack_weights_dual(const float* arena, void* packed, const seg_pack_entry
 int seg_bilinear_up_fwd(const seg_view* src, int32_t Hs, int32_t Ws, int32_t factor, const float* filt,
                         const seg_view* add, const seg_view* dst, int32_t Hd, int32_t Wd,
                         int32_t cy, int32_t cx, int32_t B, int32_t C, int32_t dst_f32, int32_t dtype, void* stream);
+/* mask_act / dz_masked (both or neither): ALSO store the gradient behind the ReLU of mask_act, dz_masked = dsrc * (mask_act > 0)
+ * -- the score convolutions of the FCN skip fusion keep their ReLU (models/fcn.py:149-170), and their backward wants exactly
+ * that tensor; saves a relu-grad launch per fusion level. */
 int seg_bilinear_up_bwd(const seg_view* ddst, int32_t Hd, int32_t Wd, int32_t cy, int32_t cx,
                         int32_t factor, const float* filt, const seg_view* dsrc, int32_t Hs, int32_t Ws,
-                        int32_t B, int32_t C, int32_t ddst_f32, int32_t dtype, void* stream);
+                        int32_t B, int32_t C, int32_t ddst_f32, const seg_view* mask_act, const seg_view* dz_masked,
+                        int32_t dtype, void* stream);
 
 /* The FCN training head in one launch: logits = the (cropped) bilinear up-sampling of the score map, softmax x-entropy against
  * the labels, dlogits -- models/fcn.py:199-218 + models/basemodel.py:59-70 -- without materialising the float logits
@@ -267,7 +271,7 @@ int seg_bilinear_xent(const seg_view* src, int32_t Hs, int32_t Ws, int32_t facto
 int64_t seg_bilinear_up_bwd_ws_bytes(int32_t B, int32_t Hd, int32_t Ws, int32_t C);
 int seg_bilinear_up_bwd_sep(const seg_view* ddst, int32_t Hd, int32_t Wd, int32_t cy, int32_t cx, int32_t factor, const float* filt,
                             const seg_view* dsrc, int32_t Hs, int32_t Ws, int32_t B, int32_t C, int32_t ddst_f32, float* ws,
-                            int64_t ws_bytes, int32_t dtype, void* stream);
+                            int64_t ws_bytes, const seg_view* mask_act, const seg_view* dz_masked, int32_t dtype, void* stream);
 
 /* out = a * (relu_mask>0) elementwise over a [B,H,W,C] window (ReLU-grad where no conv epilogue can do it). */
 int seg_relu_grad(const seg_view* dy, const seg_view* y_act, const seg_view* dz,

@@ -85,9 +85,9 @@ SIGNATURES = {
     'seg_pack_weights': [vp, vp, vp, i32, i64, i32, vp],
     'seg_pack_weights_dual': [vp, vp, vp, vp, i32, i64, i32, vp],
     'seg_bilinear_up_fwd': [PV, i32, i32, i32, vp, PV, PV, i32, i32, i32, i32, i32, i32, i32, i32, vp],
-    'seg_bilinear_up_bwd': [PV, i32, i32, i32, i32, i32, vp, PV, i32, i32, i32, i32, i32, i32, vp],
+    'seg_bilinear_up_bwd': [PV, i32, i32, i32, i32, i32, vp, PV, i32, i32, i32, i32, i32, PV, PV, i32, vp],
     'seg_bilinear_xent': [PV, i32, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, PV, PV, i32, vp],
-    'seg_bilinear_up_bwd_sep': [PV, i32, i32, i32, i32, i32, vp, PV, i32, i32, i32, i32, i32, vp, C.c_int64, i32, vp],
+    'seg_bilinear_up_bwd_sep': [PV, i32, i32, i32, i32, i32, vp, PV, i32, i32, i32, i32, i32, vp, C.c_int64, PV, PV, i32, vp],
     'seg_relu_grad': [PV, PV, PV, i32, i32, i32, i32, i32, vp],
     'seg_dropout': [PV, PV, i32, i32, i32, i32, f32, u64, u64, i32, vp],
     'seg_cast_pad': [vp, i64, i32, PV, i32, vp],

@@ -784,7 +784,7 @@ __global__ void bilinear_fwd_kernel(seg_view src, int Hs, int Ws, int f, const f
 // fixed butterfly.  (One thread per source pixel walked all k*k = 256 taps of the 8x layer alone: 131 k threads for a 134 MB
 // tensor, 146 us per FCN-8s step.)
 template <typename T, int LP>
-__global__ void bilinear_bwd_kernel(seg_view dd, int Hd, int Wd, int cy, int cx, int f, const float* filt, seg_view ds,
+__global__ void bilinear_bwd_kernel(seg_view mk, seg_view dzm, seg_view dd, int Hd, int Wd, int cy, int cx, int f, const float* filt, seg_view ds,
                                     int Hs, int Ws, int B, int C8, int dd_f32) {
   const int k = 2 * f - f % 2, pb = (k - f) / 2;
   const int64_t total = (int64_t)B * Hs * Ws * C8 * LP;
@@ -817,6 +817,11 @@ __global__ void bilinear_bwd_kernel(seg_view dd, int Hd, int Wd, int cy, int cx,
     if (on && r == 0) {
       Vec8<T> o; for (int e = 0; e < 8; ++e) o.set(e, a[e]);
       o.store(reinterpret_cast<T*>(ds.ptr) + view_off(ds, b, iy, ix) + c8 * 8);
+      if (dzm.ptr != nullptr) {          // the same gradient behind the ReLU of `mk` (the score convolution's own activation)
+        Vec8<T> m; m.load(reinterpret_cast<const T*>(mk.ptr) + view_off(mk, b, iy, ix) + c8 * 8);
+        for (int e = 0; e < 8; ++e) o.set(e, m.get(e) > 0.f ? o.get(e) : 0.f);
+        o.store(reinterpret_cast<T*>(dzm.ptr) + view_off(dzm, b, iy, ix) + c8 * 8);
+      }
     }
   }
 }
@@ -944,7 +949,7 @@ __global__ void bilinear_bwd_h_kernel(seg_view dd, int Hd, int Wd, int cx, int f
 }
 
 template <typename T>
-__global__ void bilinear_bwd_v_kernel(const float* tmp, int Hd, int cy, int f, const float* filt, seg_view ds, int Hs, int Ws, int B, int C8) {
+__global__ void bilinear_bwd_v_kernel(seg_view mk, seg_view dzm, const float* tmp, int Hd, int cy, int f, const float* filt, seg_view ds, int Hs, int Ws, int B, int C8) {
   const int k = 2 * f - f % 2, pb = (k - f) / 2, c0 = (k - 1) / 2;
   const float nrm = rsqrtf(filt[c0 * k + c0]);
   const int64_t total = (int64_t)B * Hs * Ws * C8;
@@ -961,6 +966,11 @@ __global__ void bilinear_bwd_v_kernel(const float* tmp, int Hd, int cy, int f, c
     }
     Vec8<T> o; for (int e = 0; e < 8; ++e) o.set(e, a[e]);
     o.store(reinterpret_cast<T*>(ds.ptr) + view_off(ds, b, iy, ix) + c8 * 8);
+    if (dzm.ptr != nullptr) {
+      Vec8<T> m; m.load(reinterpret_cast<const T*>(mk.ptr) + view_off(mk, b, iy, ix) + c8 * 8);
+      for (int e = 0; e < 8; ++e) o.set(e, m.get(e) > 0.f ? o.get(e) : 0.f);
+      o.store(reinterpret_cast<T*>(dzm.ptr) + view_off(dzm, b, iy, ix) + c8 * 8);
+    }
   }
 }
 
@@ -1202,11 +1212,13 @@ extern "C" int seg_bilinear_up_fwd(const seg_view* src, int32_t Hs, int32_t Ws, 
 }
 
 extern "C" int seg_bilinear_up_bwd(const seg_view* ddst, int32_t Hd, int32_t Wd, int32_t cy, int32_t cx, int32_t factor, const float* filt,
-                                   const seg_view* dsrc, int32_t Hs, int32_t Ws, int32_t B, int32_t C, int32_t ddst_f32, int32_t dtype,
-                                   void* stream) {
+                                   const seg_view* dsrc, int32_t Hs, int32_t Ws, int32_t B, int32_t C, int32_t ddst_f32,
+                                   const seg_view* mask_act, const seg_view* dz_masked, int32_t dtype, void* stream) {
   if (!view_ok(ddst, Hd, Wd, C) || !view_ok(dsrc, Hs, Ws, C) || !filt || factor < 1 || C % 8) { seg_set_error("bilinear_bwd: bad args"); return SEG_ERR_ARG; }
+  if ((mask_act != nullptr) != (dz_masked != nullptr) || (mask_act && (!view_ok(mask_act, Hs, Ws, C) || !view_ok(dz_masked, Hs, Ws, C)))) { seg_set_error("bilinear_bwd: bad masked output"); return SEG_ERR_ARG; }
+  const seg_view mkv = mask_act ? *mask_act : null_view(), dzv = dz_masked ? *dz_masked : null_view();
   const int64_t n = (int64_t)B * Hs * Ws * (C / 8);
-#define BIL_BWD(TT, LP) SEG_LAUNCH((bilinear_bwd_kernel<TT, LP>), dim3(grid_for(n * LP, 256, 16384)), dim3(256), 0, ST(stream), *ddst, Hd, Wd, cy, cx, factor, filt, *dsrc, Hs, Ws, B, C / 8, ddst_f32)
+#define BIL_BWD(TT, LP) SEG_LAUNCH((bilinear_bwd_kernel<TT, LP>), dim3(grid_for(n * LP, 256, 16384)), dim3(256), 0, ST(stream), mkv, dzv, *ddst, Hd, Wd, cy, cx, factor, filt, *dsrc, Hs, Ws, B, C / 8, ddst_f32)
 #define BIL_BWD_F(TT) do { if (factor >= 8) BIL_BWD(TT, 16); else if (factor >= 2) BIL_BWD(TT, 4); else BIL_BWD(TT, 1); } while (0)
   DISPATCH(dtype, BIL_BWD_F(float), BIL_BWD_F(bf16_t));
 #undef BIL_BWD_F
@@ -1248,7 +1260,9 @@ extern "C" int64_t seg_bilinear_up_bwd_ws_bytes(int32_t B, int32_t Hd, int32_t W
 
 extern "C" int seg_bilinear_up_bwd_sep(const seg_view* ddst, int32_t Hd, int32_t Wd, int32_t cy, int32_t cx, int32_t factor, const float* filt,
                                        const seg_view* dsrc, int32_t Hs, int32_t Ws, int32_t B, int32_t C, int32_t ddst_f32, float* ws,
-                                       int64_t ws_bytes, int32_t dtype, void* stream) {
+                                       int64_t ws_bytes, const seg_view* mask_act, const seg_view* dz_masked, int32_t dtype, void* stream) {
+  if ((mask_act != nullptr) != (dz_masked != nullptr) || (mask_act && (!view_ok(mask_act, Hs, Ws, C) || !view_ok(dz_masked, Hs, Ws, C)))) { seg_set_error("bilinear_bwd_sep: bad masked output"); return SEG_ERR_ARG; }
+  const seg_view mkv = mask_act ? *mask_act : null_view(), dzv = dz_masked ? *dz_masked : null_view();
   if (!view_ok(ddst, Hd, Wd, C) || !view_ok(dsrc, Hs, Ws, C) || !filt || factor < 1 || C % 8 || !ws || ws_bytes < seg_bilinear_up_bwd_ws_bytes(B, Hd, Ws, C)) { seg_set_error("bilinear_bwd_sep: bad args / workspace"); return SEG_ERR_ARG; }
   const int64_t n1 = (int64_t)B * Hd * Ws * (C / 8), n2 = (int64_t)B * Hs * Ws * (C / 8);
   DISPATCH(dtype,
@@ -1256,7 +1270,7 @@ extern "C" int seg_bilinear_up_bwd_sep(const seg_view* ddst, int32_t Hd, int32_t
            SEG_LAUNCH(bilinear_bwd_h_kernel<bf16_t>, dim3(grid_for(n1, 256, 16384)), dim3(256), 0, ST(stream), *ddst, Hd, Wd, cx, factor, filt, ws, Ws, B, C / 8, ddst_f32));
   if (int rc = seg_check_launch("bilinear_bwd_h")) return rc;
   DISPATCH(dtype,
-           SEG_LAUNCH(bilinear_bwd_v_kernel<float>, dim3(grid_for(n2, 256, 16384)), dim3(256), 0, ST(stream), (const float*)ws, Hd, cy, factor, filt, *dsrc, Hs, Ws, B, C / 8),
-           SEG_LAUNCH(bilinear_bwd_v_kernel<bf16_t>, dim3(grid_for(n2, 256, 16384)), dim3(256), 0, ST(stream), (const float*)ws, Hd, cy, factor, filt, *dsrc, Hs, Ws, B, C / 8));
+           SEG_LAUNCH(bilinear_bwd_v_kernel<float>, dim3(grid_for(n2, 256, 16384)), dim3(256), 0, ST(stream), mkv, dzv, (const float*)ws, Hd, cy, factor, filt, *dsrc, Hs, Ws, B, C / 8),
+           SEG_LAUNCH(bilinear_bwd_v_kernel<bf16_t>, dim3(grid_for(n2, 256, 16384)), dim3(256), 0, ST(stream), mkv, dzv, (const float*)ws, Hd, cy, factor, filt, *dsrc, Hs, Ws, B, C / 8));
   return seg_check_launch("bilinear_bwd_v");
 }

@@ -864,21 +864,25 @@ class Net(object):
                  kernel='bilinear_fwd_kernel')
         return cy, cx
 
-    def bilinear_bwd(self, plan, ddst, Hd, Wd, factor, filt, dsrc, Hs, Ws):
+    def bilinear_bwd(self, plan, ddst, Hd, Wd, factor, filt, dsrc, Hs, Ws, mask=None, dz=None):
+        """dsrc = adjoint of bilinear_fwd wrt its source.  mask / dz (Acts shaped like dsrc): also dz = dsrc * (mask > 0), the
+        gradient behind the ReLU of the activation `mask` (one launch instead of a relu_grad behind this one)."""
         cy = (Hs * factor - Hd) // 2 if Hs * factor >= Hd else -((Hd - Hs * factor) // 2)
         cx = (Ws * factor - Wd) // 2 if Ws * factor >= Wd else -((Wd - Ws * factor) // 2)
         gv, sv = ddst.view(), dsrc.view()
-        plan.keep += [gv, sv, filt]
+        mv, zv = (mask.view(), dz.view()) if mask is not None else (None, None)
+        plan.keep += [gv, sv, filt, mv, zv]
+        mp, zp = (C.byref(mv), C.byref(zv)) if mask is not None else (None, None)
         if factor >= 4:
             # big factors: separable form (2k instead of k*k taps, the gradient map read once instead of four times)
             nb = int(self.lib.seg_bilinear_up_bwd_ws_bytes(self.B, Hd, Ws, dsrc.Cp))
             ws = torch.empty(nb // 4, dtype=torch.float32, device=self.device)
             plan.keep.append(ws)
             plan.add('bilinear_up%d/bwd' % factor, self.lib.seg_bilinear_up_bwd_sep, C.byref(gv), Hd, Wd, cy, cx, factor, filt.data_ptr(),
-                     C.byref(sv), Hs, Ws, self.B, dsrc.Cp, 0, ws.data_ptr(), nb, self.dtype, kernel='bilinear_bwd_h_kernel')
+                     C.byref(sv), Hs, Ws, self.B, dsrc.Cp, 0, ws.data_ptr(), nb, mp, zp, self.dtype, kernel='bilinear_bwd_h_kernel')
             return
         plan.add('bilinear_up%d/bwd' % factor, self.lib.seg_bilinear_up_bwd, C.byref(gv), Hd, Wd, cy, cx, factor, filt.data_ptr(),
-                 C.byref(sv), Hs, Ws, self.B, dsrc.Cp, 0, self.dtype, kernel='bilinear_bwd_kernel')
+                 C.byref(sv), Hs, Ws, self.B, dsrc.Cp, 0, mp, zp, self.dtype, kernel='bilinear_bwd_kernel')
 
     def bilinear_xent(self, plan, src, Hs, Ws, factor, filt, labels_u8, LH, LW, loff, H, W, n_classes, loss_buf, dlogits, logits=None):
         """logits = crop_or_pad(up_factor(src), H, W); mean softmax x-entropy; dlogits -- one launch (seg_bilinear_xent).  logits:

@@ -195,35 +195,35 @@ class FCNModel(BaseModel):
         def act_like(a, name):
             return net.act(a.H, a.W, a.C, name=name)
 
-        def score_bwd(score_name, src_pool, dfuse, dpool):
-            """dfuse = gradient of (score + cropped up-sampled stream); the score conv keeps its ReLU."""
-            dz = act_like(A[score_name], 'dz_' + score_name)
-            net.relu_grad(seg, dfuse, A[score_name], dz, dz.H, dz.W)
+        def score_bwd(score_name, src_pool, dz, dpool):
+            """dz = gradient of (score + cropped up-sampled stream) behind the score conv's own ReLU (written by the bilinear
+            adjoint that produced the fused gradient)."""
             net.conv_bwd(seg, Ly[score_name], [(src_pool, 0, 0)], src_pool.H, src_pool.W, dz, [(dpool, (0, 0), None, (0, 0))])
 
         fr = A['conv_fr']
         dfr = act_like(fr, 'd_conv_fr')
+        dzfr = act_like(fr, 'dz_conv_fr')
         dP3 = dP4 = None
         src_name, f_final = geo['final']
         if self.fcn_type == '32s':
-            net.bilinear_bwd(seg, dlog, H, W, 32, self._filt(32), dfr, fr.H, fr.W)
+            net.bilinear_bwd(seg, dlog, H, W, 32, self._filt(32), dfr, fr.H, fr.W, mask=fr, dz=dzfr)
         else:
             p4 = A['pool4']
             dP4 = act_like(p4, 'dpool4')
             dfuse4 = act_like(A['fuse4'], 'd_fuse4')
+            dz4 = act_like(A['pool4_score'], 'dz_pool4_score')
             if self.fcn_type == '16s':
-                net.bilinear_bwd(seg, dlog, H, W, 16, self._filt(16), dfuse4, p4.H, p4.W)
+                net.bilinear_bwd(seg, dlog, H, W, 16, self._filt(16), dfuse4, p4.H, p4.W, mask=A['pool4_score'], dz=dz4)
             else:
                 p3 = A['pool3']
                 dP3 = act_like(p3, 'dpool3')
                 dfuse3 = act_like(A['fuse3'], 'd_fuse3')
-                net.bilinear_bwd(seg, dlog, H, W, 8, self._filt(8), dfuse3, p3.H, p3.W)
-                score_bwd('pool3_score', p3, dfuse3, dP3)
-                net.bilinear_bwd(seg, dfuse3, p3.H, p3.W, 2, self._filt(2), dfuse4, p4.H, p4.W)
-            score_bwd('pool4_score', p4, dfuse4, dP4)
-            net.bilinear_bwd(seg, dfuse4, p4.H, p4.W, 2, self._filt(2), dfr, fr.H, fr.W)
-        dzfr = act_like(fr, 'dz_conv_fr')
-        net.relu_grad(seg, dfr, fr, dzfr, fr.H, fr.W)
+                dz3 = act_like(A['pool3_score'], 'dz_pool3_score')
+                net.bilinear_bwd(seg, dlog, H, W, 8, self._filt(8), dfuse3, p3.H, p3.W, mask=A['pool3_score'], dz=dz3)
+                score_bwd('pool3_score', p3, dz3, dP3)
+                net.bilinear_bwd(seg, dfuse3, p3.H, p3.W, 2, self._filt(2), dfuse4, p4.H, p4.W, mask=A['pool4_score'], dz=dz4)
+            score_bwd('pool4_score', p4, dz4, dP4)
+            net.bilinear_bwd(seg, dfuse4, p4.H, p4.W, 2, self._filt(2), dfr, fr.H, fr.W, mask=fr, dz=dzfr)
         dz7 = act_like(A['conv7'], 'dz_conv7')
         net.conv_bwd(seg, Ly['conv_fr'], [(A['conv7'], 0, 0)], fr.H, fr.W, dzfr, [(dz7, (0, 0), A['conv7'], (0, 0))])
         dz6 = act_like(A['conv6'], 'dz_conv6')

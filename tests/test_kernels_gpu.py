@@ -501,17 +501,25 @@ def test_bilinear_up(dtype, f, Hs, Hd, add):
     ga = net.act(Hd, Hd, Cc); U.fill_act(ga, gv)
     dsa = net.act(Hs, Hs, Cc)
     g_v, ds_v = ga.view(), dsa.view()
-    L.check(lib.seg_bilinear_up_bwd(C.byref(g_v), Hd, Hd, cy, cy, f, ft.data_ptr(), C.byref(ds_v), Hs, Hs, B, sa.Cp, 0, dtype, U.stream()))
+    # ... with the gradient behind a ReLU as a second output (mask = the source activation here)
+    dza = net.act(Hs, Hs, Cc); m_v, dz_v = sa.view(), dza.view()
+    L.check(lib.seg_bilinear_up_bwd(C.byref(g_v), Hd, Hd, cy, cy, f, ft.data_ptr(), C.byref(ds_v), Hs, Hs, B, sa.Cp, 0, C.byref(m_v), C.byref(dz_v), dtype, U.stream()))
     U.sync()
+    got_ds = U.read_act(dsa)
+    assert np.array_equal(U.read_act(dza), got_ds * (U.read_act(sa) > 0))
     gref = ops.conv2d_transpose_dgrad(ops.crop_or_pad_bwd(gv, (Hs * f, Hs * f)), ops.bilinear_upsample_weights(f, Cc), (Hs, Hs), f, 'SAME')
     assert U.rel_err(U.read_act(dsa), gref) < U.tol(dtype, 1e-6, 1e-2)
     # the separable form of the adjoint (horizontal pass into a float workspace, then vertical)
     nb = int(lib.seg_bilinear_up_bwd_ws_bytes(B, Hd, Hs, sa.Cp))
     ws = torch.empty(nb // 4, dtype=torch.float32, device=U.dev())
     dsa.t.fill_(3.0)
-    L.check(lib.seg_bilinear_up_bwd_sep(C.byref(g_v), Hd, Hd, cy, cy, f, ft.data_ptr(), C.byref(ds_v), Hs, Hs, B, sa.Cp, 0, ws.data_ptr(), nb, dtype, U.stream()))
+    dza.t.fill_(5.0)
+    L.check(lib.seg_bilinear_up_bwd_sep(C.byref(g_v), Hd, Hd, cy, cy, f, ft.data_ptr(), C.byref(ds_v), Hs, Hs, B, sa.Cp, 0, ws.data_ptr(), nb, C.byref(m_v), C.byref(dz_v), dtype, U.stream()))
     U.sync()
     assert U.rel_err(U.read_act(dsa), gref) < U.tol(dtype, 2e-6, 1e-2) and U.pad_channels_zero(dsa)
+    assert np.array_equal(U.read_act(dza), U.read_act(dsa) * (U.read_act(sa) > 0)) and U.pad_channels_zero(dza)
+    L.check(lib.seg_bilinear_up_bwd_sep(C.byref(g_v), Hd, Hd, cy, cy, f, ft.data_ptr(), C.byref(ds_v), Hs, Hs, B, sa.Cp, 0, ws.data_ptr(), nb, None, None, dtype, U.stream()))
+    U.sync()
 
 
 @pytest.mark.parametrize('dtype', DT)
