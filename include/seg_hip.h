@@ -118,6 +118,14 @@ typedef struct seg_wgrad_desc {
    * out as the [3][3][cin][n] HWIO filter gradient. */
   const float* im2col_x;
   int32_t im2col_h, im2col_w, im2col_cin, im2col_pad;
+  /* ... and (bf16) pool_y.ptr != NULL makes dz VIRTUAL as well: the gradient of the layer's own activation pool_y [B,Ho,Wo,n]
+   * rebuilt while the tiles are staged from the 2x2/s2 max-pool that consumes it -- exactly seg_maxpool2x2_bwd:
+   *   dz = (pool_y > 0) * (pool_dp routed to the first maximum of each window + pool_add inside its window)
+   * pool_dp [B,Ho/2,Wo/2,n] (ptr NULL: no routing); pool_add (ptr NULL: none) = gradient from the layer's other consumer, a
+   * [pool_add_h, pool_add_w] window whose pixel (0,0) is pixel (pool_add_y0, pool_add_x0) of the map (the U-Net's conv1_2 data
+   * gradient).  dz.ptr is then not dereferenced (dz.c = n still describes the channel padding). */
+  seg_view pool_y, pool_dp, pool_add;
+  int32_t pool_add_h, pool_add_w, pool_add_y0, pool_add_x0;
 } seg_wgrad_desc;
 int seg_conv2d_wgrad(const seg_wgrad_desc* d, void* stream);
 int seg_conv2d_wgrad_plan(const seg_wgrad_desc* d, int32_t* ksplit, int64_t* ws_bytes);

@@ -99,7 +99,9 @@ template <int DT, int TH, int TW, int KH, int KW, int S, int WCI, int WCO, int F
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   using T = typename DtSel<DT>::type;
   constexpr bool IM = IMC > 0;
-  using XV = typename XVsel<IM ? IMC : 1>::type;
+  constexpr int ICH = IMC & 3;                   // input channels of the virtual im2col source
+  constexpr bool PDZ = (IMC & 4) != 0;           // dZ is virtual too: rebuilt from the 2x2 max-pool that consumes this layer (below)
+  using XV = typename XVsel<IM ? ICH : 1>::type;
   constexpr int BM = TH * TW;
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW, NPIX = PH * PW;
   constexpr int NU = RS ? 1 : KH;
@@ -124,7 +126,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   constexpr int KS = BM / 32;
   static_assert(WCI * WCO == 4 && (CIT == 32 || CIT == 64), "wave layout");
   static_assert(BM % 32 == 0, "tile pixels");
-  static_assert(!IM || (KH == 1 && KW == 1 && S == 1 && BM == 256 && CIT == 32 && IMC <= 3), "im2col staging: one tile pixel per thread");
+  static_assert(!IM || (KH == 1 && KW == 1 && S == 1 && BM == 256 && CIT == 32 && ICH >= 1), "im2col staging: one tile pixel per thread");
+  static_assert(!PDZ || (sizeof(T) == 2 && BN == 32 && TH == 16 && TW == 16), "pooled-dZ staging: one (window, 8-channel group) per thread");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sP = smem;
@@ -191,11 +194,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   // Every load is issued unconditionally (clamped address; a bit mask remembers which pieces to zero), so each
   // prefetch is exactly NLD wave-instructions and "the other set is younger" is vmcnt(NLD).
   constexpr int NXL = IM ? 9 : NPP;               // loads per thread for the X side of a tile
-  constexpr int NLD = NXL + NZP;
+  constexpr int NZL = PDZ ? 9 : NZP;              // ... and for the dZ side (pooled-dZ staging: 4 activations, 1 pooled gradient, 4 skip gradients)
+  constexpr int NLD = NXL + NZL;
   static_assert(NLD <= 60, "vmcnt range / mask bits");
-  constexpr bool DUAL = sizeof(T) == 2;              // f32 (parity mode) keeps one set: twice the registers per piece
+  constexpr bool DUAL = sizeof(T) == 2 && !PDZ;      // f32 (parity mode) keeps one set: twice the registers per piece; so does the
+                                                     // pooled-dZ staging (18 loads of 16 bytes per thread and tile: two sets would not fit the register budget)
   u32x4 rpA[NPP], rzA[NZP], rpB[DUAL ? NPP : 1], rzB[DUAL ? NZP : 1];
   XV xA[IM ? 9 : 1], xB[IM && DUAL ? 9 : 1];
+  u32x4 qA[PDZ ? 9 : 1], qB[PDZ && DUAL ? 9 : 1];   // pooled-dZ staging: [0..3] activation window, [4] pooled gradient, [5..8] skip gradient
   uint64_t okA = 0, okB = 0;
   auto gload = [&](u32x4& r, const T* ptr) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory"); };
   // interior tiles: wave-uniform 64-bit base in SGPRs + the thread's constant 32-bit byte offset (no per-load 64-bit VALU)
@@ -274,27 +280,75 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   const int imH = d.im2col_h, imW = d.im2col_w, impad = d.im2col_pad;
   unsigned x_boff[3];
 #pragma unroll
-  for (int u = 0; u < 3; ++u) x_boff[u] = (unsigned)(((tid / TW + u) * imW + tid % TW) * (IM ? IMC : 1) * 4);
-  auto prefetch_im = [&](const TileIt& it, XV (&xr)[IM ? 9 : 1], u32x4 (&rz)[NZP], uint64_t& okm, bool& inter) {
+  for (int u = 0; u < 3; ++u) x_boff[u] = (unsigned)(((tid / TW + u) * imW + tid % TW) * (IM ? ICH : 1) * 4);
+  // ---- pooled-dZ staging (PDZ) ----
+  // dZ of the first layer = (its activation y > 0) * (the pooled gradient routed to the window's first maximum + the gradient of
+  // its other consumer) -- exactly seg_maxpool2x2_bwd (models/unet.py pool1 over conv1_1 with conv1_2 as second consumer, finding
+  // F11; models/fcn.py:116 pool1) -- rebuilt per tile from y, dpool and the skip gradient instead of being written by a launch of
+  // its own on the critical stream and read back.  Thread t owns window t / 4 of the tile's 8 x 8 windows and channel group t % 4:
+  // nine 16-byte loads give the four dZ pieces of that window.  Mask bits: 9..12 pixel k inside the map, 13 routing on,
+  // 14..17 skip gradient of pixel k present.
+  const seg_view& pyv = d.pool_y; const seg_view& pdv = d.pool_dp; const seg_view& pav = d.pool_add;
+  const int pwin = tid >> 2, ph = tid & 3, pwy = pwin >> 3, pwx = pwin & 7;
+  const T* const py_base = reinterpret_cast<const T*>(pyv.ptr) + pyv.coff + n0 + ((int64_t)pyv.oy * pyv.W + pyv.ox) * pyv.cs + ph * 8;
+  const T* const pd_base = reinterpret_cast<const T*>(pdv.ptr) + pdv.coff + n0 + ((int64_t)pdv.oy * pdv.W + pdv.ox) * pdv.cs + ph * 8;
+  const T* const pa_base = reinterpret_cast<const T*>(pav.ptr) + pav.coff + n0 + ((int64_t)(pav.oy - d.pool_add_y0) * pav.W + (pav.ox - d.pool_add_x0)) * pav.cs + ph * 8;
+  const int64_t py_img = (int64_t)pyv.H * pyv.W * pyv.cs, pd_img = (int64_t)pdv.H * pdv.W * pdv.cs, pa_img = (int64_t)pav.H * pav.W * pav.cs;
+  auto prefetch_pdz = [&](int b, int oy0, int ox0, bool tile_in, u32x4 (&q)[PDZ ? 9 : 1], uint64_t& m) {
+    if constexpr (PDZ) {
+      const int Hp = d.Ho >> 1, Wp = d.Wo >> 1;
+      const bool has_dp = pdv.ptr != nullptr, has_add = pav.ptr != nullptr;
+      const T* yb = py_base + b * py_img + ((int64_t)oy0 * pyv.W + ox0) * pyv.cs;
+      const T* db = pd_base + b * pd_img + ((int64_t)(oy0 >> 1) * pdv.W + (ox0 >> 1)) * pdv.cs;
+      const T* ab = pa_base + b * pa_img + ((int64_t)oy0 * pav.W + ox0) * pav.cs;
+      const int wy = (oy0 >> 1) + pwy, wx = (ox0 >> 1) + pwx;
+      const bool route = has_dp && wy < Hp && wx < Wp;
+      // NOTE every load below is ONE unconditional asm statement with a selected address.  An asm load under a condition makes
+      // its destination a phi for the compiler, which may then implement it as "load into a temporary, copy" -- a copy made
+      // before the load has landed (tried: skipping the skip-gradient loads of tiles outside the window gave NaN gradients as
+      // soon as a workgroup walked more than one tile).
+      m |= (uint64_t)(route ? 1 : 0) << 13;
+      gload(q[4], route ? db + ((int64_t)pwy * pdv.W + pwx) * pdv.cs : reinterpret_cast<const T*>(pyv.ptr));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ly = 2 * pwy + (k >> 1), lx = 2 * pwx + (k & 1);
+        const int y = oy0 + ly, x = ox0 + lx;
+        const bool ok = tile_in || (y < d.Ho && x < d.Wo);
+        const int ay = y - d.pool_add_y0, ax = x - d.pool_add_x0;
+        const bool oka = ok && has_add && ay >= 0 && ay < d.pool_add_h && ax >= 0 && ax < d.pool_add_w;
+        m |= (uint64_t)(ok ? 1 : 0) << (9 + k);
+        m |= (uint64_t)(oka ? 1 : 0) << (14 + k);
+        gload(q[k], ok ? yb + ((int64_t)ly * pyv.W + lx) * pyv.cs : reinterpret_cast<const T*>(pyv.ptr));
+        gload(q[5 + k], oka ? ab + ((int64_t)ly * pav.W + lx) * pav.cs : reinterpret_cast<const T*>(pyv.ptr));
+      }
+    }
+  };
+  auto prefetch_im = [&](const TileIt& it, XV (&xr)[IM ? 9 : 1], u32x4 (&rz)[NZP], u32x4 (&q)[PDZ ? 9 : 1], uint64_t& okm, bool& inter) {
     if constexpr (IM) {
       const int b = __builtin_amdgcn_readfirstlane(it.b), ty = __builtin_amdgcn_readfirstlane(it.ty), tx = __builtin_amdgcn_readfirstlane(it.tx);
       const int oy0 = ty * TH, ox0 = tx * TW;
       const int iy0 = oy0 - impad, ix0 = ox0 - impad;
-      const float* xb = imx + (((int64_t)b * imH + iy0) * imW + ix0) * IMC;
+      const float* xb = imx + (((int64_t)b * imH + iy0) * imW + ix0) * ICH;
       const T* zb = z_base + b * z_img + (ty * z_ty + tx * z_tx);
       const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + TH + 2 <= imH && ix0 + TW + 2 <= imW && oy0 + TH <= d.Ho && ox0 + TW <= d.Wo;
       inter = interior;
       if (interior) {
-        const uint64_t xbu = uniform64(xb), zbu = uniform64(zb);
+        const uint64_t xbu = uniform64(xb), zbu = PDZ ? 0 : uniform64(zb);
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-          xload_s<IMC, 0>(xr[u * 3 + 0], x_boff[u], xbu);
-          xload_s<IMC, IMC * 4>(xr[u * 3 + 1], x_boff[u], xbu);
-          xload_s<IMC, IMC * 8>(xr[u * 3 + 2], x_boff[u], xbu);
+          xload_s<ICH, 0>(xr[u * 3 + 0], x_boff[u], xbu);
+          xload_s<ICH, ICH * 4>(xr[u * 3 + 1], x_boff[u], xbu);
+          xload_s<ICH, ICH * 8>(xr[u * 3 + 2], x_boff[u], xbu);
         }
+        if constexpr (PDZ) {
+          uint64_t mq = 0x1ffull;
+          prefetch_pdz(b, oy0, ox0, true, q, mq);
+          okm = mq;
+        } else {
 #pragma unroll
-        for (int i = 0; i < NZP; ++i) gload_s(rz[i], sz_boff[i], zbu);
-        okm = full;
+          for (int i = 0; i < NZP; ++i) gload_s(rz[i], sz_boff[i], zbu);
+          okm = full;
+        }
         return;
       }
       uint64_t m = 0;
@@ -305,14 +359,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
         const int iy = oy - impad + t / 3, ix = ox - impad + t % 3;
         const bool ok = pix && iy >= 0 && iy < imH && ix >= 0 && ix < imW;
         m |= (uint64_t)(ok ? 1 : 0) << t;
-        xload_p<IMC>(xr[t], ok ? imx + (((int64_t)b * imH + iy) * imW + ix) * IMC : imx);
+        xload_p<ICH>(xr[t], ok ? imx + (((int64_t)b * imH + iy) * imW + ix) * ICH : imx);
       }
+      if constexpr (PDZ) {
+        prefetch_pdz(b, oy0, ox0, false, q, m);
+      } else {
 #pragma unroll
-      for (int i = 0; i < NZP; ++i) {
-        const int mm = (tid + i * 256) / ZPIECES;
-        const bool ok = sz_lds[i] >= 0 && oy0 + mm / TW < d.Ho && ox0 + mm % TW < d.Wo;
-        m |= (uint64_t)(ok ? 1 : 0) << (NXL + i);
-        gload(rz[i], ok ? zb + sz_off[i] : dzp);
+        for (int i = 0; i < NZP; ++i) {
+          const int mm = (tid + i * 256) / ZPIECES;
+          const bool ok = sz_lds[i] >= 0 && oy0 + mm / TW < d.Ho && ox0 + mm % TW < d.Wo;
+          m |= (uint64_t)(ok ? 1 : 0) << (NXL + i);
+          gload(rz[i], ok ? zb + sz_off[i] : dzp);
+        }
       }
       okm = m;
     }
@@ -350,17 +408,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
     }
     commit_z(rz, okm, inter);
   };
-  auto wait_set_im = [&](XV (&xr)[IM ? 9 : 1], u32x4 (&rz)[NZP], bool younger) {
+  auto wait_set_im = [&](XV (&xr)[IM ? 9 : 1], u32x4 (&rz)[NZP], u32x4 (&q)[PDZ ? 9 : 1], bool younger) {
     if (younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < (IM ? 9 : 1); ++i) asm volatile("" : "+v"(xr[i]));
+    if constexpr (PDZ) {
 #pragma unroll
-    for (int i = 0; i < NZP; ++i) asm volatile("" : "+v"(rz[i]));
+      for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(q[i]));
+    } else {
+#pragma unroll
+      for (int i = 0; i < NZP; ++i) asm volatile("" : "+v"(rz[i]));
+    }
   };
-  auto commit_im = [&](const XV (&xr)[IM ? 9 : 1], const u32x4 (&rz)[NZP], uint64_t okm, bool inter) {
+  // the four dZ pieces of this thread's window (same arithmetic and rounding as maxpool_bwd_kernel: float sum, one rounding to T)
+  auto commit_pdz = [&](const u32x4 (&q)[PDZ ? 9 : 1], uint64_t okm) {
+    if constexpr (PDZ) {
+      const bool route = (okm >> 13) & 1;
+      Vec8<T> yv[4], av[4], dp, o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { yv[k].v = __builtin_bit_cast(bf16x8, q[k]); av[k].v = __builtin_bit_cast(bf16x8, q[5 + k]); }
+      dp.v = __builtin_bit_cast(bf16x8, q[4]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float yk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) yk[k] = ((okm >> (9 + k)) & 1) ? yv[k].get(e) : 0.f;
+        float m = yk[0]; int mi = 0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (yk[k] > m) { m = yk[k]; mi = k; }
+        const float dpe = route ? dp.get(e) : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float g = ((okm >> (14 + k)) & 1) ? av[k].get(e) : 0.f;
+          if (route && mi == k) g += dpe;
+          o[k].set(e, yk[k] > 0.f ? g : 0.f);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k].store(sZ + ((2 * pwy + (k >> 1)) * TW + 2 * pwx + (k & 1)) * RSZ + ph * 16);
+    }
+  };
+  auto commit_im = [&](const XV (&xr)[IM ? 9 : 1], const u32x4 (&rz)[NZP], const u32x4 (&q)[PDZ ? 9 : 1], uint64_t okm, bool inter) {
     if constexpr (IM) {
-      // the pixel's 32-channel row: k = tap * IMC + ci (the HWIO order of the filter gradient), zeros behind 9 * IMC
+      // the pixel's 32-channel row: k = tap * ICH + ci (the HWIO order of the filter gradient), zeros behind 9 * ICH
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         Vec8<T> o;
@@ -368,12 +459,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
         for (int e = 0; e < 8; ++e) {
           const int k = h * 8 + e;
           float v = 0.f;
-          if (k < 9 * IMC) { const int t = k / IMC, ci = k % IMC; v = (inter || ((okm >> t) & 1)) ? __builtin_bit_cast(float, xv_get<IMC>(xr[t], ci)) : 0.f; }
+          if (k < 9 * ICH) { const int t = k / ICH, ci = k % ICH; v = (inter || ((okm >> t) & 1)) ? __builtin_bit_cast(float, xv_get<ICH>(xr[t], ci)) : 0.f; }
           o.set(e, v);
         }
         o.store(sP + tid * RSP + h * 8 * ES);
       }
-      commit_z(rz, okm, inter);
+      if constexpr (PDZ) commit_pdz(q, okm); else commit_z(rz, okm, inter);
     }
   };
 
@@ -471,12 +562,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
     }
   };
   bool intA = false, intB = false;
-  auto prefetchA = [&](const TileIt& it) { if constexpr ((SEG_WABL & 8) != 0) { okA = full; } else if constexpr (IM) prefetch_im(it, xA, rzA, okA, intA); else prefetch(it, rpA, rzA, okA, intA); };
-  auto prefetchB = [&](const TileIt& it) { if constexpr ((SEG_WABL & 8) != 0) { okB = full; } else if constexpr (DUAL) { if constexpr (IM) prefetch_im(it, xB, rzB, okB, intB); else prefetch(it, rpB, rzB, okB, intB); } };
-  auto waitA = [&](bool younger) { if constexpr (IM) wait_set_im(xA, rzA, younger); else wait_set(rpA, rzA, younger); };
-  auto waitB = [&](bool younger) { if constexpr (DUAL) { if constexpr (IM) wait_set_im(xB, rzB, younger); else wait_set(rpB, rzB, younger); } };
-  auto commitA = [&]() { if constexpr ((SEG_WABL & 4) != 0) { asm volatile("" :: "v"(rpA[0]), "v"(rzA[0])); } else if constexpr (IM) commit_im(xA, rzA, okA, intA); else commit(rpA, rzA, okA, intA); };
-  auto commitB = [&]() { if constexpr ((SEG_WABL & 4) != 0) { asm volatile("" :: "v"(rpB[0]), "v"(rzB[0])); } else if constexpr (DUAL) { if constexpr (IM) commit_im(xB, rzB, okB, intB); else commit(rpB, rzB, okB, intB); } };
+  auto prefetchA = [&](const TileIt& it) { if constexpr ((SEG_WABL & 8) != 0) { okA = full; } else if constexpr (IM) prefetch_im(it, xA, rzA, qA, okA, intA); else prefetch(it, rpA, rzA, okA, intA); };
+  auto prefetchB = [&](const TileIt& it) { if constexpr ((SEG_WABL & 8) != 0) { okB = full; } else if constexpr (DUAL) { if constexpr (IM) prefetch_im(it, xB, rzB, qB, okB, intB); else prefetch(it, rpB, rzB, okB, intB); } };
+  auto waitA = [&](bool younger) { if constexpr (IM) wait_set_im(xA, rzA, qA, younger); else wait_set(rpA, rzA, younger); };
+  auto waitB = [&](bool younger) { if constexpr (DUAL) { if constexpr (IM) wait_set_im(xB, rzB, qB, younger); else wait_set(rpB, rzB, younger); } };
+  auto commitA = [&]() { if constexpr ((SEG_WABL & 4) != 0) { asm volatile("" :: "v"(rpA[0]), "v"(rzA[0])); } else if constexpr (IM) commit_im(xA, rzA, qA, okA, intA); else commit(rpA, rzA, okA, intA); };
+  auto commitB = [&]() { if constexpr ((SEG_WABL & 4) != 0) { asm volatile("" :: "v"(rpB[0]), "v"(rzB[0])); } else if constexpr (DUAL) { if constexpr (IM) commit_im(xB, rzB, qB, okB, intB); else commit(rpB, rzB, okB, intB); } };
   int tile = blockIdx.y;
   const int ks_ = P.ksplit;
 #ifdef SEG_STAMPS
@@ -736,7 +827,9 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
   // of the workgroup tile, so never more than needed and never more than there are tiles.
   const bool rs = KH > 1 && P.d.bias_mode != 2 && P.ntiles <= 64 && base < 192;
   const int wg = base * (rs ? KH : 1);
-  const int target_wgs = wgrad_target_wgs();
+  // (the first layer's filter gradient is the LAST kernel of the backward pass: it has the chip to itself and is bound by the
+  // latency of its image / activation gathers, so it fills every resident slot instead of sharing with the critical stream)
+  const int target_wgs = IMC ? 256 : wgrad_target_wgs();
   auto k0 = conv_wgrad_kernel<Tr<T>::DT, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, 0, IMC>;
   auto k1 = conv_wgrad_kernel<Tr<T>::DT, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, (KH > 1 ? 1 : 0), IMC>;
   static int occ = 0;                      // resident workgroups per CU of this instance
@@ -802,6 +895,15 @@ int launch_k(const WgK& P, hipStream_t st) {
   const seg_wgrad_desc& d = P.d;
   if constexpr (KH == 1 && KW == 1 && S == 1) {
     if (d.im2col_x) {                       // first layer: virtual im2col source, 256-pixel tiles, 32 x 32 channels
+      if constexpr (sizeof(T) == 2) {
+        if (d.pool_y.ptr) {                 // ... and dZ rebuilt from the max-pool that consumes the layer (IMC bit 2)
+          switch (d.im2col_cin) {
+            case 1: return launch_cfg<T, 16, 16, 1, 1, 1, 2, 2, 1, 1, 5>(P, st);
+            case 2: return launch_cfg<T, 16, 16, 1, 1, 1, 2, 2, 1, 1, 6>(P, st);
+            default: return launch_cfg<T, 16, 16, 1, 1, 1, 2, 2, 1, 1, 7>(P, st);
+          }
+        }
+      }
       switch (d.im2col_cin) {
         case 1: return launch_cfg<T, 16, 16, 1, 1, 1, 2, 2, 1, 1, 1>(P, st);
         case 2: return launch_cfg<T, 16, 16, 1, 1, 1, 2, 2, 1, 1, 2>(P, st);
@@ -909,6 +1011,16 @@ extern "C" int seg_conv2d_wgrad(const seg_wgrad_desc* dp, void* stream) {
         d.src0_clog != 9 * d.im2col_cin || d.im2col_pad < 0 || d.im2col_pad > 1 || d.Hi != d.Ho || d.Wi != d.Wo ||
         d.Ho != d.im2col_h + 2 * d.im2col_pad - 2 || d.Wo != d.im2col_w + 2 * d.im2col_pad - 2) {
       seg_set_error("wgrad: inconsistent im2col source (1x1 walk over [B,Ho,Wo,32], 9*cin logical channels, cin 1..3)"); return SEG_ERR_ARG;
+    }
+  }
+  if (d.pool_y.ptr) {
+    const seg_view& y = d.pool_y; const seg_view& p = d.pool_dp; const seg_view& a = d.pool_add;
+    auto inside = [](const seg_view& v, int H, int W, int C) { return v.oy >= 0 && v.ox >= 0 && v.oy + H <= v.H && v.ox + W <= v.W && v.coff >= 0 && v.coff + C <= v.cs && v.cs % 8 == 0 && v.coff % 8 == 0; };
+    if (!d.im2col_x || d.dtype != SEG_BF16 || y.c != d.dz.c || !inside(y, d.Ho, d.Wo, y.c) ||
+        (p.ptr && (p.c != y.c || !inside(p, d.Ho / 2, d.Wo / 2, y.c))) ||
+        (a.ptr && (a.c != y.c || d.pool_add_h <= 0 || d.pool_add_w <= 0 || d.pool_add_y0 < 0 || d.pool_add_x0 < 0 || !inside(a, d.pool_add_h, d.pool_add_w, y.c))) ||
+        (int64_t)y.H * y.W * y.cs >= ((int64_t)1 << 31)) {
+      seg_set_error("wgrad: inconsistent pooled-dZ source (first layer, bf16; y [Ho,Wo,n], dpool [Ho/2,Wo/2,n], optional skip gradient window)"); return SEG_ERR_ARG;
     }
   }
   if (d.bias_mode < 0 || d.bias_mode > 2 || (d.bias_mode && (!d.db || d.bias_n <= 0))) { seg_set_error("wgrad: bad bias request"); return SEG_ERR_ARG; }

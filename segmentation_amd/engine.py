@@ -696,10 +696,17 @@ class Net(object):
                  self.dtype, kernel='im2col3x3_kernel', side=1)
         return col
 
-    def first_bwd(self, plan, layer, x_f32, H, W, dz, col=None, same_stream=True):
+    def fuses_first_pool_bwd(self, col=None):
+        """True when first_bwd(pool=...) can rebuild dZ from the max-pool that consumes the first layer (bf16, virtual im2col)."""
+        return col is None and self.dtype == L.SEG_BF16 and os.environ.get('SEG_FUSE_POOL1_BWD', '1') != '0'
+
+    def first_bwd(self, plan, layer, x_f32, H, W, dz, col=None, same_stream=True, pool=None, ksplit=0):
         """First-layer filter/bias gradient = the generic 1x1 MFMA wgrad over the im2col'd input; the [1][9*cin][cout]
         result is exactly the HWIO filter gradient.  col=None: the im2col rows are gathered from the float image inside the
-        filter-gradient kernel (seg_wgrad_desc.im2col_x); else `col` is the tensor first_im2col wrote."""
+        filter-gradient kernel (seg_wgrad_desc.im2col_x); else `col` is the tensor first_im2col wrote.
+        pool = (y_act, dpool, add, add_hw, add_off) with dz=None (fuses_first_pool_bwd()): dZ is rebuilt inside the kernel from
+        the layer's activation, the pooled gradient and the other consumer's gradient -- the arguments of pool_bwd, whose launch
+        (on the critical stream) and whose dZ tensor then do not exist."""
         Ho, Wo = H + 2 * layer.pad - 2, W + 2 * layer.pad - 2
         if layer.cin > 3:
             raise L.SegError('first-layer gradient supports input_channel <= 3')
@@ -714,12 +721,24 @@ class Net(object):
         w.B, w.Hi, w.Wi = self.B, Ho, Wo
         w.KH = w.KW = 1; w.stride = 1; w.pad_t = w.pad_l = 0
         w.Ho, w.Wo = Ho, Wo
-        w.dz = dz.view(); w.n_log = layer.cout
+        if pool is not None:
+            assert dz is None and col is None
+            y_act, dpool, add, add_hw, add_off = pool
+            w.pool_y = y_act.view()
+            w.pool_dp = dpool.view() if dpool is not None else L.null_view()
+            w.pool_add = add.view() if add is not None else L.null_view()
+            w.pool_add_h, w.pool_add_w, w.pool_add_y0, w.pool_add_x0 = add_hw[0], add_hw[1], add_off[0], add_off[1]
+            w.dz = y_act.view()                       # (describes the channel padding; never dereferenced)
+        else:
+            w.dz = dz.view()
+        w.n_log = layer.cout
         w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = 0
         w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
-        self._wgrad_ws(w, plan)
+        self._wgrad_ws(w, plan, ksplit)
         fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
         self._wg_bytes = self.B * (H * W * layer.cin * 4 + Ho * Wo * layer.cout * self.es) + 9 * layer.cin * layer.cout * 4
+        if pool is not None:
+            self._wg_bytes += self.B * (Ho // 2) * (Wo // 2) * layer.cout * self.es + (self.B * add_hw[0] * add_hw[1] * layer.cout * self.es if add is not None else 0)
         # same side stream as the im2col that feeds it (stream 1): in order behind it, so a plan that runs forward and
         # backward back to back needs no join of the side streams in between
         # (same_stream=False: the data-parallel plans, which join the side streams after the forward anyway, keep the

@@ -237,6 +237,10 @@ class FCNModel(BaseModel):
         for i in (5, 4, 3, 2, 1):
             name = 'conv%d' % i
             a = A[name]
+            if i == 1 and net.fuses_first_pool_bwd(col):
+                # pool1's backward happens inside the first layer's filter gradient (no launch, no dZ(conv1) tensor)
+                net.first_bwd(seg, Ly[name], self.input_x, H, W, None, same_stream=not self.pg.enabled, pool=(a, dP[i], None, (0, 0), (0, 0)))
+                break
             dz = act_like(a, 'dz_' + name)
             net.pool_bwd(seg, a, dP[i], None, (0, 0), (0, 0), dz, a.H, a.W)
             if i == 1:

@@ -322,8 +322,13 @@ class UNetModel(BaseModel):
         net.conv_bwd(seg, Ly['conv1_2'], [(A['conv1_1'], o4[0], o4[1])], t4h + 2, t4w + 2, dskip['conv1_2'],
                      [(d11s, (0, 0), None, (0, 0))])
         close_segment('conv1_2')
-        net.pool_bwd(seg, A['conv1_1'], dP[1], d11s, (t4h + 2, t4w + 2), o4, gz('conv1_1'), A['conv1_1'].H, A['conv1_1'].W)
-        net.first_bwd(seg, Ly['conv1_1'], self.input_x, H, W, G['conv1_1'], col=col, same_stream=not self.pg.enabled)
+        if net.fuses_first_pool_bwd(col):
+            # pool1's backward happens inside the first layer's filter gradient (no launch, no dZ(conv1_1) tensor)
+            net.first_bwd(seg, Ly['conv1_1'], self.input_x, H, W, None, same_stream=not self.pg.enabled,
+                          pool=(A['conv1_1'], dP[1], d11s, (t4h + 2, t4w + 2), o4))
+        else:
+            net.pool_bwd(seg, A['conv1_1'], dP[1], d11s, (t4h + 2, t4w + 2), o4, gz('conv1_1'), A['conv1_1'].H, A['conv1_1'].W)
+            net.first_bwd(seg, Ly['conv1_1'], self.input_x, H, W, G['conv1_1'], col=col, same_stream=not self.pg.enabled)
         close_segment('conv1_1')
         self.grads_act = G
         self._finish_training_plans(segs)

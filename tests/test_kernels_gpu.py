@@ -311,6 +311,10 @@ def test_conv_first(dtype, pad, cin, cout, H, monkeypatch):
         assert U.rel_err(g['weights'], dw_ref) < U.tol(dtype, 2e-5, 1e-2)
         assert U.rel_err(g['biases'], db_ref) < U.tol(dtype, 2e-5, 1e-2)
         assert [o[0] for o in bp.ops if o[1] is not None][0] == 'f/dw'          # no im2col launch: the rows are gathered while staging
+        store.g.zero_()
+        bl = E.Plan('bl'); net.first_bwd(bl, layer, xt, H, W, dz, ksplit=2); net.flush_reduce(bl); bl.run(U.stream()); U.sync()     # long tile walks
+        gl = store.get_grads()['f']
+        assert U.rel_err(gl['weights'], dw_ref) < U.tol(dtype, 2e-5, 1e-2) and U.rel_err(gl['biases'], db_ref) < U.tol(dtype, 2e-5, 1e-2)
         # the explicit form (im2col tensor + the same 1x1 walk): the same rounded operands, another summation order at most
         monkeypatch.setenv('SEG_FIRST_IM2COL', '1')
         store.g.zero_()
@@ -318,6 +322,30 @@ def test_conv_first(dtype, pad, cin, cout, H, monkeypatch):
         net.first_bwd(bp2, layer, xt, H, W, dz, col=col); net.flush_reduce(bp2); bp2.run(U.stream()); U.sync()
         g2 = store.get_grads()['f']
         assert U.rel_err(g2['weights'], g['weights']) < 2e-5 and U.rel_err(g2['biases'], g['biases']) < 2e-5
+        monkeypatch.delenv('SEG_FIRST_IM2COL')
+        if net.fuses_first_pool_bwd():
+            # dZ rebuilt inside the kernel from the 2x2 max-pool that consumes the layer (+ a second consumer's gradient in a
+            # window, as the U-Net's conv1_2) against the separate pool backward launch feeding the same filter gradient
+            Hp, Wp = Ho // 2, Wo // 2
+            dpv = U.round_dtype(rng.standard_normal((B, Hp, Wp, cout)), dtype)
+            dpa = net.act(Hp, Wp, cout); U.fill_act(dpa, dpv)
+            # (ksplit 2: every workgroup walks many tiles -- the staging registers are reused from tile to tile)
+            for add_on, ks in ((False, 0), (True, 0), (False, 2), (True, 2)):
+                ah, aw, ay0, ax0 = (max(Ho - 7, 1), max(Wo - 5, 1), 3, 2) if add_on else (0, 0, 0, 0)
+                adda = None
+                if add_on:
+                    adda = net.act(ah, aw, cout); U.fill_act(adda, U.round_dtype(rng.standard_normal((B, ah, aw, cout)), dtype))
+                dzr = net.act(Ho, Wo, cout)
+                store.g.zero_()
+                pr = E.Plan('pr'); net.pool_bwd(pr, out, dpa, adda, (ah, aw), (ay0, ax0), dzr, Ho, Wo)
+                net.first_bwd(pr, layer, xt, H, W, dzr, ksplit=ks); net.flush_reduce(pr); pr.run(U.stream()); U.sync()
+                gr = store.get_grads()['f']
+                store.g.zero_()
+                pf = E.Plan('pf'); net.first_bwd(pf, layer, xt, H, W, None, pool=(out, dpa, adda, (ah, aw), (ay0, ax0)), ksplit=ks)
+                net.flush_reduce(pf); pf.run(U.stream()); U.sync()
+                gf = store.get_grads()['f']
+                assert [o[0] for o in pf.ops if o[1] is not None][0] == 'f/dw'
+                assert U.rel_err(gf['weights'], gr['weights']) < 2e-5 and U.rel_err(gf['biases'], gr['biases']) < 2e-5, (add_on, ks)
 
 
 @pytest.mark.parametrize('dtype', DT)
