@@ -126,6 +126,10 @@ typedef struct seg_wgrad_desc {
    * gradient).  dz.ptr is then not dereferenced (dz.c = n still describes the channel padding). */
   seg_view pool_y, pool_dp, pool_add;
   int32_t pool_add_h, pool_add_w, pool_add_y0, pool_add_x0;
+  /* Workgroups the automatic K split aims for (0 = the library default, 128: half the chip, because filter gradients normally
+   * share it with the data gradients of the critical stream).  The last filter gradients of a backward pass run after the
+   * critical stream has finished: the caller marks them with 256. */
+  int32_t target_wgs;
 } seg_wgrad_desc;
 int seg_conv2d_wgrad(const seg_wgrad_desc* d, void* stream);
 int seg_conv2d_wgrad_plan(const seg_wgrad_desc* d, int32_t* ksplit, int64_t* ws_bytes);

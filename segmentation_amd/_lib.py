@@ -41,7 +41,8 @@ class WgradDesc(C.Structure):
                 ('db', C.c_void_p), ('bias_n', C.c_int32), ('phase', C.c_int32),
                 ('im2col_x', C.c_void_p), ('im2col_h', C.c_int32), ('im2col_w', C.c_int32), ('im2col_cin', C.c_int32),
                 ('im2col_pad', C.c_int32), ('pool_y', View), ('pool_dp', View), ('pool_add', View),
-                ('pool_add_h', C.c_int32), ('pool_add_w', C.c_int32), ('pool_add_y0', C.c_int32), ('pool_add_x0', C.c_int32)]
+                ('pool_add_h', C.c_int32), ('pool_add_w', C.c_int32), ('pool_add_y0', C.c_int32), ('pool_add_x0', C.c_int32),
+                ('target_wgs', C.c_int32)]
 
 
 class DconvDesc(C.Structure):

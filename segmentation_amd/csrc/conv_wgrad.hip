@@ -829,7 +829,7 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
   const int wg = base * (rs ? KH : 1);
   // (the first layer's filter gradient is the LAST kernel of the backward pass: it has the chip to itself and is bound by the
   // latency of its image / activation gathers, so it fills every resident slot instead of sharing with the critical stream)
-  const int target_wgs = IMC ? 256 : wgrad_target_wgs();
+  const int target_wgs = IMC ? 256 : (P.d.target_wgs > 0 ? P.d.target_wgs : wgrad_target_wgs());
   auto k0 = conv_wgrad_kernel<Tr<T>::DT, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, 0, IMC>;
   auto k1 = conv_wgrad_kernel<Tr<T>::DT, TH, TW, KH, KW, S, WCI, WCO, FCI, FCO, (KH > 1 ? 1 : 0), IMC>;
   static int occ = 0;                      // resident workgroups per CU of this instance

@@ -237,6 +237,15 @@ def _cfg_overrides():
     return _CFG_OV
 
 
+def _tail_layers(default=()):
+    """Layers whose filter gradients run after the critical stream has finished (the models name the last ones of their backward
+    pass); SEG_WGRAD_TAIL="a,b" overrides, "-" = none."""
+    v = os.environ.get('SEG_WGRAD_TAIL')
+    if v is None:
+        return set(default)
+    return set(x for x in v.split(',') if x and x != '-')
+
+
 class Plan(object):
     """Ordered list of C-ABI launches.  Every entry is (name, fn, args-without-stream)."""
 
@@ -762,6 +771,8 @@ class Net(object):
         w.dz = dz.view(dz_off[0], dz_off[1]); w.n_log = layer.cout
         w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = wcfg
         w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
+        if layer.name in _tail_layers(getattr(self, 'tail_layers', ())):
+            w.target_wgs = 256                       # runs after the critical stream has finished: the whole chip is its own
         self._wgrad_ws(w, plan, ksplit)
         fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
         self._wg_bytes = self.B * (Hi * Wi * layer.cin + Ho * Wo * layer.cout) * self.es + k * k * layer.cin * layer.cout * 4

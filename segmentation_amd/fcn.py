@@ -166,6 +166,7 @@ class FCNModel(BaseModel):
         B, (H, W) = self.batch_size, self.input_dims
         net = self.net = E.Net(self.store, B, self.dtype, self.device)
         net.n_wgrad_streams = max(1, len(self._side) - 1) if self._side else 1
+        net.tail_layers = ('conv2',)      # last tiled filter gradient of the backward pass: aims for the whole chip (see unet.py); +2 % at C3
         Ly, nc = self.store.layers, self.n_classes
         fwd = self.fwd_plan = E.Plan('fwd')
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)

@@ -203,6 +203,8 @@ class UNetModel(BaseModel):
         B, (H, W) = self.batch_size, self.input_dims
         net = self.net = E.Net(self.store, B, self.dtype, self.device)
         net.n_wgrad_streams = max(1, len(self._side) - 1) if self._side else 1
+        # the last filter gradients of the backward pass outlive the critical stream: they aim for the whole chip (256 workgroups)
+        net.tail_layers = ('conv1_2', 'conv2_1')
         Ly = self.store.layers
         fwd = self.fwd_plan = E.Plan('fwd')
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
