@@ -161,6 +161,10 @@ int seg_conv_first_pool_fwd(const float* x, int32_t B, int32_t H, int32_t W, int
  * layer's Conv2DBackpropFilter run as a 1x1 seg_conv2d_wgrad on the MFMA path (dw comes out in HWIO order). */
 int seg_im2col3x3(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, int32_t pad, const seg_view* dst,
                   int32_t Ho, int32_t Wo, int32_t dtype, void* stream);
+/* The same for any window / stride / leading pads (k = (u*KW+v)*cin + c, zero-filled up to dst->c, a multiple of 32): the
+ * DeconvModel's 5x5/s2 SAME first layer (models/deconvolution.py) as a 1x1 convolution on the MFMA kernels. */
+int seg_im2col(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, int32_t KH, int32_t KW, int32_t stride,
+               int32_t pad_t, int32_t pad_l, const seg_view* dst, int32_t Ho, int32_t Wo, int32_t dtype, void* stream);
 
 /* slim.max_pool2d(x, 2) (kernel 2, stride 2, VALID): models/unet.py:120,124,128,132; models/fcn.py:116-126.
  * idx (nullable): uint8 plane [B,Ho,Wo,C] with the first-max position 0..3 in window order. */

@@ -305,6 +305,55 @@ extern "C" int seg_im2col3x3(const float* x, int32_t B, int32_t H, int32_t W, in
   return seg_check_launch("im2col3x3");
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// General im2col of the raw float input: KH x KW window, any stride, explicit leading pads; channel k = (u*KW + v)*cin + c,
+// zero-filled up to dst->c (a multiple of 32).  The DeconvModel's first layer (/root/reference/models/deconvolution.py: 5x5/s2
+// SAME on 3 channels, K = 75 -> 96) becomes a 1x1 convolution over this tensor: forward and filter gradient on the MFMA
+// kernels instead of the direct ones (1.6 + 2.6 ms -> ~0.2 ms at 512 x 512).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void im2col_kernel(const float* x, int B, int H, int W, int cin, int KH, int KW, int stride, int pad_t, int pad_l, seg_view dst,
+                              int Ho, int Wo, int pieces) {
+  const int64_t total = (int64_t)B * Ho * Wo * pieces;
+  const int nk = KH * KW * cin;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int piece = (int)(i % pieces);
+    int64_t t = i / pieces;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho); const int b = (int)(t / Ho);
+    Vec8<T> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = piece * 8 + e;
+      float v = 0.f;
+      if (k < nk) {
+        const int tap = k / cin, c = k - tap * cin;
+        const int iy = oy * stride - pad_t + tap / KW, ix = ox * stride - pad_l + tap % KW;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((int64_t)b * H + iy) * W + ix) * cin + c];
+      }
+      o.set(e, v);
+    }
+    o.store(reinterpret_cast<T*>(dst.ptr) + view_off(dst, b, oy, ox) + piece * 8);
+  }
+}
+
+extern "C" int seg_im2col(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, int32_t KH, int32_t KW, int32_t stride,
+                          int32_t pad_t, int32_t pad_l, const seg_view* dst, int32_t Ho, int32_t Wo, int32_t dtype, void* stream) {
+  if (!x || !dst || !dst->ptr || cin < 1 || KH < 1 || KW < 1 || stride < 1 || pad_t < 0 || pad_l < 0 || B <= 0 || Ho <= 0 || Wo <= 0) { seg_set_error("im2col: bad args"); return SEG_ERR_ARG; }
+  if (dst->c % 32 || KH * KW * cin > dst->c || dst->oy + Ho > dst->H || dst->ox + Wo > dst->W || dst->coff + dst->c > dst->cs || dst->cs % 8 || dst->coff % 8) {
+    seg_set_error("im2col: destination window must hold %d channels padded to a multiple of 32", KH * KW * cin); return SEG_ERR_ARG;
+  }
+  if ((Ho - 1) * stride - pad_t >= H || (Wo - 1) * stride - pad_l >= W) { seg_set_error("im2col: output extent reaches past the input"); return SEG_ERR_ARG; }
+  const int pieces = dst->c / 8;
+  const int64_t n = (int64_t)B * Ho * Wo * pieces;
+  int g = (int)((n + 255) / 256); if (g > 16384) g = 16384;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SEG_F32) SEG_LAUNCH(im2col_kernel<float>, dim3(g), dim3(256), 0, st, x, B, H, W, cin, KH, KW, stride, pad_t, pad_l, *dst, Ho, Wo, pieces);
+  else if (dtype == SEG_BF16) SEG_LAUNCH(im2col_kernel<bf16_t>, dim3(g), dim3(256), 0, st, x, B, H, W, cin, KH, KW, stride, pad_t, pad_l, *dst, Ho, Wo, pieces);
+  else { seg_set_error("im2col: bad dtype"); return SEG_ERR_ARG; }
+  return seg_check_launch("im2col");
+}
+
 extern "C" int seg_conv_first_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const float* w_hwio, const float* bias,
                                   int32_t cout, int32_t pad, const seg_view* dst, int32_t Ho, int32_t Wo, int32_t relu, int32_t dtype,
                                   void* stream) {

@@ -37,7 +37,9 @@ def deconv_layers(n_classes, nk, cin):
 
     def add(name, kind, k, ci, co, padding='VALID', relu=True, stride=1):
         Ly[name] = E.Layer(name, kind, k, [ci], co, padding, relu, stride)
-    add('conv1_0', 'direct', 5, cin, nk, 'SAME', stride=2); add('bn1', 'bn', 1, nk, nk)
+    # conv1_0 (5x5/s2 SAME on the raw image) runs as a 1x1 convolution over the im2col of its input (K = 25*cin, seg_im2col): MFMA
+    # forward and filter gradient instead of the direct kernels; its parameter stays the [5,5,cin,nk] HWIO tensor (same memory order)
+    add('conv1_0', 'conv', 1, 25 * cin, nk, 'VALID'); Ly['conv1_0'].wshape = (5, 5, cin, nk); add('bn1', 'bn', 1, nk, nk)
     add('conv2_0', 'conv', 3, nk, 2 * nk); add('bn2', 'bn', 1, 2 * nk, 2 * nk)
     add('conv3_0', 'conv', 3, 2 * nk, 4 * nk); add('bn3', 'bn', 1, 4 * nk, 4 * nk)
     add('conv4_0', 'conv', 3, 4 * nk, 8 * nk); add('bn4', 'bn', 1, 8 * nk, 8 * nk)
@@ -160,8 +162,12 @@ class DeconvModel(BaseModel):
         sz = deconv_sizes(H)
         bn = self._bn_states(net)
         A, Y = {}, {}
-        xin = net.act(H, W, self.input_channel, name='x')
-        net.cast_pad(plan, x_in, xin)
+        xin = net.act(sz['conv1_0'], sz['conv1_0'], 25 * self.input_channel, name='x_im2col')
+        pad = max((sz['conv1_0'] - 1) * 2 + 5 - H, 0) // 2           # TF SAME, stride 2: leading pad = total // 2
+        cv = xin.view()
+        plan.keep.append(cv)
+        plan.add('conv1_0/im2col', net.lib.seg_im2col, x_in.data_ptr(), net.B, H, W, self.input_channel, 5, 5, 2, pad, pad, E.C.byref(cv),
+                 sz['conv1_0'], sz['conv1_0'], net.dtype, kernel='im2col_kernel')
         net.join_aux(plan)                     # packed weights (re-packed on the aux stream in training) are needed from here on
 
         def act_bn(name, a):
@@ -184,7 +190,7 @@ class DeconvModel(BaseModel):
             return out
 
         a = net.act(sz['conv1_0'], sz['conv1_0'], nk, name='conv1_0')
-        net.dlayer_fwd(plan, Ly['conv1_0'], xin, a)
+        net.conv_fwd(plan, Ly['conv1_0'], [(xin, 0, 0)], xin.H, xin.W, a)
         t = act_bn('conv1_0', a)
         P = {}
         P[1] = net.act(sz['pool1'], sz['pool1'], nk, name='pool1'); net.pool_k_fwd(plan, t, P[1], 2)
@@ -278,7 +284,7 @@ class DeconvModel(BaseModel):
         d = like(Y['bn1'], 'd_bn1')
         net.pool_k_bwd(seg, Y['bn1'], dP[1], d, 2)
         dz = bn_bwd('bn1', 'conv1_0', d)
-        net.dlayer_bwd(seg, Ly['conv1_0'], A['x'], dz, dsrc=None)
+        net.conv_bwd(seg, Ly['conv1_0'], [(A['x'], 0, 0)], A['x'].H, A['x'].W, dz, [None])
         self.grads_act = G
         net.flush_reduce(seg)
         l = Ly['conv1_0']

@@ -3,6 +3,8 @@
 model's train_step() / test() / infer() through the C-ABI against oracle/deconv.py on identical weights and inputs."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -210,7 +212,11 @@ def test_deconv_f32_forward_backward_parity(bayesian):
     # (224 -> a 3x3 bottleneck: at 160 conv4_0 is 1x1 and bn4 normalises over the TWO values of the batch, where 1/sqrt(var+eps)
     # turns f32 round-off of nearly equal pairs into 4e-4 logit differences)
     B, S, nc = 2, 224, 3
-    x, y = _data(B, S, nc)
+    # The gradient error of this net against the float64 oracle is bimodal in the data seed: ~3e-5 of the tensor maximum, or
+    # >= 2e-3 when float32 round-off flips one ReLU of the 3x3 bottleneck (batch norm over 18 values couples every gradient to
+    # it).  Seeds 5559, 5563-5566 are flip-free with and without dropout (measured); 5555 was flip-free only for the summation
+    # order of the direct first-layer kernel.
+    x, y = _data(B, S, nc, seed=5559)
     m = _model(x, y, nc, S, 'f32', use_graph=False, bayesian=bayesian)
     assert sum(v[k].size for v in m.store.get_params().values() for k in v) == 55682
     p = _oracle_params(m, np.random.default_rng(1))
@@ -235,7 +241,7 @@ def test_deconv_f32_forward_backward_parity(bayesian):
     for bn in ('bn1', 'bn4', 'bn8'):
         a = m.bn_out[bn]
         assert np.abs(a.t[..., :a.C].cpu().numpy() - c[bn]).max() < 2e-4, bn
-    _grads_close(m.store.get_grads(), g_ref, 5e-4)
+    _grads_close(m.store.get_grads(), g_ref, 2e-4)
     mov = m.get_moving()
     for bn, (nm, nv) in newmov.items():
         assert np.abs(mov[bn][0] - nm).max() < 1e-6 and np.abs(mov[bn][1] - nv).max() < 1e-6, bn
