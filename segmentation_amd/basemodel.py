@@ -546,8 +546,19 @@ class BaseModel(object):
         self.bwd_upd_plan = E.Plan('bwd+update')
         for plan, _ in self.bwd_segments:
             self.bwd_upd_plan.extend(plan)
-        self.net.join_all(self.bwd_upd_plan)           # the last filter gradients / reductions are on the side streams
-        self.net.adam(self.bwd_upd_plan, self.learning_rate, grad_scale=1.0)
+        tail = getattr(self, '_aux_tail_layer', None)    # the layer whose filter gradient the model put on the auxiliary stream
+        lt = self.store.layers.get(tail) if tail else None
+        if lt is not None and not self.pg.enabled and lt.b_off + lt.nbias == self.store.n:
+            # Adam for everything but the last layer runs BESIDE that layer's filter gradient (both are bandwidth-bound and
+            # alone on the chip at the end of the step); its own few parameters follow in a second, tiny launch
+            cut = lt.w_off // 4 * 4                          # (slices of the arena start on 16-byte boundaries)
+            self.net.join_wgrad(self.bwd_upd_plan)
+            self.net.adam(self.bwd_upd_plan, self.learning_rate, grad_scale=1.0, lo=0, hi=cut)
+            self.net.join_all(self.bwd_upd_plan)
+            self.net.adam(self.bwd_upd_plan, self.learning_rate, grad_scale=1.0, lo=cut, hi=self.store.n)
+        else:
+            self.net.join_all(self.bwd_upd_plan)           # the last filter gradients / reductions are on the side streams
+            self.net.adam(self.bwd_upd_plan, self.learning_rate, grad_scale=1.0)
         if self.adversary is not None:
             self.adversary.emit_update(self.bwd_upd_plan)
         # the whole single-GPU step as ONE plan: no join of the side streams between forward and backward (the only forward

@@ -332,6 +332,10 @@ class Plan(object):
                 if aux_used:
                     join(aux)
                 continue
+            if fn is None and name == 'join_wgrad':    # marker: ... for the filter-gradient streams only (the aux stream keeps running)
+                for o_ in used.values():
+                    join(o_)
+                continue
             if fn is None:               # marker: make the main stream wait for the aux stream
                 if aux_used:
                     join(aux)
@@ -470,10 +474,10 @@ class Plan(object):
             tag = self.meta[i].get('side', 0) if side else 0
             if self.meta[i].get('flavor', flavor) != flavor:
                 continue
-            if fn is None and name == 'join_all':
+            if fn is None and name in ('join_all', 'join_wgrad'):
                 for o_ in used.values():
                     ev = torch_mod.cuda.Event(); ev.record(o_); main.wait_event(ev)
-                if side and aux_used:
+                if side and aux_used and name == 'join_all':
                     ev = torch_mod.cuda.Event(); ev.record(aux); main.wait_event(ev)
                 continue
             if fn is None:
@@ -671,10 +675,10 @@ class Net(object):
         behind a join of the side streams (everything pending, whatever stream it ran on)."""
         pending, self._pending_reduce = self._pending_reduce, {}
         if on_main and pending:
-            allw = [w for sid in sorted(pending) for w in pending[sid]]
+            allw = [w for sid in sorted(pending, key=str) for w in pending[sid]]
             pending = {0: allw}
             self.join_all(plan)
-        for sid in sorted(pending):
+        for sid in sorted(pending, key=str):
             ws = pending[sid]
             n = len(ws)
             arr = (C.POINTER(L.WgradDesc) * n)(*[C.pointer(w) for w in ws])
@@ -709,7 +713,7 @@ class Net(object):
         """True when first_bwd(pool=...) can rebuild dZ from the max-pool that consumes the first layer (bf16, virtual im2col)."""
         return col is None and self.dtype == L.SEG_BF16 and os.environ.get('SEG_FUSE_POOL1_BWD', '1') != '0'
 
-    def first_bwd(self, plan, layer, x_f32, H, W, dz, col=None, same_stream=True, pool=None, ksplit=0):
+    def first_bwd(self, plan, layer, x_f32, H, W, dz, col=None, same_stream=True, pool=None, ksplit=0, on_aux=False):
         """First-layer filter/bias gradient = the generic 1x1 MFMA wgrad over the im2col'd input; the [1][9*cin][cout]
         result is exactly the HWIO filter gradient.  col=None: the im2col rows are gathered from the float image inside the
         filter-gradient kernel (seg_wgrad_desc.im2col_x); else `col` is the tensor first_im2col wrote.
@@ -752,7 +756,9 @@ class Net(object):
         # backward back to back needs no join of the side streams in between
         # (same_stream=False: the data-parallel plans, which join the side streams after the forward anyway, keep the
         # alternating assignment -- pinning changed the shape of their captured segment graph and made it 20 % slower)
-        self._add_wgrad(plan, layer.name + '/dw', w, fl, sid=1 if (same_stream and col is not None) else None)
+        # on_aux: the LAST filter gradient of the backward pass goes to the auxiliary stream, so that Adam for every other layer
+        # (basemodel._finish_training_plans) can run beside it
+        self._add_wgrad(plan, layer.name + '/dw', w, fl, sid='aux' if on_aux else (1 if (same_stream and col is not None) else None))
         plan.flops += fl
 
     def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0, ksplit=0):
@@ -1137,6 +1143,11 @@ class Net(object):
 
     def join_aux(self, plan):
         plan.ops.append(('join_aux', None, ()))
+        plan.meta.append({'kernel': 'marker'})
+
+    def join_wgrad(self, plan):
+        """main stream waits for the filter-gradient side streams, not for the auxiliary one"""
+        plan.ops.append(('join_wgrad', None, ()))
         plan.meta.append({'kernel': 'marker'})
 
     def adam(self, plan, lr, grad_scale=1.0, b1=0.9, b2=0.999, eps=1e-8, lo=0, hi=None):

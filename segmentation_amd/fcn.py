@@ -240,7 +240,11 @@ class FCNModel(BaseModel):
             a = A[name]
             if i == 1 and net.fuses_first_pool_bwd(col):
                 # pool1's backward happens inside the first layer's filter gradient (no launch, no dZ(conv1) tensor)
-                net.first_bwd(seg, Ly[name], self.input_x, H, W, None, same_stream=not self.pg.enabled, pool=(a, dP[i], None, (0, 0), (0, 0)))
+                aux_tail = not self.pg.enabled and not self.adversarial_training and os.environ.get('SEG_ADAM_OVERLAP', '1') != '0'
+                if aux_tail:
+                    self._aux_tail_layer = name
+                net.first_bwd(seg, Ly[name], self.input_x, H, W, None, same_stream=not self.pg.enabled, pool=(a, dP[i], None, (0, 0), (0, 0)),
+                              on_aux=aux_tail)
                 break
             dz = act_like(a, 'dz_' + name)
             net.pool_bwd(seg, a, dP[i], None, (0, 0), (0, 0), dz, a.H, a.W)

@@ -326,8 +326,13 @@ class UNetModel(BaseModel):
         close_segment('conv1_2')
         if net.fuses_first_pool_bwd(col):
             # pool1's backward happens inside the first layer's filter gradient (no launch, no dZ(conv1_1) tensor)
+            # (Adam beside the last filter gradient: +1 % for the FCN, -0.4 % here at 256^2, +-0 at 512^2 -- both kernels are bandwidth-bound;
+            # off by default for the U-Net)
+            aux_tail = not self.pg.enabled and not self.adversarial_training and os.environ.get('SEG_ADAM_OVERLAP', '0') == '1'
+            if aux_tail:
+                self._aux_tail_layer = 'conv1_1'
             net.first_bwd(seg, Ly['conv1_1'], self.input_x, H, W, None, same_stream=not self.pg.enabled,
-                          pool=(A['conv1_1'], dP[1], d11s, (t4h + 2, t4w + 2), o4))
+                          pool=(A['conv1_1'], dP[1], d11s, (t4h + 2, t4w + 2), o4), on_aux=aux_tail)
         else:
             net.pool_bwd(seg, A['conv1_1'], dP[1], d11s, (t4h + 2, t4w + 2), o4, gz('conv1_1'), A['conv1_1'].H, A['conv1_1'].W)
             net.first_bwd(seg, Ly['conv1_1'], self.input_x, H, W, G['conv1_1'], col=col, same_stream=not self.pg.enabled)
