@@ -166,6 +166,18 @@ int seg_im2col3x3(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, 
 int seg_im2col(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, int32_t KH, int32_t KW, int32_t stride,
                int32_t pad_t, int32_t pad_l, const seg_view* dst, int32_t Ho, int32_t Wo, int32_t dtype, void* stream);
 
+/* The DeconvModel's 5x5/s2 transposed convolutions on the MFMA kernels (models/deconvolution.py deconv1_0 / deconv2_0 /
+ * deconv2_1): a transposed convolution with filter [kh,kw,Cout,Cin] is the adjoint of the strided convolution whose HWIO filter
+ * is the same memory, and that one is a 1x1 convolution over the strided im2col of its input.
+ * seg_im2col_act: dst[b,oy,ox,(u*KW+v)*C + c] = src[b, oy*s - pad_t + u, ox*s - pad_l + v, c] (zero outside, zero-filled up to
+ * dst->c, a multiple of 32).  seg_col2im: the adjoint gather, dst[b,Y,X,c] = relu?(bias[c] + sum of col[b,(Y+pad_t-u)/s,
+ * (X+pad_l-v)/s,(u*KW+v)*C + c] over the taps that divide) -- C a multiple of 8. */
+int seg_im2col_act(const seg_view* src, int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t KH, int32_t KW, int32_t stride,
+                   int32_t pad_t, int32_t pad_l, const seg_view* dst, int32_t Ho, int32_t Wo, int32_t dtype, void* stream);
+int seg_col2im(const seg_view* col, int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t KH, int32_t KW, int32_t stride,
+               int32_t pad_t, int32_t pad_l, const float* bias, int32_t relu, const seg_view* dst, int32_t Ho, int32_t Wo,
+               int32_t dtype, void* stream);
+
 /* slim.max_pool2d(x, 2) (kernel 2, stride 2, VALID): models/unet.py:120,124,128,132; models/fcn.py:116-126.
  * idx (nullable): uint8 plane [B,Ho,Wo,C] with the first-max position 0..3 in window order. */
 int seg_maxpool2x2_fwd(const seg_view* src, const seg_view* dst, uint8_t* idx,
@@ -211,7 +223,7 @@ int seg_head_dw_reduce(const void* dw_ws, int64_t dw_ws_bytes, int32_t B, int32_
 int seg_sigmoid_argmax(const seg_view* logits, int32_t B, int32_t H, int32_t W, int32_t n_classes,
                        float* sig, float* out, void* stream);
 
-/* BiasAddGrad: db[c] += sum over B*H*W of dz[...,c] for c < n_log (atomic f32). */
+/* BiasAddGrad: db[c] = sum over B*H*W of dz[...,c] for c < n_log (overwritten; one workgroup per 8 channels, fixed order). */
 int seg_bias_grad(const seg_view* dz, int32_t B, int32_t H, int32_t W, int32_t n_log, float* db,
                   int32_t dtype, void* stream);
 

@@ -75,6 +75,8 @@ SIGNATURES = {
     'seg_conv_first_pool_fwd': [vp, i32, i32, i32, i32, vp, vp, i32, i32, PV, i32, i32, i32, PV, i32, i32, i32, vp],
     'seg_im2col3x3': [vp, i32, i32, i32, i32, i32, PV, i32, i32, i32, vp],
     'seg_im2col': [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, PV, i32, i32, i32, vp],
+    'seg_im2col_act': [PV, i32, i32, i32, i32, i32, i32, i32, i32, i32, PV, i32, i32, i32, vp],
+    'seg_col2im': [PV, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, PV, i32, i32, i32, vp],
     'seg_maxpool2x2_fwd': [PV, PV, vp, i32, i32, i32, i32, i32, vp],
     'seg_maxpool2x2_bwd': [PV, PV, PV, i32, i32, i32, i32, PV, i32, i32, i32, i32, i32, vp],
     'seg_softmax_xent': [PV, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, PV, i32, vp],

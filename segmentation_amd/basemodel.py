@@ -514,7 +514,7 @@ class BaseModel(object):
             k2 = l.wshape[0] * l.wshape[1]
             lim = (6.0 / (k2 * l.wshape[2] + k2 * l.wshape[3])) ** 0.5
             params[name] = {'weights': rng.uniform(-lim, lim, size=l.wshape).astype(np.float32),
-                            'biases': np.zeros((l.cout,), np.float32)}
+                            'biases': np.zeros((l.nbias,), np.float32)}
         self.store.set_params(params)
 
     def _repack_initial(self):

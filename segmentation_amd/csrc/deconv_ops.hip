@@ -823,3 +823,110 @@ extern "C" int seg_resize_bilinear_bwd(const seg_view* ddst, int32_t Hd, int32_t
   else { seg_set_error("resize_bilinear_bwd: bad dtype"); return SEG_ERR_ARG; }
   return seg_check_launch("resize_bilinear_bwd");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The 5x5/s2 transposed convolutions of the DeconvModel on the MFMA kernels (models/deconvolution.py deconv1_0, deconv2_0,
+// deconv2_1).  A transposed convolution T with filter [kh,kw,Cout,Cin] is the adjoint of the strided convolution C with
+// the SAME memory read as HWIO [kh,kw,Cin_C = Cout,Cout_C = Cin]; C is a 1x1 convolution over the strided im2col of its
+// input.  So:   T.forward(x)  = col2im( 1x1-dgrad_C(x) )        -> seg_col2im below (+ bias, ReLU)
+//               T.dgrad(dz)   = 1x1-forward_C( im2col(dz) )     -> seg_im2col_act below
+//               T.wgrad       = 1x1-wgrad_C( im2col(dz), x )    (the [1][kh*kw*Cout][Cin] result IS the TF filter layout)
+// Both kernels here only move data; the arithmetic runs in conv_fwd.hip / conv_wgrad.hip.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void im2col_act_kernel(seg_view src, int B, int Hs, int Ws, int C_, int KH, int KW, int stride, int pad_t, int pad_l, seg_view dst,
+                                  int Ho, int Wo, int pieces) {
+  const int64_t total = (int64_t)B * Ho * Wo * pieces;
+  const int nk = KH * KW * C_;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int piece = (int)(i % pieces);
+    int64_t t = i / pieces;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho); const int b = (int)(t / Ho);
+    Vec8<T> o;
+    const int k0 = piece * 8;
+    if ((C_ & 7) == 0 && k0 + 8 <= nk) {               // the eight k share one tap: one 16-byte load
+      const int tap = k0 / C_, c = k0 - tap * C_;
+      const int iy = oy * stride - pad_t + tap / KW, ix = ox * stride - pad_l + tap % KW;
+      if (iy >= 0 && iy < Hs && ix >= 0 && ix < Ws) o.load(reinterpret_cast<const T*>(src.ptr) + view_off(src, b, iy, ix) + c);
+      else o.zero();
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e;
+        float v = 0.f;
+        if (k < nk) {
+          const int tap = k / C_, c = k - tap * C_;
+          const int iy = oy * stride - pad_t + tap / KW, ix = ox * stride - pad_l + tap % KW;
+          if (iy >= 0 && iy < Hs && ix >= 0 && ix < Ws) v = (float)reinterpret_cast<const T*>(src.ptr)[view_off(src, b, iy, ix) + c];
+        }
+        o.set(e, v);
+      }
+    }
+    o.store(reinterpret_cast<T*>(dst.ptr) + view_off(dst, b, oy, ox) + piece * 8);
+  }
+}
+
+extern "C" int seg_im2col_act(const seg_view* src, int32_t B, int32_t Hs, int32_t Ws, int32_t C_, int32_t KH, int32_t KW, int32_t stride,
+                              int32_t pad_t, int32_t pad_l, const seg_view* dst, int32_t Ho, int32_t Wo, int32_t dtype, void* stream) {
+  if (!src || !dst || !view_ok(*src, Hs, Ws, src->c) || C_ < 1 || C_ > src->c || KH < 1 || KW < 1 || stride < 1 || pad_t < 0 || pad_l < 0 || B <= 0) { seg_set_error("im2col_act: bad args"); return SEG_ERR_ARG; }
+  if (!view_ok(*dst, Ho, Wo, dst->c) || dst->c % 32 || KH * KW * C_ > dst->c) { seg_set_error("im2col_act: destination must hold %d channels padded to a multiple of 32", KH * KW * C_); return SEG_ERR_ARG; }
+  const int pieces = dst->c / 8;
+  const int64_t n = (int64_t)B * Ho * Wo * pieces;
+  if (dtype == SEG_F32) SEG_LAUNCH(im2col_act_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, *src, B, Hs, Ws, C_, KH, KW, stride, pad_t, pad_l, *dst, Ho, Wo, pieces);
+  else if (dtype == SEG_BF16) SEG_LAUNCH(im2col_act_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, *src, B, Hs, Ws, C_, KH, KW, stride, pad_t, pad_l, *dst, Ho, Wo, pieces);
+  else { seg_set_error("im2col_act: bad dtype"); return SEG_ERR_ARG; }
+  return seg_check_launch("im2col_act");
+}
+
+// out[b,Y,X,c] = relu?( bias[c] + sum over taps (u,v) with (Y + pad_t - u) % s == 0, (X + pad_l - v) % s == 0 of
+//                col[b, (Y + pad_t - u)/s, (X + pad_l - v)/s, (u*KW + v)*C + c] ),   C % 8 == 0, c < C (channels beyond: zero)
+template <typename T>
+__global__ void col2im_kernel(seg_view col, int B, int Hi, int Wi, int C_, int KH, int KW, int stride, int pad_t, int pad_l, const float* bias,
+                              int relu, seg_view dst, int Ho, int Wo) {
+  const int C8 = dst.c / 8;
+  const int64_t total = (int64_t)B * Ho * Wo * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    int64_t t = i / C8;
+    const int X = (int)(t % Wo); t /= Wo;
+    const int Y = (int)(t % Ho); const int b = (int)(t / Ho);
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    if (c8 * 8 < C_) {
+      for (int u = (Y + pad_t) % stride; u < KH; u += stride) {
+        const int iy = (Y + pad_t - u) / stride;
+        if (Y + pad_t - u < 0 || iy >= Hi) continue;
+        for (int v = (X + pad_l) % stride; v < KW; v += stride) {
+          const int ix = (X + pad_l - v) / stride;
+          if (X + pad_l - v < 0 || ix >= Wi) continue;
+          Vec8<T> s; s.load(reinterpret_cast<const T*>(col.ptr) + view_off(col, b, iy, ix) + (u * KW + v) * C_ + c8 * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += s.get(e);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (bias) a[e] += bias[c8 * 8 + e];
+        if (relu) a[e] = fmaxf(a[e], 0.f);
+      }
+    }
+    Vec8<T> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.set(e, a[e]);
+    o.store(reinterpret_cast<T*>(dst.ptr) + view_off(dst, b, Y, X) + c8 * 8);
+  }
+}
+
+extern "C" int seg_col2im(const seg_view* col, int32_t B, int32_t Hi, int32_t Wi, int32_t C_, int32_t KH, int32_t KW, int32_t stride,
+                          int32_t pad_t, int32_t pad_l, const float* bias, int32_t relu, const seg_view* dst, int32_t Ho, int32_t Wo,
+                          int32_t dtype, void* stream) {
+  if (!col || !dst || C_ < 8 || C_ % 8 || KH < 1 || KW < 1 || stride < 1 || pad_t < 0 || pad_l < 0 || B <= 0 || !view_ok(*col, Hi, Wi, col->c) || KH * KW * C_ > col->c ||
+      !view_ok(*dst, Ho, Wo, dst->c) || C_ > dst->c) { seg_set_error("col2im: bad args (channel count a multiple of 8)"); return SEG_ERR_ARG; }
+  const int64_t n = (int64_t)B * Ho * Wo * (dst->c / 8);
+  if (dtype == SEG_F32) SEG_LAUNCH(col2im_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, *col, B, Hi, Wi, C_, KH, KW, stride, pad_t, pad_l, bias, relu, *dst, Ho, Wo);
+  else if (dtype == SEG_BF16) SEG_LAUNCH(col2im_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, *col, B, Hi, Wi, C_, KH, KW, stride, pad_t, pad_l, bias, relu, *dst, Ho, Wo);
+  else { seg_set_error("col2im: bad dtype"); return SEG_ERR_ARG; }
+  return seg_check_launch("col2im");
+}

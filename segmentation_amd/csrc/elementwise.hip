@@ -458,32 +458,30 @@ __global__ void sigmoid_argmax_kernel(seg_view lg, int B, int H, int W, int nc, 
 // bias grad: column sums of a [B*H*W, C] window
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void bias_grad_kernel(seg_view dz, int B, int H, int W, int C8, int n_log, float* db) {
-  __shared__ float red[256 * 8];
-  const int tid = threadIdx.x;
-  const int c8 = tid % C8, pl = tid / C8, npl = 256 / C8;     // C8 <= 256 (checked by the launcher)
+__global__ __launch_bounds__(1024) void bias_grad_kernel(seg_view dz, int B, int H, int W, int n_log, float* db) {
+  // one workgroup per 8-channel group: a fixed summation order (bitwise reproducible), db overwritten
+  __shared__ float red[1024 * 8];
+  const int tid = threadIdx.x, c8 = blockIdx.x;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const int64_t npix = (int64_t)B * H * W;
-  if (pl < npl) {
-    for (int64_t p = (int64_t)blockIdx.x * npl + pl; p < npix; p += (int64_t)gridDim.x * npl) {
-      int64_t t = p;
-      const int x = t % W; t /= W;
-      const int y = t % H; const int b = t / H;
-      Vec8<T> v;
-      v.load(reinterpret_cast<const T*>(dz.ptr) + view_off(dz, b, y, x) + c8 * 8);
+  const int npix = B * H * W;
+  for (int p = tid; p < npix; p += 1024) {
+    const Idx3 q_ = split3(p, W, H);
+    Vec8<T> v;
+    v.load(reinterpret_cast<const T*>(dz.ptr) + view_off(dz, q_.b, q_.y, q_.x) + c8 * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s[e] += v.get(e);
-    }
+    for (int e = 0; e < 8; ++e) s[e] += v.get(e);
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) red[tid * 8 + e] = s[e];
+  for (int e = 0; e < 8; ++e) red[e * 1024 + tid] = s[e];
   __syncthreads();
-  for (int ch = tid; ch < C8 * 8 && ch < n_log; ch += 256) {
-    const int cc8 = ch / 8, e = ch % 8;
-    float a = 0.f;
-    for (int q = 0; q < npl; ++q) a += red[(q * C8 + cc8) * 8 + e];
-    atomicAdd(db + ch, a);
+  for (int h = 512; h > 0; h >>= 1) {
+    if (tid < h) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[e * 1024 + tid] += red[e * 1024 + tid + h];
+    }
+    __syncthreads();
   }
+  if (tid < 8 && c8 * 8 + tid < n_log) db[c8 * 8 + tid] = red[tid * 1024];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1146,15 +1144,11 @@ extern "C" int seg_sigmoid_argmax(const seg_view* logits, int32_t B, int32_t H, 
 }
 
 extern "C" int seg_bias_grad(const seg_view* dz, int32_t B, int32_t H, int32_t W, int32_t n_log, float* db, int32_t dtype, void* stream) {
-  if (!dz || !dz->ptr || !db || dz->c % 8 || dz->c > 2048 || n_log > dz->c || !view_ok(dz, H, W, dz->c)) { seg_set_error("bias_grad: bad args"); return SEG_ERR_ARG; }
-  const int C8 = dz->c / 8;
-  const int64_t npix = (int64_t)B * H * W;
-  int npl = 256 / C8; if (npl < 1) npl = 1;
-  if (C8 > 256) { seg_set_error("bias_grad: more than 2048 channels"); return SEG_ERR_UNSUPPORTED; }
-  const int g = grid_for(npix, npl * 16, 1024);
+  if (!dz || !dz->ptr || !db || dz->c % 8 || n_log > dz->c || n_log < 1 || !view_ok(dz, H, W, dz->c) || (int64_t)B * H * W >= ((int64_t)1 << 31)) { seg_set_error("bias_grad: bad args"); return SEG_ERR_ARG; }
+  const int g = (n_log + 7) / 8;
   DISPATCH(dtype,
-           SEG_LAUNCH(bias_grad_kernel<float>, dim3(g), dim3(256), 0, ST(stream), *dz, B, H, W, C8, n_log, db),
-           SEG_LAUNCH(bias_grad_kernel<bf16_t>, dim3(g), dim3(256), 0, ST(stream), *dz, B, H, W, C8, n_log, db));
+           SEG_LAUNCH(bias_grad_kernel<float>, dim3(g), dim3(1024), 0, ST(stream), *dz, B, H, W, n_log, db),
+           SEG_LAUNCH(bias_grad_kernel<bf16_t>, dim3(g), dim3(1024), 0, ST(stream), *dz, B, H, W, n_log, db));
   return seg_check_launch("bias_grad");
 }
 

@@ -18,6 +18,8 @@ test() is the moving-average graph (models/basemodel.py:397).  Moving averages a
 step): TF's RNG stream cannot be reproduced, so the masks are build-defined (oracle.np_ops.dropout_mask restates them).
 Limits: even input sizes (the reference pads an odd one by a row after deconv3_0; rejected here), input >= 140 pixels.
 Data parallel: batch statistics are per rank (like slim towers); rank 0's moving averages are the ones snapshotted."""
+import os
+
 import numpy as np
 import torch
 
@@ -43,9 +45,16 @@ def deconv_layers(n_classes, nk, cin):
     add('conv2_0', 'conv', 3, nk, 2 * nk); add('bn2', 'bn', 1, 2 * nk, 2 * nk)
     add('conv3_0', 'conv', 3, 2 * nk, 4 * nk); add('bn3', 'bn', 1, 4 * nk, 4 * nk)
     add('conv4_0', 'conv', 3, 4 * nk, 8 * nk); add('bn4', 'bn', 1, 8 * nk, 8 * nk)
-    add('deconv1_0', 'dtrans', 5, 8 * nk, 2 * nk, stride=2); add('bn5', 'bn', 1, 2 * nk, 2 * nk)
-    add('deconv2_0', 'dtrans', 5, 2 * nk, nk, stride=2); add('bn6', 'bn', 1, nk, nk)
-    add('deconv2_1', 'dtrans', 5, nk, nk, stride=2); add('bn7', 'bn', 1, nk, nk)
+    # the 5x5/s2 transposed convolutions: on the MFMA kernels as adjoints of strided convolutions (engine.Net.tconv_layer) when their
+    # channel counts allow the 16-byte gathers (multiples of 8), else on the direct kernels
+    def addt(name, ci, co):
+        if co % 8 == 0 and os.environ.get('SEG_TCONV_MFMA', '1') != '0':
+            Ly[name] = E.Net.tconv_layer(name, 5, ci, co, 2)
+        else:
+            add(name, 'dtrans', 5, ci, co, stride=2)
+    addt('deconv1_0', 8 * nk, 2 * nk); add('bn5', 'bn', 1, 2 * nk, 2 * nk)
+    addt('deconv2_0', 2 * nk, nk); add('bn6', 'bn', 1, nk, nk)
+    addt('deconv2_1', nk, nk); add('bn7', 'bn', 1, nk, nk)
     add('deconv3_0', 'up', 2, nk, n_classes); add('bn8', 'bn', 1, n_classes, n_classes)
     add('conv_out', 'conv', 3, n_classes, n_classes, 'SAME', relu=False)
     Ly['conv1_0'].need_dgrad = False
@@ -203,10 +212,14 @@ class DeconvModel(BaseModel):
         net.conv_fwd(plan, Ly['conv4_0'], [(P[3], 0, 0)], P[3].H, P[3].W, a)
         t = act_bn('conv4_0', a)
         for dn in ('deconv1_0', 'deconv2_0', 'deconv2_1'):
-            a = net.act(sz[dn], sz[dn], Ly[dn].cout, name=dn)
-            net.dlayer_fwd(plan, Ly[dn], t, a)
+            tc = getattr(Ly[dn], 'tconv', None)
+            a = net.act(sz[dn], sz[dn], tc[2] if tc else Ly[dn].cout, name=dn)
+            if tc:
+                net.tconv_fwd(plan, Ly[dn], t, a)
+            else:
+                net.dlayer_fwd(plan, Ly[dn], t, a)
             t = act_bn(dn, a)
-        R = net.act(sz['resize'], sz['resize'], Ly['deconv2_1'].cout, name='resize')
+        R = net.act(sz['resize'], sz['resize'], t.C, name='resize')
         net.resize_fwd(plan, t, R)
         a = net.act(sz['deconv3_0'], sz['deconv3_0'], self.n_classes, name='deconv3_0')
         net.up_fwd(plan, Ly['deconv3_0'], R, R.H, R.W, a)
@@ -270,7 +283,10 @@ class DeconvModel(BaseModel):
             dz = bn_bwd(b, dn, d)
             src = last(srcs[dn])
             d = like(src, 'd_' + srcs[dn] + '_out')
-            net.dlayer_bwd(seg, Ly[dn], src, dz, dsrc=d, mask=None)
+            if getattr(Ly[dn], 'tconv', None):
+                net.tconv_bwd(seg, Ly[dn], src, dz, dsrc=d)
+            else:
+                net.dlayer_bwd(seg, Ly[dn], src, dz, dsrc=d, mask=None)
         dz = bn_bwd('bn4', 'conv4_0', d)
         dP = {3: like(P[3], 'dpool3')}
         net.conv_bwd(seg, Ly['conv4_0'], [(P[3], 0, 0)], P[3].H, P[3].W, dz, [(dP[3], (0, 0), None, (0, 0))])

@@ -104,7 +104,7 @@ class ParamStore(object):
             modes = []
             if l.kind == 'conv':
                 modes.append((L.PACK_CONV_FWD, l.k * l.k, kin, l.cout_p, 'pk_fwd'))
-                if training and l.need_dgrad:
+                if (training and l.need_dgrad) or getattr(l, 'tconv', None):      # (a transposed conv's FORWARD is the 1x1 dgrad)
                     modes.append((L.PACK_CONV_DGRAD, l.k * l.k, l.cout_p, kin, 'pk_dgrad'))
             else:
                 modes.append((L.PACK_UP_FWD, 1, kin, 4 * l.cout_p, 'pk_fwd'))
@@ -962,6 +962,83 @@ class Net(object):
         d.mask = mask.view() if mask is not None else L.null_view()
         d.dtype = self.dtype
         return d
+
+    # ---- k x k / stride-s transposed convolutions on the MFMA kernels (Layer.tconv = (k, stride, Cout); see deconv_ops.hip) ----
+    @staticmethod
+    def tconv_layer(name, k, cin, cout, stride, relu=True):
+        """The layer object of a VALID transposed convolution [k,k,Cout,Cin] run as the adjoint of a strided convolution that is
+        a 1x1 convolution over an im2col: a 'conv' layer with K = k*k*Cout inputs and Cin outputs over the same parameter memory
+        (TF filter layout kept for get/set_params and snapshots; the bias has Cout entries)."""
+        l = Layer(name, 'conv', 1, [k * k * cout], cin, 'VALID', relu)
+        l.wshape = (k, k, cout, cin)
+        l.nbias = cout
+        l.tconv = (k, stride, cout)
+        return l
+
+    def _conv1x1_desc(self, layer, src_view, dst_view, H, W, dgrad):
+        d = L.ConvDesc()
+        d.accum = 0
+        d.src0 = src_view; d.src1 = L.null_view()
+        d.B, d.Hi, d.Wi = self.B, H, W
+        d.KH = d.KW = 1; d.stride = 1; d.pad_t = d.pad_l = 0
+        d.Ho, d.Wo = H, W
+        if dgrad:
+            d.w_packed = self.store.packed_ptr(layer.pk_dgrad); d.n_total = layer.cin_p[0]
+        else:
+            d.w_packed = self.store.packed_ptr(layer.pk_fwd); d.n_total = layer.cout_p
+        d.n_off = 0; d.n_count = d.n_total
+        d.bias = None; d.bias_n = 0
+        d.dst = dst_view; d.up2 = 0; d.up_cout = 0; d.mask = L.null_view()
+        d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = 0
+        return d
+
+    def tconv_fwd(self, plan, layer, src, dst):
+        """dst = relu(bias + conv2d_transpose(src)): the 1x1 data gradient of the adjoint convolution (MFMA), then the col2im gather"""
+        k, s_, co = layer.tconv
+        Hi, Wi = src.H, src.W
+        col = self.act(Hi, Wi, k * k * co, name=layer.name + '/col')
+        sv, cv, ov = src.view(), col.view(), dst.view()
+        d = self._conv1x1_desc(layer, sv, cv, Hi, Wi, dgrad=True)
+        plan.keep += [d, sv, cv, ov]
+        fl = 2 * self.B * Hi * Wi * k * k * co * layer.cout
+        plan.add(layer.name, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl,
+                 bytes=self.B * Hi * Wi * (layer.cout + k * k * co) * self.es + k * k * co * layer.cout * self.es)
+        plan.add(layer.name + '/col2im', self.lib.seg_col2im, C.byref(cv), self.B, Hi, Wi, co, k, k, s_, 0, 0, self.store.p_ptr(layer.b_off),
+                 1 if layer.relu else 0, C.byref(ov), dst.H, dst.W, self.dtype, kernel='col2im_kernel')
+        plan.flops += fl
+
+    def tconv_bwd(self, plan, layer, src, dz, dsrc=None):
+        """bias, filter and (dsrc given) input gradient of a tconv layer from its masked output gradient dz"""
+        k, s_, co = layer.tconv
+        Hi, Wi = src.H, src.W
+        zv, sv = dz.view(), src.view()
+        col = self.act(Hi, Wi, k * k * co, name=layer.name + '/dzcol')
+        cv = col.view()
+        plan.keep += [zv, sv, cv]
+        plan.add(layer.name + '/db', self.lib.seg_bias_grad, C.byref(zv), self.B, dz.H, dz.W, co, self.store.g_ptr(layer.b_off), self.dtype,
+                 kernel='bias_grad_kernel')
+        plan.add(layer.name + '/im2col', self.lib.seg_im2col_act, C.byref(zv), self.B, dz.H, dz.W, co, k, k, s_, 0, 0, C.byref(cv), Hi, Wi,
+                 self.dtype, kernel='im2col_act_kernel')
+        w = L.WgradDesc()
+        w.src0 = cv; w.src1 = L.null_view(); w.src0_clog = k * k * co; w.src1_clog = 0
+        w.B, w.Hi, w.Wi = self.B, Hi, Wi
+        w.KH = w.KW = 1; w.stride = 1; w.pad_t = w.pad_l = 0
+        w.Ho, w.Wo = Hi, Wi
+        w.dz = sv; w.n_log = layer.cout
+        w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = 0
+        w.bias_mode = 0; w.db = None; w.bias_n = 0
+        self._wgrad_ws(w, plan)
+        fl = 2 * self.B * Hi * Wi * k * k * co * layer.cout
+        self._wg_bytes = self.B * Hi * Wi * (k * k * co + layer.cout) * self.es + k * k * co * layer.cout * 4
+        self._add_wgrad(plan, layer.name + '/dw', w, fl)
+        plan.flops += fl
+        if dsrc is not None:
+            dv = dsrc.view()
+            d = self._conv1x1_desc(layer, cv, dv, Hi, Wi, dgrad=False)
+            plan.keep += [d, dv]
+            plan.add(layer.name + '/dx', self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl,
+                     bytes=self.B * Hi * Wi * (layer.cout + k * k * co) * self.es + k * k * co * layer.cout * self.es)
+            plan.flops += fl
 
     def dlayer_fwd(self, plan, layer, src, dst):
         """forward of a 'direct' conv (src -> dst) or a 'dtrans' transposed conv (small src -> large dst), bias + ReLU"""
