@@ -336,7 +336,7 @@ __global__ void maxpool_k_bwd_kernel(seg_view src, seg_view dpool, seg_view dsrc
 //   apply    : elementwise
 // MODE 0: s1 = sum a, s2 = sum a^2.  MODE 1: s1 = sum dy, s2 = sum dy * xhat.
 // ------------------------------------------------------------------------------------------
-constexpr int BN_NB = 256;
+constexpr int BN_NB = 1024;      // partial-sum rows = workgroups of the statistics pass (256 left three quarters of the resident slots empty on the 512 x 512 maps)
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(seg_view a, seg_view dy, const float* stats, int B, int H, int W, int C, float* ws) {
@@ -383,10 +383,20 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(seg_view a, seg_view dy
 template <int MODE>
 __global__ void bn_final_kernel(const float* ws, int nb, int C, int c_log, double inv_n, float eps, float decay, int training,
                                 float* moving, float* stats, float* out2, float* dbeta, int dbeta_add) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  // 32 channels x 8 slices per workgroup: a thread sums every 8th partial row, the slices meet in LDS in a fixed order (one
+  // thread per channel walking all nb rows was 60 us of pure load latency per batch norm)
+  __shared__ double r1[8][32], r2[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nb; ++b) { s1 += (double)ws[((int64_t)b * C + c) * 2]; s2 += (double)ws[((int64_t)b * C + c) * 2 + 1]; }
+  if (c < C)
+    for (int b = sl; b < nb; b += 8) { s1 += (double)ws[((int64_t)b * C + c) * 2]; s2 += (double)ws[((int64_t)b * C + c) * 2 + 1]; }
+  r1[sl][cl] = s1; r2[sl][cl] = s2;
+  __syncthreads();
+  if (sl != 0 || c >= C) return;
+  s1 = 0.0; s2 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { s1 += r1[q][cl]; s2 += r2[q][cl]; }
   if (MODE == 0) {
     float mean, var;
     if (training) {
@@ -411,13 +421,32 @@ __global__ void bn_final_kernel(const float* ws, int nb, int C, int c_log, doubl
 }
 
 template <typename T, int MODE>
-__global__ void bn_apply_kernel(seg_view a, seg_view in2, seg_view out, const float* stats, const float* aux, int B, int H, int W, int C8, int C, int c_log) {
+__global__ void bn_apply_kernel(seg_view a, seg_view in2, seg_view out, const float* stats_g, const float* aux_g, int B, int H, int W, int C8, int C, int c_log) {
+  // the per-channel constants go through LDS once per workgroup: read from global memory they were 16-24 scalar loads per
+  // 16-byte element and the kernel ran at a quarter of the HBM rate
+  extern __shared__ float sst[];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    sst[c] = stats_g[c]; sst[C + c] = stats_g[C + c];
+    if (MODE == 0) { sst[2 * C + c] = c < c_log ? aux_g[c] : 0.f; sst[3 * C + c] = 0.f; }
+    else { sst[2 * C + c] = aux_g[c]; sst[3 * C + c] = aux_g[C + c]; }
+  }
+  __syncthreads();
+  const float* stats = sst;
+  const float* aux = sst + 2 * C;
   const int64_t total = (int64_t)B * H * W * C8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = i;
-    const int c8 = t % C8; t /= C8;
-    const int x = t % W; t /= W;
-    const int y = t % H; const int b = t / H;
+    int c8, x, y, b;
+    if (i <= 0x7fffffff) {                               // (32-bit divisions: the 64-bit ones were most of this kernel's time)
+      unsigned t = (unsigned)i;
+      c8 = t % (unsigned)C8; t /= (unsigned)C8;
+      x = t % (unsigned)W; t /= (unsigned)W;
+      y = t % (unsigned)H; b = t / (unsigned)H;
+    } else {
+      int64_t t = i;
+      c8 = t % C8; t /= C8;
+      x = t % W; t /= W;
+      y = t % H; b = (int)(t / H);
+    }
     Vec8<T> av; av.load(reinterpret_cast<const T*>(a.ptr) + view_off(a, b, y, x) + c8 * 8);
     Vec8<T> o;
     if (MODE == 0) {                                     // aux = beta (c_log entries: pad channels stay 0)
@@ -775,12 +804,12 @@ extern "C" int seg_bn_fwd(const seg_view* a, const seg_view* y, const float* bet
     else SEG_LAUNCH((bn_partial_kernel<bf16_t, 0>), dim3(nb), dim3(256), 0, st, *a, none, (const float*)nullptr, B, H, W, C, ws);
     if (int rc = seg_check_launch("bn_partial")) return rc;
   }
-  SEG_LAUNCH(bn_final_kernel<0>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, training ? nb : 0, C, c_log, 1.0 / (double)npix, eps, decay,
+  SEG_LAUNCH(bn_final_kernel<0>, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)ws, training ? nb : 0, C, c_log, 1.0 / (double)npix, eps, decay,
              training, moving, stats, (float*)nullptr, (float*)nullptr, 0);
   if (int rc = seg_check_launch("bn_final")) return rc;
   const int g = grid_for(npix * (C / 8));
-  if (dtype == SEG_F32) SEG_LAUNCH((bn_apply_kernel<float, 0>), dim3(g), dim3(256), 0, st, *a, none, *y, (const float*)stats, beta, B, H, W, C / 8, C, c_log);
-  else SEG_LAUNCH((bn_apply_kernel<bf16_t, 0>), dim3(g), dim3(256), 0, st, *a, none, *y, (const float*)stats, beta, B, H, W, C / 8, C, c_log);
+  if (dtype == SEG_F32) SEG_LAUNCH((bn_apply_kernel<float, 0>), dim3(g), dim3(256), (size_t)C * 16, st, *a, none, *y, (const float*)stats, beta, B, H, W, C / 8, C, c_log);
+  else SEG_LAUNCH((bn_apply_kernel<bf16_t, 0>), dim3(g), dim3(256), (size_t)C * 16, st, *a, none, *y, (const float*)stats, beta, B, H, W, C / 8, C, c_log);
   return seg_check_launch("bn_apply");
 }
 
@@ -795,12 +824,12 @@ extern "C" int seg_bn_relu_bwd(const seg_view* a, const seg_view* dy, const seg_
   if (dtype == SEG_F32) SEG_LAUNCH((bn_partial_kernel<float, 1>), dim3(nb), dim3(256), 0, st, *a, *dy, stats, B, H, W, C, ws);
   else SEG_LAUNCH((bn_partial_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, st, *a, *dy, stats, B, H, W, C, ws);
   if (int rc = seg_check_launch("bn_partial_bwd")) return rc;
-  SEG_LAUNCH(bn_final_kernel<1>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, nb, C, c_log, 1.0 / (double)npix, 0.f, 0.f, 1,
+  SEG_LAUNCH(bn_final_kernel<1>, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)ws, nb, C, c_log, 1.0 / (double)npix, 0.f, 0.f, 1,
              (float*)nullptr, (float*)nullptr, means, dbeta, dbeta_add);
   if (int rc = seg_check_launch("bn_final_bwd")) return rc;
   const int g = grid_for(npix * (C / 8));
-  if (dtype == SEG_F32) SEG_LAUNCH((bn_apply_kernel<float, 1>), dim3(g), dim3(256), 0, st, *a, *dy, *dz, stats, (const float*)means, B, H, W, C / 8, C, c_log);
-  else SEG_LAUNCH((bn_apply_kernel<bf16_t, 1>), dim3(g), dim3(256), 0, st, *a, *dy, *dz, stats, (const float*)means, B, H, W, C / 8, C, c_log);
+  if (dtype == SEG_F32) SEG_LAUNCH((bn_apply_kernel<float, 1>), dim3(g), dim3(256), (size_t)C * 16, st, *a, *dy, *dz, stats, (const float*)means, B, H, W, C / 8, C, c_log);
+  else SEG_LAUNCH((bn_apply_kernel<bf16_t, 1>), dim3(g), dim3(256), (size_t)C * 16, st, *a, *dy, *dz, stats, (const float*)means, B, H, W, C / 8, C, c_log);
   return seg_check_launch("bn_apply_bwd");
 }
 
