@@ -58,6 +58,7 @@ def parse():
     ap.add_argument('--force-dist', action='store_true', help='diagnostic: take the data-parallel code path (RCCL group of size 1) on one GPU')
     ap.add_argument('--dp-cuts', default='auto', help="N>1: gradient-bucket boundaries (layer names, backward order); 'auto' times three bucket plans "
                     "(2, 4 and 6 buckets) on the actual node during warm-up and keeps the fastest; 'default' = the model's 4-bucket plan")
+    ap.add_argument('--windows', type=int, default=5, help='timed windows of --steps steps each; the FIRST one is `value`, all of them are reported as config.ms_per_step_windows')
     ap.add_argument('--host-data', action='store_true', help='feed from host memory through the pinned-buffer prefetcher (PCIe-inclusive rate; not the headline value)')
     return ap.parse_args()
 
@@ -354,6 +355,34 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    # Beside `value` (exactly K steps, above): further windows of K steps each, same bracketing, max over ranks; their median
+    # says whether the headline window caught a clock / thermal transient (at K = 20 a window is ~20 ms).  Not part of `value`.
+    windows = [dt / args.steps * 1e3]
+    for _ in range(0 if args.windows <= 1 else args.windows - 1):
+        barrier()
+        w0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        wd = time.perf_counter() - w0
+        if world > 1:
+            t = torch.tensor([wd], dtype=torch.float64, device='cuda')
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            wd = float(t.item())
+        windows.append(wd / args.steps * 1e3)
+    # per-bucket exposure of the gradient all-reduce: the instrumented steps issue real collectives, so EVERY rank runs them
+    # (rank 0 alone would wait for peers that have already left); only rank 0 reports
+    dp_rep = None
+    if world > 1 and training and dp:
+        try:
+            dp_rep = model.dp_exposure_report()
+        except Exception as e:                           # noqa
+            dp_rep = {'error': repr(e)}
+    elif args.force_dist and training and dp:
+        try:
+            dp_rep = model.dp_exposure_report()
+        except Exception as e:                           # noqa
+            dp_rep = {'error': repr(e)}
 
     out = None
     if rank == 0:
@@ -374,14 +403,14 @@ def main():
         }
         if training:
             out['config']['final_loss'] = round(model.last_loss(), 5)
-        if world > 1 and training:
-            # per-bucket exposure of the gradient all-reduce: how long the update waits for each bucket after the last
-            # backward segment has been enqueued (measured with events on rank 0 in one instrumented step)
-            try:
-                out['config']['allreduce'] = model.dp_exposure_report()
+        sw = sorted(windows)
+        out['config']['ms_per_step_windows'] = {'n': len(windows), 'steps_each': args.steps, 'median': round(sw[len(sw) // 2], 4),
+                                                'min': round(sw[0], 4), 'max': round(sw[-1], 4), 'all': [round(w, 4) for w in windows]}
+        if dp_rep is not None:
+            # how long the update waits for each gradient bucket after the last backward segment has been enqueued
+            out['config']['allreduce'] = dp_rep
+            if isinstance(dp_rep, dict):
                 out['config']['allreduce']['bucket_plan_probe_ms'] = cuts_probe
-            except Exception as e:                       # noqa
-                out['config']['allreduce'] = {'error': repr(e)}
     # roofline / per-kernel table: eager, instrumented, after the timed region (rank 0 only does the reporting)
     if not args.no_roofline and world == 1:
         stream = torch.cuda.current_stream().cuda_stream
@@ -420,6 +449,7 @@ def main():
         print(json.dumps(out), file=json_out)
         json_out.flush()
     if world > 1 or args.force_dist:
+        barrier()                                   # nobody tears the group down while a peer is still inside a collective
         torch.distributed.destroy_process_group()
 
 
