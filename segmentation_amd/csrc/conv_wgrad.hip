@@ -12,6 +12,7 @@
 // (deterministic, no atomics: 768 workgroups hammering one 36 KB filter with f32 atomics measured 10-30x
 // slower than the MFMA work).  The bias gradient rides along as one extra MFMA against an all-ones fragment.
 #include "common.h"
+#include "wgrad_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -672,19 +673,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK P) {
   }
 }
 
-// Sums the ksplit slabs (fixed association => bitwise reproducible) and scatters to the logical TF layout.
-// One thread owns V consecutive n (V = 4: 16-byte coalesced loads, needs n_log % 4 == 0).  SG = 16: a block =
+// Sums the ksplit slabs (fixed association => bitwise reproducible) and scatters to the logical TF layout (RedArgs / RedJob:
+// wgrad_common.h).  One thread owns V consecutive n (V = 4: 16-byte coalesced loads, needs n_log % 4 == 0).  SG = 16: a block =
 // 16 outputs x 16 split groups, group g sums splits g, g+16, ... (8 loads in flight), partials meet in LDS and
 // are added in group order; SG = 1 (few splits): one thread per output.
-struct RedArgs {
-  const float* ws; float* dw; float* db;
-  int64_t slab;
-  int ksplit, taps, k_pad, n_pad, seg0_c, seg0_cp, seg1_c, n_log, bias_mode, bias_n;
-};
-// One job of the batched reduction (seg_wgrad_reduce_batch): RedArgs + the job's block range and kernel form.
-struct RedJob { RedArgs a; int first_block, nblocks, flags, pad_; int64_t pad2_; };
-static_assert(sizeof(RedJob) == 96, "RedJob is an opaque 96-byte record in the C-ABI");
-
 template <int V>
 SEG_DEV void reduce_body(const RedArgs& A, const int sg_log, const int blk, const int nblk, float* red) {
   const float* ws = A.ws; float* dw = A.dw; float* db = A.db;
@@ -872,22 +864,11 @@ int launch_cfg(const WgK& P0, hipStream_t st) {
     rc = seg_check_launch("conv_wgrad");
   }
   if (rc || P.direct || (P.d.phase == 1 && !g_job_out)) return rc;
-  const int taps = KH * KW, k_log = P.d.src0_clog + P.d.src1_clog;
-  const bool v4 = (P.d.n_log % 4 == 0) && (P.n_pad % 4 == 0);
-  const int V = v4 ? 4 : 1;
-  const int64_t units = (int64_t)taps * k_log * (P.d.n_log / V) + (P.d.bias_mode ? (P.d.bias_n + V - 1) / V : 0);
-  // split groups: one 8-deep load batch per thread whenever ksplit <= 256 (sg = ceil(ks/8) rounded up to a power of two)
-  int sg_log = 0;
-  while ((8 << sg_log) < ks && sg_log < 5) ++sg_log;
-  const int opb = 256 >> sg_log;
-  int rg = (int)((units + opb - 1) / opb); if (rg > 16384) rg = 16384;
   RedArgs RA;
-  RA.ws = P.d.ws; RA.dw = P.d.dw; RA.db = P.d.db; RA.slab = P.slab; RA.ksplit = ks; RA.taps = taps; RA.k_pad = P.k_pad; RA.n_pad = P.n_pad;
+  RA.ws = P.d.ws; RA.dw = P.d.dw; RA.db = P.d.db; RA.slab = P.slab; RA.ksplit = ks; RA.taps = KH * KW; RA.k_pad = P.k_pad; RA.n_pad = P.n_pad;
   RA.seg0_c = P.d.src0_clog; RA.seg0_cp = P.d.src0.c; RA.seg1_c = P.d.src1_clog; RA.n_log = P.d.n_log; RA.bias_mode = P.d.bias_mode; RA.bias_n = P.d.bias_n;
-  if (g_job_out) { g_job_out->a = RA; g_job_out->nblocks = rg; g_job_out->flags = (v4 ? 1 : 0) | (sg_log << 4); g_job_out->first_block = 0; g_job_out->pad_ = 0; return SEG_OK; }
-  if (v4) SEG_LAUNCH((wgrad_reduce_kernel<4>), dim3(rg), dim3(256), 0, st, RA, sg_log);
-  else SEG_LAUNCH((wgrad_reduce_kernel<1>), dim3(rg), dim3(256), 0, st, RA, sg_log);
-  return seg_check_launch("wgrad_reduce");
+  WgQuery q = WgQuery(); q.job_out = g_job_out;
+  return seg_wgrad_reduce_launch(RA, ks, q, st);
 }
 
 template <typename T, int KH, int KW, int S>
@@ -984,6 +965,22 @@ int launch_t(const WgK& P, hipStream_t st) {
 
 }  // namespace
 
+int seg_wgrad_reduce_launch(const RedArgs& RA, int ks, const WgQuery& q, hipStream_t st) {
+  const bool v4 = (RA.n_log % 4 == 0) && (RA.n_pad % 4 == 0);
+  const int V = v4 ? 4 : 1;
+  const int k_log = RA.seg0_c + RA.seg1_c;
+  const int64_t units = (int64_t)RA.taps * k_log * (RA.n_log / V) + (RA.bias_mode ? (RA.bias_n + V - 1) / V : 0);
+  // split groups: one 8-deep load batch per thread whenever ksplit <= 256 (sg = ceil(ks/8) rounded up to a power of two)
+  int sg_log = 0;
+  while ((8 << sg_log) < ks && sg_log < 5) ++sg_log;
+  const int opb = 256 >> sg_log;
+  int rg = (int)((units + opb - 1) / opb); if (rg > 16384) rg = 16384;
+  if (q.job_out) { q.job_out->a = RA; q.job_out->nblocks = rg; q.job_out->flags = (v4 ? 1 : 0) | (sg_log << 4); q.job_out->first_block = 0; q.job_out->pad_ = 0; return SEG_OK; }
+  if (v4) SEG_LAUNCH((wgrad_reduce_kernel<4>), dim3(rg), dim3(256), 0, st, RA, sg_log);
+  else SEG_LAUNCH((wgrad_reduce_kernel<1>), dim3(rg), dim3(256), 0, st, RA, sg_log);
+  return seg_check_launch("wgrad_reduce");
+}
+
 extern "C" int seg_conv2d_wgrad(const seg_wgrad_desc* dp, void* stream);
 extern "C" int seg_conv2d_wgrad_kernel_name(const seg_wgrad_desc* dp, char* buf, int32_t cap) {
   if (!buf || cap <= 0) { seg_set_error("kernel_name: bad buffer"); return SEG_ERR_ARG; }
@@ -1040,6 +1037,12 @@ extern "C" int seg_conv2d_wgrad(const seg_wgrad_desc* dp, void* stream) {
       (d.src1.ptr && (d.src1.oy + d.Hi > d.src1.H || d.src1.ox + d.Wi > d.src1.W || d.src1.coff + d.src1.c > d.src1.cs)) ||
       d.dz.oy + d.Ho > d.dz.H || d.dz.ox + d.Wo > d.dz.W || d.dz.coff + d.dz.c > d.dz.cs) {
     seg_set_error("wgrad: window exceeds its buffer"); return SEG_ERR_ARG;
+  }
+  {
+    // bf16 3x3 / stride 1: the wave-specialised walk (wgrad_sweep.hip) unless the caller asks for a layout of this file (cfg 1..99)
+    WgQuery q; q.name_out = g_wname_out; q.name_cap = g_wname_cap; q.plan_ks = g_plan_ks; q.plan_bytes = g_plan_bytes; q.job_out = g_job_out;
+    int rc = SEG_OK;
+    if (seg_wgrad_sweep(d, q, reinterpret_cast<hipStream_t>(stream), &rc)) return rc;
   }
   WgK P;
   P.d = d;

@@ -161,6 +161,71 @@ def test_wgrad_layouts(case):
     assert torch.equal(g1, store.g)
 
 
+@pytest.mark.parametrize('case', [
+    # padding, segs, cout, H, W, B, wcfg (200 + 10 * tap groups + window class; 0 = automatic), ksplit (0 = automatic)
+    ('VALID', [64], 64, 37, 35, 3, 210, 0),             # 64 ci x 64 co, all 9 taps, 4-K-step windows, 3-stage ring
+    ('VALID', [64], 64, 37, 35, 3, 211, 0),             # ... 8-K-step windows, 2-stage ring
+    ('VALID', [64], 64, 37, 35, 3, 230, 1),             # one filter row per workgroup, every workgroup sweeps all pixels (no slabs)
+    ('VALID', [64], 64, 37, 35, 3, 291, 1),             # one tap per workgroup
+    ('VALID', [64], 64, 37, 35, 3, 290, 3),             # one tap per workgroup AND a K split (slabs + reduction)
+    ('SAME', [128], 64, 20, 44, 2, 210, 0),             # two X chunks, zero padding: every window is an edge window
+    ('SAME', [128], 64, 20, 44, 2, 231, 2),
+    ('VALID', [64, 64], 128, 26, 26, 2, 210, 0),        # channel-concat input, two dZ blocks
+    ('VALID', [64], 64, 61, 59, 4, 210, 5),             # long window walk + K split + slab reduction
+    ('VALID', [256], 256, 10, 10, 5, 211, 1),           # deep layer: 8 x 8 maps, several images per window, direct store
+    ('VALID', [256], 256, 10, 10, 5, 291, 1),
+    ('VALID', [128], 192, 12, 12, 3, 230, 1),           # whole 10 x 10 maps as windows (100 pixels -> 4 K steps)
+    ('VALID', [128], 128, 16, 16, 2, 211, 1),           # 14 x 14 = 196 pixels: one window per image at 7 K steps
+    ('VALID', [32], 64, 37, 35, 3, 0, 0),               # 32 ci x 64 co
+    ('VALID', [96], 32, 19, 23, 2, 0, 0),               # 32-channel layouts on unpadded / ragged channel counts
+    ('SAME', [32, 32], 64, 33, 17, 2, 0, 3),
+    ('VALID', [64], 32, 41, 23, 2, 0, 0),               # 64 ci x 32 co
+    ('VALID', [32], 32, 41, 23, 2, 0, 4),               # 32 x 32
+    ('VALID', [48, 16], 40, 21, 19, 2, 0, 0),           # unpadded channel counts
+    ('VALID', [64], 64, 37, 35, 3, 0, 0),               # automatic choice
+    ('VALID', [512], 512, 10, 10, 4, 0, 0),             # automatic choice on a bottleneck layer
+])
+def test_wgrad_sweep(case):
+    """The wave-specialised bf16 3x3 filter gradient (csrc/wgrad_sweep.hip) against the oracle: every tap grouping, both window
+    classes, whole-image / multi-image / rectangular windows, edge windows, K splits with slab reduction, all four channel layouts."""
+    padding, segs, cout, H, W, B, wcfg, ksplit = case
+    k = 3
+    dtype = L.SEG_BF16
+    rng = np.random.default_rng(sum(segs) * 7 + cout * 3 + H + W + wcfg + ksplit)
+    layer = E.Layer('c', 'conv', k, segs, cout, padding, True)
+    p = {'c': _rand_params(layer, rng, dtype)}
+    store = U.make_store([layer], dtype, p)
+    net = E.Net(store, B, dtype, U.dev())
+    srcs, xs = [], []
+    for i, c in enumerate(segs):
+        a = net.act(H + 2, W + 3, c)
+        full = U.round_dtype(rng.standard_normal((B, a.H, a.W, c)), dtype)
+        U.fill_act(a, full)
+        srcs.append((a, 1, 2 - i)); xs.append(full[:, 1:1 + H, 2 - i:2 - i + W, :])
+    x = np.concatenate(xs, -1)
+    Ho, Wo = H + 2 * layer.pad - k + 1, W + 2 * layer.pad - k + 1
+    dzv = U.round_dtype(rng.standard_normal((B, Ho, Wo, cout)) * 0.5, dtype)
+    dz = net.act(Ho, Wo, cout); U.fill_act(dz, dzv)
+    store.g.fill_(float('nan'))
+    bplan = E.Plan('b')
+    net.conv_bwd(bplan, layer, srcs, H, W, dz, [None] * len(segs), wcfg=wcfg, ksplit=ksplit)
+    net.flush_reduce(bplan)
+    name = bplan.kernel_name(0)
+    assert name.startswith('wgrad_sweep_kernel<'), name
+    if wcfg >= 200:
+        nu_nv = {1: ',3,3,', 3: ',1,3,', 9: ',1,1,'}[(wcfg - 200) // 10]
+        assert nu_nv in name and name.endswith(',4,192>' if wcfg % 10 == 0 else ',8,352>'), name
+    bplan.run(U.stream()); U.sync()
+    dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (k, k), padding, 1)
+    g = store.get_grads()['c']
+    assert np.isfinite(g['weights']).all() and np.isfinite(g['biases']).all(), name
+    assert U.rel_err(g['weights'], dw_ref) < 1e-2, 'wgrad ' + name
+    assert U.rel_err(g['biases'], db_ref) < 1e-2, 'bias grad ' + name
+    # same bits on a second run (fixed summation order), also from a poisoned workspace
+    g1 = store.g.clone(); store.g.fill_(float('nan')); bplan.run(U.stream()); U.sync()
+    assert torch.equal(g1, store.g), name
+
+
 @pytest.mark.parametrize('cin,cout,H,W,padding', [(64, 64, 23, 37, 'VALID'), (32, 32, 34, 34, 'SAME'), (128, 96, 19, 50, 'VALID')])
 def test_conv_with_fused_maxpool(cin, cout, H, W, padding):
     """seg_conv_desc.pool: same activation bits as the plain launch, pooled map == 2x2 max-pool of those bits."""
