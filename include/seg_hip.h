@@ -75,6 +75,9 @@ typedef struct seg_conv_desc {
                             * released, so another stream can wait for it with hipStreamWaitValue32(signal >= value) -- a fork that
                             * puts no packet on the producing stream (an event record costs it 4-7 us; tools/micro/sigwait.hip) */
   uint32_t signal_value;
+  int32_t* sched;          /* nullable: two zero-initialised int32 words of device memory owned by this launch site (not shared with a
+                            * launch that may run concurrently).  The persistent bf16 3x3 kernel hands its tiles out through them (an
+                            * atomic ticket) and leaves them zero again when it ends; without them tiles are split statically. */
 } seg_conv_desc;
 
 /* slim.convolution2d / conv2d_transpose fwd, Conv2DBackpropInput: models/unet.py:111-166,

@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
                 ('dst', View), ('up2', C.c_int32), ('up_cout', C.c_int32), ('mask', View), ('relu', C.c_int32),
                 ('out_f32', C.c_int32), ('dtype', C.c_int32), ('cfg', C.c_int32), ('accum', C.c_int32),
                 ('n_split', C.c_int32), ('dst1', View), ('mask1', View), ('pool', View), ('pool_h', C.c_int32), ('pool_w', C.c_int32),
-                ('signal', C.c_void_p), ('signal_value', C.c_uint32)]
+                ('signal', C.c_void_p), ('signal_value', C.c_uint32), ('sched', C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -178,9 +178,11 @@ def hip_runtime():
         h.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]; h.hipEventRecord.restype = C.c_int
         h.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]; h.hipStreamWaitEvent.restype = C.c_int
         h.hipStreamWaitValue32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint, C.c_uint32]; h.hipStreamWaitValue32.restype = C.c_int
+        h.hipDeviceGetAttribute.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int]; h.hipDeviceGetAttribute.restype = C.c_int
         _hip = h
     return _hip
 
 
 HIP_EVENT_DISABLE_TIMING = 0x2
+HIP_DEVICE_ATTRIBUTE_CAN_USE_STREAM_WAIT_VALUE = 10013     # hipDeviceAttributeCanUseStreamWaitValue (hip_runtime_api.h, AMD-specific block)
 HIP_EVENT_RELEASE_TO_DEVICE = 0x40000000

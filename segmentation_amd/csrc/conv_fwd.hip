@@ -17,6 +17,8 @@
 #include "common.h"
 #include <stdlib.h>
 
+int seg_conv_sweep(const seg_conv_desc& d, char* name_out, int name_cap, hipStream_t st, int* rc);   // conv_sweep.hip
+
 namespace {
 
 struct ConvK {          // kernel-side copy of the descriptor (trivially copyable)
@@ -780,6 +782,11 @@ extern "C" int seg_conv2d(const seg_conv_desc* dp, void* stream) {
     if (d.mask.ptr && (d.mask.oy + sc * d.Ho > d.mask.H || d.mask.ox + sc * d.Wo > d.mask.W || d.mask.coff + nch > d.mask.cs)) {
       seg_set_error("conv: mask window exceeds its buffer"); return SEG_ERR_ARG;
     }
+  }
+  {
+    // bf16 3x3 / stride 1 without the fused pool: the wave-specialised kernel (conv_sweep.hip) unless a tile of this file is forced
+    int rc = SEG_OK;
+    if (seg_conv_sweep(d, g_name_out, g_name_cap, reinterpret_cast<hipStream_t>(stream), &rc)) return rc;
   }
   ConvK P;
   P.d = d;

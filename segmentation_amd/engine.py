@@ -196,18 +196,29 @@ def _fork(src, dst):
 # queue.  One flag per main stream (the numbers must reach it in launch order); SEG_FORK_SIGNAL=0 falls back to events.
 _SIGNALS = {}
 def _signals_allowed():
-    """Signal forks need the waiting kernel and the kernel it waits for to be free to run at the same time.  A profiler that
-    runs ONE kernel at a time (rocprofv3 --pmc: counter collection serialises dispatches across queues; thread trace and PC
-    sampling likewise; any unknown HSA tool) can pick the waiter first and then never dispatch its signaller: fall back to
-    events there.  Kernel tracing alone (ROCPROF_KERNEL_TRACE) leaves the queues concurrent."""
+    """Signal forks need the waiting kernel and the kernel it waits for to be free to run at the same time, and the wait has no
+    time-out: a tool or runtime mode that dispatches one kernel at a time across queues (rocprofv3 --pmc serialises dispatches,
+    thread trace and PC sampling likewise) can pick the waiter first and never dispatch its signaller -- an unrecoverable hang.
+    So the default is conservative: signals only when NO profiler / HSA tool is in sight (any ROCPROF_* / ROCP_* / HSA_TOOLS_*
+    variable, rocprof or roctracer libraries in LD_PRELOAD), no serialising debug mode is set, and the device reports
+    hipDeviceAttributeCanUseStreamWaitValue (checked in _signal_state).  SEG_FORK_SIGNAL=0 forces events, =1 forces signals
+    (kernel tracing alone leaves the queues concurrent: tools/refresh_lines.sh sets it for rocprofv3 --kernel-trace)."""
     e = os.environ
-    if e.get('SEG_FORK_SIGNAL', '1') == '0':
+    v = e.get('SEG_FORK_SIGNAL')
+    if v == '0':
         return False
-    if e.get('HSA_TOOLS_LIB') or e.get('AMD_SERIALIZE_KERNEL', '0') not in ('', '0'):
+    if v == '1':
+        return True
+    if e.get('AMD_SERIALIZE_KERNEL', '0') not in ('', '0') or e.get('HIP_LAUNCH_BLOCKING', '0') not in ('', '0') or e.get('AMD_LOG_LEVEL', '0') not in ('', '0'):
         return False
-    for k, v in e.items():
-        if k.startswith('ROCPROF_') and v not in ('', '0') and any(t in k for t in ('COUNTER', 'PMC', 'THREAD_TRACE', 'ATT', 'PC_SAMPLING', 'SERIALIZ')):
+    for k, val in e.items():
+        if val in ('', '0'):
+            continue
+        if k.startswith(('ROCPROF', 'ROCP_', 'HSA_TOOLS', 'ROCTRACER', 'ROCPROFILER')):
             return False
+    pre = e.get('LD_PRELOAD', '')
+    if any(t in pre for t in ('rocprof', 'roctracer', 'rocprofiler', 'omnitrace', 'rocsys')):
+        return False
     return True
 
 
@@ -218,7 +229,16 @@ def _signal_state(main):
     key = (main.device.index, main.cuda_stream)
     st = _SIGNALS.get(key)
     if st is None:
-        st = _SIGNALS[key] = {'flag': torch.zeros(16, dtype=torch.int32, device=main.device), 'n': 0, 'hip': L.hip_runtime()}
+        hip = L.hip_runtime()
+        st = _SIGNALS[key] = {'flag': torch.zeros(16, dtype=torch.int32, device=main.device), 'n': 0, 'hip': hip}
+        # hipDeviceAttributeCanUseStreamWaitValue: a device / driver without stream memory operations gets event forks
+        can = C.c_int(0)
+        try:
+            rc = hip.hipDeviceGetAttribute(C.byref(can), L.HIP_DEVICE_ATTRIBUTE_CAN_USE_STREAM_WAIT_VALUE, main.device.index or 0)
+        except Exception:                              # noqa
+            rc = 1
+        if rc != 0 or can.value == 0:
+            _SIGNALS['off'] = True
         torch.cuda.synchronize(main.device)
     return st
 
@@ -528,11 +548,21 @@ class Net(object):
         self._wg_rr = 0
         self.side_enabled = True
         self.pool_fused = False
+        # tile-ticket words of the persistent convolution launches (seg_conv_desc.sched): two zeroed int32 per launch site
+        self._sched = torch.zeros(2 * 1024, dtype=torch.int32, device=device)
+        self._sched_n = 0
 
     @property
     def es(self):
         """bytes per activation element in HBM"""
         return 4 if self.dtype == L.SEG_F32 else 2
+
+    def sched_slot(self):
+        """device address of a fresh pair of ticket words (None once the pool is used up: the kernel then splits statically)"""
+        if os.environ.get('SEG_CONV_SCHED', '1') == '0' or 2 * self._sched_n + 2 > self._sched.numel():
+            return None
+        self._sched_n += 1
+        return self._sched.data_ptr() + 8 * (self._sched_n - 1)
 
     def act(self, H, W, C, f32=False, name=''):
         a = Act(self.B, H, W, C, self.dtype, self.device, f32=f32, name=name)
@@ -587,6 +617,7 @@ class Net(object):
         d.relu = 1 if layer.relu else 0
         d.out_f32 = 1 if out_f32 else 0
         d.dtype = self.dtype; d.cfg = cfg
+        d.sched = self.sched_slot()
         name = layer.name
         if pool is not None and self.dtype == L.SEG_BF16 and dst_off == (0, 0) and os.environ.get('SEG_FUSE_POOL', '1') != '0':
             d.pool = pool.view(); d.pool_h, d.pool_w = pool.H, pool.W
@@ -803,6 +834,7 @@ class Net(object):
             d.mask = mask0.view(moff0[0], moff0[1]) if mask0 is not None else L.null_view()
             d.mask1 = mask1.view(moff1[0], moff1[1]) if mask1 is not None else L.null_view()
             d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
+            d.sched = self.sched_slot()
             plan.keep.append(d)
             fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
             nmask = sum(layer.cin_segs[i] for i, m_ in enumerate((mask0, mask1)) if m_ is not None)
@@ -825,6 +857,7 @@ class Net(object):
                 d.dst = dst.view(doff[0], doff[1]); d.up2 = 0; d.up_cout = 0
                 d.mask = mask.view(moff[0], moff[1]) if mask is not None else L.null_view()
                 d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
+                d.sched = self.sched_slot()
                 plan.keep.append(d)
                 fl = 2 * self.B * Ho * Wo * k * k * layer.cin_segs[i] * layer.cout
                 by = (self.B * (Ho * Wo * layer.cout + Hi * Wi * layer.cin_segs[i] * (1 + (1 if mask is not None else 0) + (1 if d.accum else 0))) * self.es

@@ -93,15 +93,20 @@ def test_unet_plan_geometry():
     assert sum(l.wsize + l.cout for l in ls) == 7760196
 
 
-def test_signal_forks_are_off_under_serialising_profilers(monkeypatch):
-    """hipStreamWaitValue32 waiters deadlock when a tool dispatches one kernel at a time (rocprofv3 --pmc): events there"""
+def test_signal_forks_are_off_under_any_tool(monkeypatch):
+    """hipStreamWaitValue32 waiters have no time-out and deadlock when a tool dispatches one kernel at a time (rocprofv3 --pmc):
+    the default is conservative -- events whenever ANY profiler / HSA tool / serialising mode is in sight; only an
+    explicit SEG_FORK_SIGNAL=1 (kernel tracing, which leaves the queues concurrent) overrides."""
     from segmentation_amd import engine as E
     for k in list(os.environ):
-        if k.startswith('ROCPROF_') or k in ('HSA_TOOLS_LIB', 'AMD_SERIALIZE_KERNEL', 'SEG_FORK_SIGNAL'):
+        if k.startswith(('ROCPROF', 'ROCP_', 'HSA_TOOLS', 'ROCTRACER')) or k in ('AMD_SERIALIZE_KERNEL', 'HIP_LAUNCH_BLOCKING', 'AMD_LOG_LEVEL', 'SEG_FORK_SIGNAL', 'LD_PRELOAD'):
             monkeypatch.delenv(k, raising=False)
     assert E._signals_allowed()
-    monkeypatch.setenv('ROCPROF_KERNEL_TRACE', '1'); assert E._signals_allowed()
-    monkeypatch.setenv('ROCPROF_COUNTER_COLLECTION', '1'); assert not E._signals_allowed()
-    monkeypatch.delenv('ROCPROF_COUNTER_COLLECTION'); monkeypatch.setenv('ROCPROF_COUNTERS', 'pmc: FETCH_SIZE'); assert not E._signals_allowed()
-    monkeypatch.delenv('ROCPROF_COUNTERS'); monkeypatch.setenv('HSA_TOOLS_LIB', 'librocprofiler64.so'); assert not E._signals_allowed()
-    monkeypatch.delenv('HSA_TOOLS_LIB'); monkeypatch.setenv('SEG_FORK_SIGNAL', '0'); assert not E._signals_allowed()
+    for var, val in (('ROCPROF_KERNEL_TRACE', '1'), ('ROCPROF_COUNTER_COLLECTION', '1'), ('ROCPROF_COUNTERS', 'pmc: FETCH_SIZE'),
+                     ('ROCP_TOOL_LIBRARIES', 'librocprofiler-sdk-tool.so'), ('HSA_TOOLS_LIB', 'librocprofiler64.so'),
+                     ('LD_PRELOAD', '/opt/rocm/lib/librocprofiler-sdk-tool.so'), ('AMD_SERIALIZE_KERNEL', '3'), ('HIP_LAUNCH_BLOCKING', '1')):
+        monkeypatch.setenv(var, val)
+        assert not E._signals_allowed(), var
+        monkeypatch.setenv('SEG_FORK_SIGNAL', '1'); assert E._signals_allowed()
+        monkeypatch.delenv('SEG_FORK_SIGNAL'); monkeypatch.delenv(var)
+    monkeypatch.setenv('SEG_FORK_SIGNAL', '0'); assert not E._signals_allowed()

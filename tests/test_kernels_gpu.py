@@ -41,11 +41,23 @@ def _rand_params(layer, rng, dtype):
     (3, 'VALID', [16], 24, 11, 11, 1, True, 0),          # unpadded channel counts (n_kernels=16 style)
     (1, 'SAME', [96], 4, 7, 9, 2, False, 0),
     (1, 'SAME', [64], 160, 16, 16, 1, True, 0),
+    # the wave-specialised kernel (csrc/conv_sweep.hip; bf16): cfg 100 + fragments per wave (2 / 4 / 6 = 128 / 256 / 384-pixel windows)
+    (3, 'VALID', [64, 32], 64, 35, 37, 2, True, 106),
+    (3, 'VALID', [64, 32], 64, 35, 37, 2, True, 104),
+    (3, 'VALID', [64, 32], 64, 35, 37, 2, True, 102),
+    (3, 'SAME', [64], 96, 19, 33, 3, True, 106),         # zero padding, 32-channel blocks (96 outputs)
+    (3, 'SAME', [128], 64, 9, 11, 2, False, 104),
+    (3, 'VALID', [32], 128, 26, 26, 2, True, 106),       # 24 x 24 output maps: 12 x 24 windows
+    (3, 'VALID', [16], 24, 11, 11, 1, True, 102),        # unpadded channel counts
+    (3, 'VALID', [256], 256, 12, 12, 3, True, 0),        # automatic tile class on a deep layer
+    (3, 'VALID', [32], 64, 150, 131, 4, True, 102),      # more tiles than compute units: the persistent walk + tile tickets
+    (3, 'SAME', [32, 32], 64, 97, 140, 3, True, 104),
+    (3, 'VALID', [64], 128, 120, 123, 2, True, 106),
 ])
 def test_conv_fwd_bwd(dtype, case):
     k, padding, segs, cout, H, W, B, relu, cfg = case
     if cfg > 10 and dtype != L.SEG_BF16:
-        pytest.skip('direct-to-LDS variants are bf16 only')
+        pytest.skip('direct-to-LDS / wave-specialised variants are bf16 only')
     rng = np.random.default_rng(k * 7919 + sum(segs) * 31 + cout * 17 + H * 5 + W + cfg)
     layer = E.Layer('c', 'conv', k, segs, cout, padding, relu)
     p = {'c': _rand_params(layer, rng, dtype)}
@@ -67,6 +79,8 @@ def test_conv_fwd_bwd(dtype, case):
     out = net.act(Ho, Wo, cout)
     plan = E.Plan('t')
     net.conv_fwd(plan, layer, srcs, H, W, out, cfg=cfg)
+    if cfg >= 100:
+        assert plan.kernel_name(0).startswith('conv_sweep_kernel<%d,' % (cfg - 100)), plan.kernel_name(0)
     plan.run(U.stream()); U.sync()
     ref = ops.conv2d(x, p['c']['weights'], p['c']['biases'], padding, 1, relu)
     got = U.read_act(out)
@@ -91,7 +105,7 @@ def test_conv_fwd_bwd(dtype, case):
         dsrc_acts.append(da)
     store.g.zero_()
     bplan = E.Plan('b')
-    net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs, cfg=0)
+    net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs, cfg=cfg if cfg >= 100 else 0)
     net.flush_reduce(bplan)
     bplan.run(U.stream()); U.sync()
     dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (k, k), padding, 1)

@@ -3,7 +3,7 @@
 pat=${1:-.}
 O=$GRAFT_REPO_ROOT/gpurun_out/kstats; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-roofline > $O/bench.json 2> $O/err
+SEG_FORK_SIGNAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-roofline > $O/bench.json 2> $O/err
 python3 - "$O" "$pat" <<'PY'
 import csv, glob, sys, re
 f = glob.glob(sys.argv[1] + '/*/*kernel_stats.csv')[0]
