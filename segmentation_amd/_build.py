@@ -21,8 +21,19 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def lint_ok():
+    import json
+    try:
+        rec = json.load(open(LINT))
+        return rec.get('sources') == source_digest() and not rec.get('over_budget') and rec.get('instances', 0) >= 30
+    except Exception:                                  # noqa
+        return False
+
+
 def build(force=False, verbose=True):
     if not force and not _stale():
+        if not lint_ok():
+            _lint_wgrad_registers()                    # (a library built before the lint existed, or a lost verdict file)
         return LIB
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
@@ -51,6 +62,7 @@ def _build_locked(objdir, verbose):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(cc, SOURCES))
+    _lint_wgrad_registers()              # (raises: an instance over its register budget must never ship)
     tmp = LIB + '.tmp.%d' % os.getpid()
     r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs, capture_output=True, text=True)
     if r.returncode != 0:
@@ -59,6 +71,36 @@ def _build_locked(objdir, verbose):
     if verbose:
         print('built', LIB, file=sys.stderr)
     return LIB
+
+
+LINT = os.path.join(HERE, 'wgrad_regs.json')
+
+
+def source_digest():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ('conv_wgrad.hip', 'common.h', 'wgrad_common.h'):
+        h.update(open(os.path.join(CSRC, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def _lint_wgrad_registers(limit=250):
+    """conv_wgrad.hip (f32, 1x1, 2x2/s2 and the first layer's filter gradients) waits by hand for inline-asm loads issued a tile
+    earlier: sound only while no instance makes the register allocator park a value (AGPR copy, scratch).  The ISA of every
+    instance is checked with the compiler that builds the library, the verdict is written next to the .so (it travels with it:
+    tests/test_extras_gpu.py asserts on the GPU box that the library it loaded was linted from these sources) and a violation
+    fails the build.  (The bf16 3x3 filter gradients run in wgrad_sweep.hip, which has no such loads.)"""
+    import json
+    sys.path.insert(0, os.path.join(HERE, '..', 'tools'))
+    import check_wgrad_regs as chk
+    inst = chk.instances(os.environ.get('SEG_EXTRA_FLAGS', '').split())
+    bad = [i for i in inst if i['arch_vgprs'] >= limit or i['spills'] or i['scratch_bytes']]
+    rec = {'sources': source_digest(), 'limit': limit, 'instances': len(inst), 'over_budget': bad,
+           'max_arch_vgprs': max(i['arch_vgprs'] for i in inst) if inst else 0}
+    with open(LINT, 'w') as fh:
+        json.dump(rec, fh, indent=1)
+    if bad or len(inst) < 30:
+        raise RuntimeError('conv_wgrad.hip: %d of %d instances over the register budget (hand-waited asm loads become unsound): %s' % (len(bad), len(inst), bad))
 
 
 if __name__ == '__main__':

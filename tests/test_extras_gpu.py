@@ -236,3 +236,19 @@ def test_example_adversarial_script_runs(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'Done' in r.stdout and 'l_bce_fake_one' in r.stdout and 'infer: (4, 128, 128, 2) (4, 128, 128, 1)' in r.stdout
     assert any(f.endswith('-4.npz') for f in os.listdir(tmp_path / 'examples' / 'fcn_adversarial' / 'snapshots'))
+
+
+@pytest.mark.gpu
+def test_loaded_library_was_linted_for_the_wgrad_register_budget():
+    """The register-staged filter-gradient kernels (f32, 1x1, 2x2/s2, first layer) wait by hand for asm loads: sound only while no
+    instance is over its register budget (tools/check_wgrad_regs.py).  _build runs that lint with the compiler that builds the
+    library and leaves the verdict next to the .so; here, on the GPU box, the library that is actually loaded must carry a clean
+    verdict for exactly the sources in the tree (the guard travels with the build)."""
+    import json
+    from segmentation_amd import _build, _lib
+    assert os.path.exists(_lib.LIB_PATH)
+    assert os.path.exists(_build.LINT), 'no register-budget verdict next to the library'
+    rec = json.load(open(_build.LINT))
+    assert rec['sources'] == _build.source_digest(), 'the verdict belongs to other sources than the ones in the tree'
+    assert rec['instances'] >= 30 and not rec['over_budget'], rec
+    assert rec['max_arch_vgprs'] < rec['limit']
