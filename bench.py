@@ -232,8 +232,12 @@ def main():
         spawn_ranks(args)                          # does not return
 
     # stdout carries exactly ONE line, the JSON record: whatever the library prints while it builds the model (the reference's
-    # own 'Training from scratch...' notice among it) goes to stderr
-    json_out = sys.stdout
+    # own 'Training from scratch...' notice among it) goes to stderr -- at the file-descriptor level too, because RCCL prints its
+    # version banner from C code straight to descriptor 1
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    json_out = os.fdopen(json_fd, 'w')
     sys.stdout = sys.stderr
 
     import numpy as np

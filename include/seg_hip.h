@@ -404,6 +404,12 @@ int seg_bn_rows_bwd(const seg_view* a, const seg_view* dy, const seg_view* dz, c
                     int32_t F, int32_t relu_mask, int32_t dtype, void* stream);
 int seg_bce2(const seg_view* logits, int32_t B, int32_t label, float grad_scale, float* loss_out, const seg_view* dlogits, int32_t dtype, void* stream);
 
+/* Diagnostic (tests/test_precision_gpu.py: which rounding of the bf16 mode moves the gradients): rounds a float32 window / a flat
+ * float32 array to the bf16 value grid, result still float32 (dst may be src).  With these the f32-mode plans can be run with
+ * bf16-rounded activations, gradients or filter-gradient operands one at a time. */
+int seg_round_bf16(const seg_view* src, const seg_view* dst, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+int seg_round_bf16_flat(const float* src, float* dst, int64_t n, void* stream);
+
 /* float32 NHWC -> dtype NHWC with channel padding (feeding placeholder inputs). */
 int seg_cast_pad(const float* x, int64_t npix, int32_t c, const seg_view* dst_dense, int32_t dtype, void* stream);
 

@@ -96,6 +96,8 @@ SIGNATURES = {
     'seg_relu_grad': [PV, PV, PV, i32, i32, i32, i32, i32, vp],
     'seg_dropout': [PV, PV, i32, i32, i32, i32, f32, u64, u64, i32, vp],
     'seg_cast_pad': [vp, i64, i32, PV, i32, vp],
+    'seg_round_bf16': [PV, PV, i32, i32, i32, i32, vp],
+    'seg_round_bf16_flat': [vp, vp, i64, vp],
     'seg_dconv_fwd': [C.POINTER(DconvDesc), vp],
     'seg_dconv_bwd_data': [C.POINTER(DconvDesc), vp],
     'seg_dconv_wgrad': [C.POINTER(DconvDesc), vp, vp, i32, vp, C.c_int64, vp],

@@ -101,6 +101,12 @@ class BaseModel(object):
         self._graphs = {}
         # side streams: wgrad_streams for the filter gradients + one auxiliary (weight re-pack)
         self._side = [torch.cuda.Stream(self.device) for _ in range(wgrad_streams + 1)] if wgrad_streams > 0 else None
+        if self._side is not None and self.pg.enabled and os.environ.get('SEG_DP_SHARE_AUX', '0') == '1':
+            # (experiment, off: the auxiliary work on the first filter-gradient stream, one stream fewer beside RCCL's -- 1.32 ms
+            # against 1.07 with its own stream at world 1; what did matter was NOT creating a communication stream of our own: the
+            # collectives are issued from a side stream, and asking for more hardware queues, GPU_MAX_HW_QUEUES = 6 / 8, is far
+            # worse: 1.46 / 2.6 ms -- profiles/r03_dp_overhead.txt)
+            self._side[-1] = self._side[0]
         self._packed_dirty = False
         self._infer_cache = {}
         self.sess = sess
@@ -292,7 +298,8 @@ class BaseModel(object):
         """One optimisation step (intended body of models/basemodel.py:477-489)."""
         if self.mode == 'INFERENCE':
             raise Exception('train_step() with INFERENCE mode invalid')
-        if not self.use_graph and self._side is not None and not self.pg.enabled and os.environ.get('SEG_HIPRIO', '1') != '0':
+        if (not self.use_graph and self._side is not None and os.environ.get('SEG_HIPRIO', '1') != '0' and
+                (not self.pg.enabled or os.environ.get('SEG_DP_HIPRIO', '0') == '1')):
             # Eager launches: the critical path (forward, dgrads, pools, Adam) runs on a HIGH-priority HIP stream, the filter
             # gradients stay on normal-priority side streams and fill what it leaves (+2 % measured; a captured graph
             # ignores stream priorities).  The high-priority stream BECOMES the thread's current stream (ordered after
@@ -329,6 +336,8 @@ class BaseModel(object):
                 m[self._bound[1]] = new[1]
             self.fwd_plan.rebind(m)
             self.step_plan.rebind(m)
+            if getattr(self, 'dp_step_plan', None) is not None:
+                self.dp_step_plan.rebind(m)
             self._bound = new
         return new
 
@@ -359,14 +368,51 @@ class BaseModel(object):
         the next segment's dgrad/wgrad kernels run; Adam runs after the last bucket lands.
         probe (a list): instrumented step -- an event after the last backward segment and one behind the wait for each
         bucket are appended, so that the EXPOSED part of every all-reduce can be read off (dp_exposure_report)."""
-        def head():
-            self.fwd_plan.run(self._stream(), self._side, flavor=self._flavor())
-            self.bwd_segments[0][0].run(self._stream(), self._side, flavor=self._flavor())
-        self._replay(('dp0', key), head)
-        self.pg.all_reduce_bucket(self.store.g, *self.bwd_segments[0][1])
-        for i, (plan, (lo, hi)) in enumerate(self.bwd_segments[1:], 1):
-            self._replay('dp%d' % i, lambda plan=plan: plan.run(self._stream(), self._side, flavor=self._flavor()))
-            self.pg.all_reduce_bucket(self.store.g, lo, hi)
+        nseg = len(self.bwd_segments)
+        eager = not self.use_graph and self._side is not None and os.environ.get('SEG_DP_JOIN', 'comm') == 'comm'
+        if eager:
+            # Eager: the SAME plan walk as the single-GPU step (signal forks and all); at a bucket marker the bucket's all-reduce is
+            # issued from a COMMUNICATION stream that waits for the side streams -- RCCL's stream then waits for exactly the filter
+            # gradients of that bucket and the main stream never waits for a side stream before the end of backward (r02: every
+            # segment was a plan run of its own whose end drained the side streams into the main stream, 17-30 us each).
+            evs = None if probe is None else [None]
+
+            def on_marker(md, side_streams):
+                if md['marker'] == 'bucket':
+                    # issued from the first side stream once it has also seen the other one (RCCL's stream waits for the stream that
+                    # is current at the call): no stream of our own for the collectives
+                    st0 = side_streams[0] if side_streams else torch.cuda.current_stream(self.device)
+                    for st in side_streams[1:]:
+                        ev = torch.cuda.Event(); ev.record(st); st0.wait_event(ev)
+                    with torch.cuda.stream(st0):
+                        self.pg.all_reduce_bucket(self.store.g, md['lo'], md['hi'])
+                    return
+                # 'wait': every bucket must have landed (the main stream has already waited for the side streams)
+                if evs is not None:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record(); evs[0] = e0
+                    for w in self.pg.pending:
+                        w.wait()
+                        e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
+                    self.pg.pending = []
+                else:
+                    self.pg.wait_all()
+
+            self.dp_step_plan.run(self._stream(), self._side, flavor=self._flavor(), on_marker=on_marker)
+            self._packed_dirty = True
+            self._loss_is_sum = True
+            if probe is not None:
+                probe.append(evs)
+            return
+        else:
+            def head():
+                self.fwd_plan.run(self._stream(), self._side, flavor=self._flavor())
+                self.bwd_segments[0][0].run(self._stream(), self._side, flavor=self._flavor())
+            self._replay(('dp0', key), head)
+            self.pg.all_reduce_bucket(self.store.g, self.bwd_segments[0][1][0], self.bwd_segments[0][1][1] + (1 if nseg == 1 else 0))
+            for i, (plan, (lo, hi)) in enumerate(self.bwd_segments[1:], 1):
+                self._replay('dp%d' % i, lambda plan=plan: plan.run(self._stream(), self._side, flavor=self._flavor()))
+                self.pg.all_reduce_bucket(self.store.g, lo, hi + (1 if i == nseg - 1 else 0))
+        self._loss_is_sum = True
         if probe is None:
             self.pg.wait_all()
         else:
@@ -401,8 +447,11 @@ class BaseModel(object):
                 'exposed_total_us': round(sum(us), 1), 'world': self.pg.world}
 
     def last_loss(self):
-        """Mean x-entropy of the most recent train_step (synchronises)."""
-        return float(self.loss_buf.item())
+        """Mean x-entropy of the most recent train_step (synchronises).  Data parallel: the mean over the GLOBAL batch (equal
+        local batches: the mean of the ranks' means, models/basemodel.py:360 reduce_mean) -- the accumulator rides in the last
+        gradient bucket's all-reduce, so no collective happens here and any single rank may ask."""
+        v = float(self.loss_buf.item())
+        return v / self.pg.world if getattr(self, '_loss_is_sum', False) else v
 
     def _attach_adversary(self, logits, oh, ow, LH, LW, dlogits):
         """adversarial_training: builds the adversary and its plan (forward on one_hot(labels) and softmax(logits), its own
@@ -439,7 +488,7 @@ class BaseModel(object):
             print('test() with INFERENCE mode invalid')
             return
         ds = self.test_dataset if self.test_dataset is not None else self.dataset
-        train_loss = self.loss_buf.clone()            # last_loss() keeps reporting the most recent TRAIN step
+        train_loss = self.loss_buf.clone()            # last_loss() keeps reporting the most recent TRAIN step (sum over ranks under DP)
         self._bind_batch(ds)
         self.loss_buf.zero_()
         self.fwd_plan.run(self._stream(), skip=('step_begin',))     # a test pass does not advance global_step
@@ -568,6 +617,21 @@ class BaseModel(object):
         if self.pg.enabled:
             self.net.join_all(self.step_plan)           # data-parallel builds do not pin the first layer's filter gradient to the im2col's stream
         self.step_plan.extend(self.bwd_upd_plan)
+        # the data-parallel step as ONE plan as well: the same launches in the same order as the single-GPU step, with a marker
+        # behind every backward segment (its gradient bucket is complete: the all-reduce is issued from a communication stream that
+        # waits for the side streams; the main stream does not) and one in front of Adam (every bucket has landed)
+        self.dp_step_plan = E.Plan('dp_step')
+        self.dp_step_plan.extend(self.fwd_plan)
+        self.net.join_all(self.dp_step_plan)
+        nseg = len(self.bwd_segments)
+        for i, (plan, (lo_, hi_)) in enumerate(self.bwd_segments):
+            self.dp_step_plan.extend(plan)
+            self.net.dp_marker(self.dp_step_plan, 'bucket', lo=lo_, hi=hi_ + (1 if i == nseg - 1 else 0))    # (+ the loss word behind the arena)
+        self.net.join_all(self.dp_step_plan)
+        self.net.dp_marker(self.dp_step_plan, 'wait')
+        self.net.adam(self.dp_step_plan, self.learning_rate, grad_scale=1.0 / self.pg.world)
+        if self.adversary is not None:
+            self.adversary.emit_update(self.dp_step_plan)
 
     def set_weights(self, params):
         """Load {scope: {'weights','biases'}} in TF layouts (tests / interchange)."""

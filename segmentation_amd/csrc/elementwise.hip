@@ -160,6 +160,22 @@ __global__ void relu_grad_kernel(seg_view dy, seg_view yact, seg_view dz, int B,
   }
 }
 
+// float32 window -> the bf16 value grid, still float32 (diagnostic: seg_round_bf16)
+__global__ void round_bf16_kernel(seg_view src, seg_view dst, int B, int H, int W, int C8) {
+  const int64_t total = (int64_t)B * H * W * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const Idx4 q_ = split4(i, C8, W, H);
+    Vec8<float> a, o;
+    a.load(reinterpret_cast<const float*>(src.ptr) + view_off(src, q_.b, q_.y, q_.x) + q_.c8 * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.set(e, (float)(bf16_t)a.get(e));
+    o.store(reinterpret_cast<float*>(dst.ptr) + view_off(dst, q_.b, q_.y, q_.x) + q_.c8 * 8);
+  }
+}
+__global__ void round_bf16_flat_kernel(const float* src, float* dst, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (float)(bf16_t)src[i];
+}
+
 template <typename T>
 __global__ void cast_pad_kernel(const float* x, int64_t npix, int c, seg_view dst) {
   const int C8 = dst.cs / 8;
@@ -1015,6 +1031,18 @@ extern "C" int seg_relu_grad(const seg_view* dy, const seg_view* y_act, const se
            SEG_LAUNCH(relu_grad_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *dy, *y_act, *dz, B, H, W, C / 8),
            SEG_LAUNCH(relu_grad_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST(stream), *dy, *y_act, *dz, B, H, W, C / 8));
   return seg_check_launch("relu_grad");
+}
+
+extern "C" int seg_round_bf16(const seg_view* src, const seg_view* dst, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  if (!view_ok(src, H, W, C) || !view_ok(dst, H, W, C) || C % 8 || B < 1) { seg_set_error("round_bf16: bad views"); return SEG_ERR_ARG; }
+  const int64_t n = (int64_t)B * H * W * (C / 8);
+  SEG_LAUNCH(round_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), *src, *dst, B, H, W, C / 8);
+  return seg_check_launch("round_bf16");
+}
+extern "C" int seg_round_bf16_flat(const float* src, float* dst, int64_t n, void* stream) {
+  if (!src || !dst || n < 1) { seg_set_error("round_bf16_flat: bad arguments"); return SEG_ERR_ARG; }
+  SEG_LAUNCH(round_bf16_flat_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), src, dst, n);
+  return seg_check_launch("round_bf16_flat");
 }
 
 extern "C" int seg_cast_pad(const float* x, int64_t npix, int32_t c, const seg_view* dst, int32_t dtype, void* stream) {

@@ -135,6 +135,9 @@ class ThreadedImageMaskDataSet(object):
       hand-over    batches are assembled IN a ring of pre-allocated pinned host buffers (no allocation, no pin_memory() per
                    batch); get_batch() returns views of a ring slot that stay valid until the second-next get_batch()
 
+    The defaults capacity=5000 / min_holding=1250 are the reference's shuffle_batch numbers: the first batch waits for 1250 + batch
+    decodes, and the pool holds up to 5000 crops (kept as uint8: < 1 GB at 256 x 256 x 3; pass smaller numbers for a quick start).
+
     `ratio` is accepted and unused exactly as in the reference (its only use there, decode_jpeg(ratio=), is commented out:
     utils/datasets.py:160,164).  `threads` decode workers + one batch assembler; any exception in them (unreadable file, image
     smaller than the crop) is re-raised by get_batch() instead of hanging the training loop."""
@@ -198,7 +201,11 @@ class ThreadedImageMaskDataSet(object):
                 if h < c or w < c or mk.shape[:2] != (h, w):
                     raise ValueError('%s is %dx%d (mask %s): cannot take a %dx%d crop' % (self.image_names[i], h, w, mk.shape[:2], c, c))
                 y0, x0 = int(rng.integers(0, h - c + 1)), int(rng.integers(0, w - c + 1))
-                x = im[y0:y0 + c, x0:x0 + c, :3].astype(np.float32) / np.float32(255.0)
+                # the pool keeps 8-bit crops as they are (a 5000-sample pool of float32 256 x 256 x 3 crops is 3.9 GB of host memory, of
+                # uint8 crops under 1 GB); the /255 and the float cast happen when a batch is assembled into its ring slot -- same bits
+                x = np.ascontiguousarray(im[y0:y0 + c, x0:x0 + c, :3])
+                if x.dtype != np.uint8:
+                    x = x.astype(np.float32) / np.float32(255.0)
                 y = (mk[y0:y0 + c, x0:x0 + c].astype(np.float32) / np.float32(255.0)).astype(np.uint8)
                 while not self._stop.is_set():
                     try:
@@ -234,7 +241,10 @@ class ThreadedImageMaskDataSet(object):
                     j = int(rng.integers(0, len(pool)))
                     pool[j], pool[-1] = pool[-1], pool[j]
                     x, y = pool.pop()
-                    img[b] = torch.from_numpy(x)
+                    if x.dtype == np.uint8:
+                        torch.div(torch.from_numpy(x).to(torch.float32), 255.0, out=img[b])
+                    else:
+                        img[b] = torch.from_numpy(x)
                     msk[b, ..., 0] = torch.from_numpy(y)
                 self._ready.put(slot)
         except Exception as e:                      # noqa

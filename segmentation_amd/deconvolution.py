@@ -31,6 +31,7 @@ from .basemodel import BaseModel
 GRAPH = ['conv1_0', 'bn1', 'conv2_0', 'bn2', 'conv3_0', 'bn3', 'conv4_0', 'bn4', 'deconv1_0', 'bn5', 'deconv2_0', 'bn6',
          'deconv2_1', 'bn7', 'deconv3_0', 'bn8', 'conv_out']
 BWD_ORDER = list(reversed(GRAPH))
+TEST_SEED_INC = 64                                            # test() draws from its own dropout streams
 DROP_SITES = {'bn2': 1, 'bn4': 2, 'bn5': 3}                    # batch norm followed by a `bayesian` dropout -> seed increment
 
 
@@ -108,7 +109,11 @@ class DeconvModel(BaseModel):
         self.n_kernels = n_kernels
         if n_classes > 32:
             raise Exception('n_classes > 32 not supported')
-        self.keep_prob, self.drop_seed = 0.5, self.seed
+        # dropout streams: one generator stream per (seed, site); training draws at counter offset global_step << 40 with
+        # seed + site, test() with seed + 64 + site (its own streams: the masks of the last train step are not replayed), infer() at
+        # offsets (1 << 62) | call << 40 (disjoint from every training step); data-parallel ranks fold their rank into the seed
+        self.keep_prob = 0.5
+        self.drop_seed = self.seed + 4096 * self.pg.rank
         self._init_input()
         training = self.mode != 'INFERENCE'
         self.layers = deconv_layers(n_classes, n_kernels, input_channel)
@@ -162,7 +167,7 @@ class DeconvModel(BaseModel):
         return {n: (v[n + '/moving_mean'], v[n + '/moving_variance']) for v in [self._state_blob()] for n in self.bn}
 
     # ---- forward graph (training / test / inference plans share it) ----
-    def _emit_forward(self, net, plan, x_in, H, W, bn_training, update_moving, dropout_step):
+    def _emit_forward(self, net, plan, x_in, H, W, bn_training, update_moving, dropout_step, seed_inc=0):
         """dropout_step: True -> masks keyed by the device-side global step (train / test plans); False -> by a host offset
         (ctypes c_uint64 in self._infer_off: one fresh mask per infer() call)"""
         if H != W:
@@ -189,7 +194,7 @@ class DeconvModel(BaseModel):
             if self.bayesian and b in DROP_SITES:
                 Y[b + '/drop'] = net.act(a.H, a.W, a.C, name=b + '/drop')
                 if dropout_step:
-                    net.dropout_step(plan, Y[b], Y[b + '/drop'], self.keep_prob, self.drop_seed + DROP_SITES[b], 0)
+                    net.dropout_step(plan, Y[b], Y[b + '/drop'], self.keep_prob, self.drop_seed + seed_inc + DROP_SITES[b], 0)
                 else:
                     v, o = Y[b].view(), Y[b + '/drop'].view()
                     plan.keep += [v, o]
@@ -236,7 +241,7 @@ class DeconvModel(BaseModel):
         net.n_wgrad_streams = max(1, len(self._side) - 1) if self._side else 1
         Ly, nc = self.store.layers, self.n_classes
         fwd = self.fwd_plan = E.Plan('fwd')
-        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.loss_buf = self.store.loss_slot()          # (behind the gradient arena: reduced with the last bucket under data parallelism)
         net.step_begin(fwd, self.loss_buf)
         net.pack(fwd, aux=True)
         A, Y, P, sz = self._emit_forward(net, fwd, self.input_x, H, W, bn_training=True, update_moving=True, dropout_step=True)
@@ -248,7 +253,8 @@ class DeconvModel(BaseModel):
         # the test() graph: moving averages, no update; dropout (if bayesian) stays on, exactly as in the reference's test graph
         tnet = self.test_net = E.Net(self.store, B, self.dtype, self.device)
         self.test_plan = E.Plan('test')
-        TA, _, _, _ = self._emit_forward(tnet, self.test_plan, self.input_x, H, W, bn_training=False, update_moving=False, dropout_step=True)
+        TA, _, _, _ = self._emit_forward(tnet, self.test_plan, self.input_x, H, W, bn_training=False, update_moving=False, dropout_step=True,
+                                         seed_inc=TEST_SEED_INC)
         tdl = tnet.act(H, W, nc, name='dlogits_test')
         tnet.softmax_xent(self.test_plan, TA['logits'], self.input_y, H, W, (0, 0), H, W, nc, self.loss_buf, tdl)
 
@@ -344,11 +350,11 @@ class DeconvModel(BaseModel):
 
     def infer(self, imgs, dropout_offset=None):
         """[sigmoid, argmax] of ONE pass of the training graph; with `bayesian` every call draws fresh dropout masks (counter
-        offset = call number << 40, or `dropout_offset` when given: tests replay a known mask)."""
+        offset = (1 << 62) | call number << 40 -- disjoint from the training steps' -- or `dropout_offset` when given: tests replay a known mask)."""
         if not hasattr(self, '_infer_off'):
             import ctypes as C
             self._infer_off = C.c_uint64(0)
             self._infer_calls = 0
         self._infer_calls = getattr(self, '_infer_calls', 0) + 1
-        self._infer_off.value = (self._infer_calls << 40) if dropout_offset is None else int(dropout_offset)
+        self._infer_off.value = ((1 << 62) | (self._infer_calls << 40)) if dropout_offset is None else int(dropout_offset)
         return super(DeconvModel, self).infer(imgs)

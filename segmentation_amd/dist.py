@@ -12,22 +12,48 @@ import torch.distributed as dist
 
 
 class DataParallel(object):
-    def __init__(self, process_group=None, overlap=True):
+    def __init__(self, process_group=None, overlap=True, algo=None):
         self.enabled = dist.is_available() and dist.is_initialized()
         self.group = process_group
         self.world = dist.get_world_size(process_group) if self.enabled else 1
         self.rank = dist.get_rank(process_group) if self.enabled else 0
         self.overlap = overlap
         self.pending = []
+        # 'allreduce': one RCCL all-reduce per bucket (RCCL picks ring / tree and the protocol from the message size).
+        # 'rs_ag': the bucket as reduce-scatter + all-gather over equal 1/world slices -- the two-phase form SURVEY 8(e) asks for on
+        # xGMI's point-to-point links (every rank owns 1/world of the bucket, sends the other slices straight to their owners over
+        # all 7 links and gathers the reduced slices back: 2 x bucket / world bytes per link instead of 2 x 7/8 x bucket through one
+        # link of a ring).  Same sums in the same per-element order on every rank, so replicas stay identical.  SEG_DP_ALGO selects.
+        import os
+        self.algo = algo or os.environ.get('SEG_DP_ALGO', 'allreduce')
+        self._dry = os.environ.get('SEG_DP_DRY', '0') == '1'
+        if self.algo not in ('allreduce', 'rs_ag'):
+            raise ValueError("SEG_DP_ALGO must be 'allreduce' or 'rs_ag'")
 
     def all_reduce_bucket(self, flat, lo, hi):
         if not self.enabled or hi <= lo:        # world 1 still runs the collective when a group exists (1-GPU RCCL path)
             return
-        w = dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        if self.overlap:
-            self.pending.append(w)
+        if self._dry:                           # (diagnostic: the step's own data-parallel overhead without RCCL's kernels)
+            return
+        n, w_ = hi - lo, self.world
+        if self.algo == 'rs_ag' and w_ > 1 and n >= 4096 * w_:
+            # equal slices (the tail that does not divide goes through a small all-reduce of its own)
+            per = n // w_
+            body = flat[lo:lo + per * w_]
+            mine = body[self.rank * per:(self.rank + 1) * per]
+            w1 = dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w1.wait()                          # (stream-level: orders the all-gather behind the reduce-scatter on RCCL's stream)
+            w = dist.all_gather_into_tensor(body, mine, group=self.group, async_op=True)
+            works = [w]
+            if per * w_ < n:
+                works.append(dist.all_reduce(flat[lo + per * w_:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
-            w.wait()
+            works = [dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+        for w in works:
+            if self.overlap:
+                self.pending.append(w)
+            else:
+                w.wait()
 
     def wait_all(self):
         for w in self.pending:

@@ -89,7 +89,9 @@ class ParamStore(object):
         self.n = off
         self.p = torch.zeros(off, dtype=torch.float32, device=device)
         if training:
-            self.g = torch.zeros(off, dtype=torch.float32, device=device)
+            # (+1 float behind the gradients: the loss accumulator lives at g[n], so that under data parallelism the LAST gradient
+            # bucket carries it through the same all-reduce -- BaseModel._train_step_dp -- and the reported loss is the global mean)
+            self.g = torch.zeros(off + 1, dtype=torch.float32, device=device)
             self.m = torch.zeros(off, dtype=torch.float32, device=device)
             self.v = torch.zeros(off, dtype=torch.float32, device=device)
         self.step = torch.zeros(2, dtype=torch.int64, device=device)     # [global_step, steps completed before the current one]
@@ -181,6 +183,10 @@ class ParamStore(object):
 
     def get_grads(self):
         return self._unflatten(self.g)
+
+    def loss_slot(self):
+        """the float behind the gradient arena that models use as their loss accumulator"""
+        return self.g[self.n:self.n + 1]
 
 
 def _fork(src, dst):
@@ -283,7 +289,7 @@ class Plan(object):
         self.ops.append((name, fn, args))
         self.meta.append(meta)
 
-    def run(self, stream, side=None, skip=(), flavor='per_layer'):
+    def run(self, stream, side=None, skip=(), flavor='per_layer', join_into=None, on_marker=None):
         """Launches every op in order.  Ops tagged side=1 (filter gradients: nothing on the backward critical path
         consumes them) go round-robin onto the `side` torch streams; each first waits for an event recorded on the
         main stream at its program position (so everything launched before it is its dependency) and the side
@@ -292,6 +298,9 @@ class Plan(object):
         if not side:
             dbg = os.environ.get('SEG_DEBUG_SYNC')        # name every launch on stderr and synchronise after it (fault hunting)
             for i_, (name, fn, args) in enumerate(self.ops):
+                if fn is None and on_marker is not None and self.meta[i_].get('marker'):
+                    on_marker(self.meta[i_], [])
+                    continue
                 if fn is None or name in skip or self.meta[i_].get('flavor', flavor) != flavor:
                     continue
                 d_ = self.meta[i_].get('desc')
@@ -342,9 +351,30 @@ class Plan(object):
                 # fork elision below must not treat it as up to date (a later op on it may consume st_'s output)
                 main_epoch += 1
 
+        pending_markers = []                      # data-parallel bucket markers waiting for held (signal-forked) side launches
+
+        def fire_markers():
+            # a marker's callback (the bucket's all-reduce, issued from a communication stream) may only see the side streams once
+            # every side launch in front of the marker is really enqueued: launches held back for a signal fork are not yet
+            if held or not pending_markers:
+                return
+            for md in pending_markers:
+                on_marker(md, [by_id[k] for k in dirty if k in by_id])
+            del pending_markers[:]
+
         for i, (name, fn, args) in enumerate(self.ops):
             tag = self.meta[i].get('side', 0)
             if name in skip or self.meta[i].get('flavor', flavor) != flavor:
+                continue
+            if fn is None and self.meta[i].get('marker'):
+                if on_marker is not None:
+                    if self.meta[i]['marker'] == 'wait':
+                        assert not held
+                        fire_markers()
+                        on_marker(self.meta[i], [])
+                    else:
+                        pending_markers.append(self.meta[i])
+                        fire_markers()
                 continue
             if fn is None and name == 'join_all':      # marker: the main stream waits for every side stream used so far
                 for o_ in used.values():
@@ -423,10 +453,22 @@ class Plan(object):
                             if r_ != 0:
                                 L.check(r_, '%s/%s' % (self.name, nm_))
                         del held[sid_]
+                    fire_markers()
             if rc != 0:
                 L.check(rc, '%s/%s' % (self.name, name))
         if aux_used:
             used[id(aux)] = aux
+        if pending_markers and on_marker is not None:
+            assert not held
+            fire_markers()
+        if join_into is not None and not capturing:
+            # data-parallel segment: whoever consumes this segment's side-stream results (the bucket's all-reduce, issued from the
+            # communication stream `join_into`) waits for them; the main stream does NOT -- it goes straight on to the next segment
+            # (each drain of the side streams into the main stream cost 17-30 us of step time)
+            assert not held, 'a signal fork was still pending at the end of a segment'
+            for st in used.values():
+                ev = torch.cuda.Event(); ev.record(st); join_into.wait_event(ev)
+            return
         for st in used.values():
             join(st)
 
@@ -1245,6 +1287,13 @@ class Net(object):
             return
         plan.add('pack', self.lib.seg_pack_weights, s.p.data_ptr(), s.packed.data_ptr(), s.pack_table.data_ptr(),
                  s.n_pack_entries, s.pack_blocks, self.dtype, **meta)
+
+    def dp_marker(self, plan, kind, **kw):
+        """data-parallel marker: 'bucket' (lo, hi: this slice of the gradient arena is complete once everything in front of the
+        marker has run) or 'wait' (every bucket must have landed before what follows).  Plan.run(on_marker=...) calls back; a run
+        without a callback ignores them."""
+        plan.ops.append(('dp_' + kind, None, ()))
+        plan.meta.append(dict(kernel='marker', marker=kind, **kw))
 
     def join_all(self, plan):
         """main stream waits for every side stream (the filter gradients) -- e.g. before Adam inside the same plan"""

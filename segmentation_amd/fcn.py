@@ -169,7 +169,7 @@ class FCNModel(BaseModel):
         net.tail_layers = ('conv2',)      # last tiled filter gradient of the backward pass: aims for the whole chip (see unet.py); +2 % at C3
         Ly, nc = self.store.layers, self.n_classes
         fwd = self.fwd_plan = E.Plan('fwd')
-        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.loss_buf = self.store.loss_slot()          # (behind the gradient arena: reduced with the last bucket under data parallelism)
         net.step_begin(fwd, self.loss_buf)     # aux stream: global_step += 1, loss accumulator = 0
         net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1
         col = net.first_im2col(fwd, Ly['conv1'], self.input_x, H, W)         # side stream, overlaps the forward pass

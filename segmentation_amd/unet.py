@@ -207,7 +207,7 @@ class UNetModel(BaseModel):
         net.tail_layers = ('conv1_2', 'conv2_1')
         Ly = self.store.layers
         fwd = self.fwd_plan = E.Plan('fwd')
-        self.loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.loss_buf = self.store.loss_slot()          # (behind the gradient arena: reduced with the last bucket under data parallelism)
         net.step_begin(fwd, self.loss_buf)     # aux stream: global_step += 1, loss accumulator = 0
         net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1_1
         cols = []       # im2col of the input for conv1_1's filter gradient: side stream, right after conv1_1 (both are

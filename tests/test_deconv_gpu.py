@@ -273,7 +273,7 @@ def test_deconv_train_steps_test_and_infer_match_oracle():
     # test(): moving-average graph, dropout still on (is_training defaults True); the device-side step counter still holds
     # the value of the last train step (1 completed before it)
     m.test()
-    lt, _, _ = odec.forward(p, x[0], training=False, bayesian=True, dropout={'keep': 0.5, 'seed': 5555, 'offset': 1 << 40})
+    lt, _, _ = odec.forward(p, x[0], training=False, bayesian=True, dropout={'keep': 0.5, 'seed': 5555 + 64, 'offset': 1 << 40})   # (test(): own streams, seed + 64)
     loss_t, _, _ = ops.softmax_xent(lt, y[0])
     assert abs(m.last_test_loss - loss_t) < 1e-4 * max(1.0, abs(loss_t)), (m.last_test_loss, loss_t)
     assert abs(m.last_loss() - losses[-1]) < 1e-7                       # test() does not disturb the training loss

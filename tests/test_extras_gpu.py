@@ -252,3 +252,25 @@ def test_loaded_library_was_linted_for_the_wgrad_register_budget():
     assert rec['sources'] == _build.source_digest(), 'the verdict belongs to other sources than the ones in the tree'
     assert rec['instances'] >= 30 and not rec['over_budget'], rec
     assert rec['max_arch_vgprs'] < rec['limit']
+
+
+@pytest.mark.gpu
+def test_bench_force_dist_child_process_reports_the_allreduce():
+    """`bench.py --gpus 1 --force-dist` in a child process: the data-parallel code path end to end on one GPU (RCCL group of one --
+    the launcher / multi-rank part needs an 8-GPU node and is the driver's to run): one JSON line, the bucket plan, every
+    bucket's exposed time, a finite loss -- and the line must not hang on a collective only rank 0 joins."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--force-dist', '--steps', '5', '--warmup', '3', '--windows', '2',
+                        '--no-cpu-baseline', '--no-roofline', '--dp-cuts', 'default'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-500:]
+    j = json.loads(lines[0])
+    ar = j['config']['allreduce']
+    assert ar['world'] == 1 and len(ar['buckets_mb']) == len(ar['cuts']) + 1 == len(ar['exposed_us'])
+    assert abs(sum(ar['buckets_mb']) - 31.04) < 0.01                       # the 7 760 196-parameter fp32 arena
+    assert all(u >= 0 for u in ar['exposed_us']) and ar['exposed_total_us'] < 2000
+    assert j['n_gpus'] == 1 and j['value'] > 0 and np.isfinite(j['config']['final_loss'])
+    assert j['config']['ms_per_step_windows']['n'] == 2

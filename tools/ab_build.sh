@@ -8,8 +8,9 @@ d=segmentation_amd/build/ab_$tag; rm -rf $d; mkdir -p $d/pkg/csrc $d/include
 for f in $(git ls-tree --name-only $rev segmentation_amd/csrc/); do git show $rev:$f > $d/pkg/csrc/$(basename $f); done
 git show $rev:include/seg_hip.h > $d/include/seg_hip.h
 objs=""
-for f in conv_fwd conv_wgrad conv_first elementwise deconv_ops adv_ops; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -I$d/include -c $d/pkg/csrc/$f.hip -o $d/$f.o &
+for src in $d/pkg/csrc/*.hip; do            # whatever translation units that revision has
+  f=$(basename $src .hip)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -I$d/include -c $src -o $d/$f.o &
   objs="$objs $d/$f.o"
 done
 wait
