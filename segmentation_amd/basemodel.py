@@ -385,7 +385,7 @@ class BaseModel(object):
                     for st in side_streams[1:]:
                         ev = torch.cuda.Event(); ev.record(st); st0.wait_event(ev)
                     with torch.cuda.stream(st0):
-                        self.pg.all_reduce_bucket(self.store.g, md['lo'], md['hi'])
+                        self.pg.all_reduce_bucket(self.store.g_full, md['lo'], md['hi'])
                     return
                 # 'wait': every bucket must have landed (the main stream has already waited for the side streams)
                 if evs is not None:
@@ -408,10 +408,10 @@ class BaseModel(object):
                 self.fwd_plan.run(self._stream(), self._side, flavor=self._flavor())
                 self.bwd_segments[0][0].run(self._stream(), self._side, flavor=self._flavor())
             self._replay(('dp0', key), head)
-            self.pg.all_reduce_bucket(self.store.g, self.bwd_segments[0][1][0], self.bwd_segments[0][1][1] + (1 if nseg == 1 else 0))
+            self.pg.all_reduce_bucket(self.store.g_full, self.bwd_segments[0][1][0], self.bwd_segments[0][1][1] + (1 if nseg == 1 else 0))
             for i, (plan, (lo, hi)) in enumerate(self.bwd_segments[1:], 1):
                 self._replay('dp%d' % i, lambda plan=plan: plan.run(self._stream(), self._side, flavor=self._flavor()))
-                self.pg.all_reduce_bucket(self.store.g, lo, hi + (1 if i == nseg - 1 else 0))
+                self.pg.all_reduce_bucket(self.store.g_full, lo, hi + (1 if i == nseg - 1 else 0))
         self._loss_is_sum = True
         if probe is None:
             self.pg.wait_all()

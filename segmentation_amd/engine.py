@@ -91,7 +91,8 @@ class ParamStore(object):
         if training:
             # (+1 float behind the gradients: the loss accumulator lives at g[n], so that under data parallelism the LAST gradient
             # bucket carries it through the same all-reduce -- BaseModel._train_step_dp -- and the reported loss is the global mean)
-            self.g = torch.zeros(off + 1, dtype=torch.float32, device=device)
+            self.g_full = torch.zeros(off + 1, dtype=torch.float32, device=device)
+            self.g = self.g_full[:off]
             self.m = torch.zeros(off, dtype=torch.float32, device=device)
             self.v = torch.zeros(off, dtype=torch.float32, device=device)
         self.step = torch.zeros(2, dtype=torch.int64, device=device)     # [global_step, steps completed before the current one]
@@ -186,7 +187,7 @@ class ParamStore(object):
 
     def loss_slot(self):
         """the float behind the gradient arena that models use as their loss accumulator"""
-        return self.g[self.n:self.n + 1]
+        return self.g_full[self.n:self.n + 1]
 
 
 def _fork(src, dst):

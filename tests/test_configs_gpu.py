@@ -34,18 +34,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F32_LOGIT_TOL = 1e-4            # north_star: fp32 logits within 1e-4 of the (TF-)CPU path
 
-# bf16-mode vs f32-mode bounds per config = ~2x the values measured on MI355X (profiles/r02_parity_measured.jsonl):
+# bf16-mode vs f32-mode bounds per config = 1.3x the values measured on MI355X (profiles/r03_parity_measured.jsonl; cosines
+# 1 - 1.3 (1 - measured)).  NOTE what gl2 / gcos of the U-Net rows measure: uniform-random images with random labels at the xavier /
+# zero-bias init put the pre-activations around zero, where a 2^-9 perturbation flips ReLU gates -- tests/test_precision_gpu.py
+# attributes the gap (forward roundings only; the gradient chain contributes < 1 %) and measures 0.047 / 0.9989 on image-like data.
 #   logit  max |dlogit| / max |logit|          loss   relative loss error
 #   gl2    worst relative L2 error of a gradient tensor (weights)       gcos   worst cosine of a gradient tensor
 #   dis0   argmax pixel-disagreement rate at the xavier init (tiny top-2 margins)
 #   dis1   the same after 20 bf16 train steps on the batch              miou1  |mIoU_bf16 - mIoU_f32| against the labels
 BOUNDS = {
     # measured (MI355X, r02): logit .0092  loss 1e-6  gl2 .230 (conv4_1)  gcos .976  dis0 .0028  dis1 .0063  |dmIoU| 7e-5
-    'C2': dict(logit=0.02, loss=1e-4, gl2=0.45, gcos=0.95, dis0=0.006, dis1=0.013, miou1=0.005),
+    'C2': dict(logit=0.012, loss=1e-4, gl2=0.30, gcos=0.969, dis0=0.0037, dis1=0.0082, miou1=0.005),
     # measured: logit .0067  loss 8e-6  gl2 .0123 (conv5)  gcos .99992  dis0 2e-6  dis1 .0200  |dmIoU| 1e-4
-    'C3': dict(logit=0.014, loss=1e-4, gl2=0.025, gcos=0.9995, dis0=1e-4, dis1=0.04, miou1=0.005),
+    'C3': dict(logit=0.0088, loss=1e-4, gl2=0.016, gcos=0.9999, dis0=1e-4, dis1=0.026, miou1=0.005),
     # measured: logit .0104  loss <1e-6  gl2 .190 (conv5_1)  gcos .982  dis0 .0033  dis1 .0085  |dmIoU| 1e-5
-    'C4': dict(logit=0.021, loss=1e-4, gl2=0.40, gcos=0.96, dis0=0.007, dis1=0.017, miou1=0.005),
+    'C4': dict(logit=0.0136, loss=1e-4, gl2=0.25, gcos=0.9766, dis0=0.0043, dis1=0.0111, miou1=0.005),
 }
 
 
