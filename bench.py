@@ -188,7 +188,13 @@ def roofline_report(agg, ops, reps, dtype, total_steps_ms, pmc_tag=None):
     traffic, tsrc = None, None
     # HBM bytes per launch come from the committed rocprofv3 --pmc passes OF THIS WORKLOAD (tools/collect_profiles.sh); a workload
     # without a committed counter file reports null rather than another workload's number
-    pmc_file = 'pmc_summary.json' if pmc_tag == '' else ('r02_%s_pmc_summary.json' % pmc_tag if pmc_tag else None)
+    pmc_file = None
+    if pmc_tag == '':
+        pmc_file = 'pmc_summary.json'
+    elif pmc_tag:                                  # newest round that holds this workload's counter passes
+        import glob
+        c = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_%s_pmc_summary.json' % pmc_tag)))
+        pmc_file = os.path.basename(c[-1]) if c else None
     pmc = os.path.join(ROOT, 'profiles', pmc_file) if pmc_file else None
     if pmc and os.path.exists(pmc):
         try:

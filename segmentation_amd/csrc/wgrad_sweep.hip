@@ -5,15 +5,17 @@
 //
 // What is different, and why (profiles/r02_sq_counters.json: 44 % of a lone workgroup's cycles in the
 // MFMAs, 31 % issuing staging / commit / address instructions, 18 % parked at two barriers per tile):
-//   * 8 waves = 4 MFMA waves + 4 loader waves.  The loaders move every tile global -> LDS with global_load_lds (no staging
-//     registers, no ds_write, nothing the compiler can mis-allocate: the hand-waited asm loads of the old walk are gone) into a
-//     ring of 2-3 stages; ONE s_barrier per tile; two loader groups alternate tiles so that a plain vmcnt(0) leaves a whole
-//     tile in flight behind the one being waited for.
+//   * 8 waves = 4 MFMA waves + 4 loader waves.  The loaders move every tile global -> registers -> LDS (full 64-byte pixel
+//     rows per lane group, so every load instruction covers whole cache lines; the first form of this kernel filled the
+//     32-byte-per-pixel planes with global_load_lds and spent 3.5 us per 76 KB tile touching 32 lines per instruction) through
+//     2 LDS stages + 1 register stage = two tiles of look-ahead; ONE s_barrier per tile.  The loads are plain C++ loads whose
+//     results the compiler tracks, so no hand-written waitcnt can be broken by a register-allocation change;
+//     tools/check_wgrad_regs.py still lints the register budget of both walks at build time (segmentation_amd/_build.py).
 //   * The K index of the GEMM is a LINEARISED window of output pixels (TB images x TR rows x TC columns, padded to 32): a
 //     10 x 10 map is 4 K steps (78 % useful) instead of two 8 x 16 tiles (39 %), an 8 x 8 map shares a window with the next
 //     images.  ds_read_b64_tr_b16 takes one address per pixel row, so the window shape only lives in a per-lane offset table.
 //   * LDS image = one plane per 16 channels, 32 bytes per pixel: a 32-lane half of a transposed read covers 8 consecutive
-//     pixels = 256 contiguous bytes = every bank once, with no padding and no swizzle (a glds image cannot be padded).
+//     pixels = 256 contiguous bytes = every bank once, with no swizzle (planes are 64 bytes apart modulo the bank period).
 //   * Deep layers split the TAPS (9 / 3 / 1 per workgroup) instead of K: every workgroup sweeps all pixels and stores its part of
 //     dW directly -- no partial-sum slabs, no reduction launch.  Shallow layers still split K into slabs (wgrad_reduce_kernel).
 //   * The bias gradient is one extra MFMA per K step in one wave per dZ fragment (ones x dZ), not one per fragment in every wave.
@@ -29,17 +31,12 @@ __device__ __attribute__((aligned(16))) uint32_t g_zero16_sw[4] = {0, 0, 0, 0};
 struct SwK {
   seg_wgrad_desc d;
   int TR, TC, TB, PR, PC;      // window: TB images x TR x TC output pixels; patch rows / columns per image
-  int NPX, KS, NPATCH, XS;     // window pixels, K steps of 32, patch pixels (TB*PR*PC), glds instructions per X plane
+  int NPX, KS, NPATCH, XS;     // window pixels, K steps of 32, patch pixels (TB*PR*PC), 32-pixel groups per X plane
   uint32_t m_prpc, m_pc, m_trtc, m_tc;   // reciprocals: q / d == umulhi(q, 2^32 / d + 1) for q < 2^16, d >= 2
   int wy_n, wx_n, wb_n, nwin, ksplit;
   int nchunks0, nchunks, nblk;
   int k_pad, n_pad; long long slab; int direct;
 };
-
-SEG_DEV void glds16(const void* gsrc, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 // lane (G = lane>>4, qr = (lane&15)>>2, p = lane&3) passes the address of (pixel row, channels 4p..4p+3) for the two halves of
 // its K slice; receives channel (lane&15) of 4 + 4 pixels (ds_read_b64_tr_b16: cdna_hip_programming.md T10)

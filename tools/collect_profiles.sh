@@ -2,11 +2,11 @@
 # Run on the GPU box: rocprofv3 kernel-trace stats of one bench.py workload + the two TCC PMC passes (separate runs, as
 # MI355X_MICROARCH.md prescribes; signal forks are forced ON only for the kernel-trace pass, which leaves the queues concurrent,
 # and stay off -- the default under any profiler -- for the counter passes, which serialise dispatches), summarised into profiles/<tag>_{kernel_stats.csv,pmc_summary.json,bench.json}.
-#   tools/collect_profiles.sh r02                                  the headline (U-Net 256, B=16)
-#   tools/collect_profiles.sh r02_c4 --size 512 --steps 20 --warmup 5
-#   tools/collect_profiles.sh r02_c3 --model fcn8s --size 512 --classes 21 --batch 8
-#   tools/collect_profiles.sh r02_c5 --mode mc --batch 32 --steps 5 --warmup 2
-tag=${1:-r02}; shift
+#   tools/collect_profiles.sh r03                                  the headline (U-Net 256, B=16)
+#   tools/collect_profiles.sh r03_c4 --size 512 --steps 20 --warmup 5
+#   tools/collect_profiles.sh r03_c3 --model fcn8s --size 512 --classes 21 --batch 8
+#   tools/collect_profiles.sh r03_c5 --mode mc --batch 32 --steps 5 --warmup 2
+tag=${1:-r03}; shift
 args=("$@")
 [ ${#args[@]} -eq 0 ] && args=(--steps 50 --warmup 10)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/profiles_$tag
