@@ -22,6 +22,8 @@ from . import dist as D
 
 
 class BaseModel(object):
+    SHARE_AUX_STREAM = True      # single-GPU builds: the auxiliary launches share a filter-gradient stream (see __init__)
+
     def __init__(self,
                  sess,
                  mode='TRAINING',
@@ -100,13 +102,23 @@ class BaseModel(object):
             raise Exception('adversarial_training runs in one process (the adversary has no gradient all-reduce)')
         self._graphs = {}
         # side streams: wgrad_streams for the filter gradients + one auxiliary (weight re-pack)
+        if wgrad_streams > 0 and os.environ.get('SEG_WGRAD_STREAMS'):
+            wgrad_streams = max(1, int(os.environ['SEG_WGRAD_STREAMS']))
         self._side = [torch.cuda.Stream(self.device) for _ in range(wgrad_streams + 1)] if wgrad_streams > 0 else None
+        share = os.environ.get('SEG_SHARE_AUX', '1' if self.SHARE_AUX_STREAM else '0') == '1'
+        if self._side is not None and not self.pg.enabled and share:
+            # the auxiliary launches (step_begin, the weight re-pack beside the first layer) go onto a filter-gradient
+            # stream, idle at that time: main + two side streams instead of four streams is 2.7 % faster at C2 (1.010 -> 0.983 ms
+            # on one box, 512^2 unchanged; three filter-gradient streams gain nothing more -- profiles/r03_step_structure_ab.txt).
+            # Data-parallel builds keep the stream of their own: sharing it beside RCCL's stream measured 1.32 against 1.07 ms; so
+            # does the FCN (SHARE_AUX_STREAM = False: 0.824 against 0.817 ms at C3).
+            self._side[-1] = self._side[0]
         if self._side is not None and self.pg.enabled and os.environ.get('SEG_DP_SHARE_AUX', '0') == '1':
             # (experiment, off: the auxiliary work on the first filter-gradient stream, one stream fewer beside RCCL's -- 1.32 ms
             # against 1.07 with its own stream at world 1; what did matter was NOT creating a communication stream of our own: the
             # collectives are issued from a side stream, and asking for more hardware queues, GPU_MAX_HW_QUEUES = 6 / 8, is far
             # worse: 1.46 / 2.6 ms -- profiles/r03_dp_overhead.txt)
-            self._side[-1] = self._side[0]
+            self._side[-1] = self._side[-2]          # (the last one: the first carries the FCN's input im2col at the start of forward)
         self._packed_dirty = False
         self._infer_cache = {}
         self.sess = sess

@@ -190,6 +190,18 @@ class ParamStore(object):
         return self.g_full[self.n:self.n + 1]
 
 
+def _step_wgrad_wgs(input_pixels):
+    """Workgroups a filter gradient aims for INSIDE a training step (0 = the library's default for a lone launch, 128).  It shares
+    the chip with the data gradient on the critical stream and the other side stream's filter gradient.  Small steps (C2: 16 x 256^2
+    = 1 M input pixels, C3: 8 x 512^2 = 2 M) are bound by the critical stream: 64 workgroups per filter gradient leave it half of
+    the CUs (C2 on one box: 48 / 64 / 80 / 96 / 128 -> 0.986 / 0.960 / 0.974 / 0.976 / 0.987 ms; C3 0.797 against 0.817).  At 4 M
+    input pixels (C4's shard, DeconvModel 512^2) the side streams are the tail and 128 stays (4.09 against 4.12 ms, 2.81 against
+    2.92) -- profiles/r03_step_structure_ab.txt.  SEG_WGRAD_WGS overrides."""
+    if os.environ.get('SEG_WGRAD_WGS'):
+        return int(os.environ['SEG_WGRAD_WGS'])
+    return 64 if input_pixels is not None and input_pixels <= 2500000 else 0
+
+
 def _fork(src, dst):
     """cross-stream dependency: `dst waits for what src holds now` (under stream capture this becomes a graph edge)"""
     ev = torch.cuda.Event(); ev.record(src); dst.wait_event(ev)
@@ -711,6 +723,8 @@ class Net(object):
         """Asks the library for the K split / partial-slab workspace of this wgrad and allocates it."""
         ks, nbytes = C.c_int32(0), C.c_int64(0)
         w.ksplit = ksplit
+        if w.target_wgs == 0 and self.side_enabled:
+            w.target_wgs = _step_wgrad_wgs(getattr(self, 'input_pixels', None))     # (the models set Net.input_pixels = B * H * W)
         L.check(self.lib.seg_conv2d_wgrad_plan(C.byref(w), C.byref(ks), C.byref(nbytes)), 'wgrad_plan')
         ws = torch.empty(max(nbytes.value // 4, 4), dtype=torch.float32, device=self.device)
         w.ws = ws.data_ptr(); w.ws_bytes = nbytes.value; w.ksplit = ks.value

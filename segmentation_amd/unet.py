@@ -203,6 +203,7 @@ class UNetModel(BaseModel):
         B, (H, W) = self.batch_size, self.input_dims
         net = self.net = E.Net(self.store, B, self.dtype, self.device)
         net.n_wgrad_streams = max(1, len(self._side) - 1) if self._side else 1
+        net.input_pixels = B * H * W
         # the last filter gradients of the backward pass outlive the critical stream: they aim for the whole chip (256 workgroups)
         net.tail_layers = ('conv1_2', 'conv2_1')
         Ly = self.store.layers
