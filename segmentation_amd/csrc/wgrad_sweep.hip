@@ -54,6 +54,7 @@ SEG_DEV Frag<bf16_t> tr_read(const char* lo, const char* hi) {
 // wave 4 (loader) of every workgroup: [wg][0] row 0: entry, set-up done, walk done, flush done, then (barrier passed, tile
 // computed) per tile; row 1: loader set-up done, then the time each of its tile issues was complete
 __device__ long long* g_swstamps = nullptr;
+__device__ int g_swfilter[3] = {0, 0, 0};      // (Ho, k_pad, n_pad) of the one layer that stamps inside a whole step; 0 = every launch
 #define SWSTAMP(row, idx) do { if (swst && (idx) < 32) swst[(row) * 32 + (idx)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define SWSTAMP(row, idx) do { } while (0)
@@ -94,7 +95,9 @@ __global__ __launch_bounds__(512) void wgrad_sweep_kernel(const SwK P) {
   auto barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
 #ifdef SEG_STAMPS
   const int wg_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  long long* swst = (g_swstamps && wg_lin < 1024 && lane == 0 && (wave == 0 || wave == 4)) ? g_swstamps + (int64_t)wg_lin * 64 : nullptr;
+  long long* swst = (g_swstamps && wg_lin < 1024 && lane == 0 && (wave == 0 || wave == 4) &&
+                     (g_swfilter[0] == 0 || (P.d.Ho == g_swfilter[0] && P.k_pad == g_swfilter[1] && P.n_pad == g_swfilter[2])))
+                        ? g_swstamps + (int64_t)wg_lin * 64 : nullptr;
   if (wave == 0) SWSTAMP(0, 0);
 #endif
 
@@ -459,6 +462,7 @@ bool choose(const seg_wgrad_desc& d, int layout, Choice* best) {
   if (d.ksplit > 0) f_ks = d.ksplit;
   bool found = false;
   best->cost = 1e30;
+  static const double reduce_us = getenv("SEG_SWEEP_REDUCE_US") ? atof(getenv("SEG_SWEEP_REDUCE_US")) : 5.5;
   static const int tg_opts[] = {1, 3, 9};
   for (int tgs : tg_opts) {
     if (f_tgs && tgs != f_tgs) continue;
@@ -478,7 +482,7 @@ bool choose(const seg_wgrad_desc& d, int layout, Choice* best) {
         const double rounds = (double)((wgs + target - 1) / target);
         const double tiles = (double)((g.nwin + ks - 1) / ks);
         const double t_wg = 4.5 + tiles * g.cyc_win + slab_tile / 1024.0 * (ks > 1 ? 0.028 : 0.011);
-        const double t_s = ks > 1 ? 5.5 + wgs * slab_tile / 6.0e6 : 0.0;
+        const double t_s = ks > 1 ? reduce_us + wgs * slab_tile / 6.0e6 : 0.0;
         const double cost = 3.0 + rounds * t_wg + t_s;
         if (cost < best->cost) { best->cost = cost; best->layout = layout; best->tgs = tgs; best->cls = cls; best->ks = ks; best->g = g; found = true; }
       };
@@ -495,6 +499,10 @@ bool choose(const seg_wgrad_desc& d, int layout, Choice* best) {
 }  // namespace
 
 #ifdef SEG_STAMPS
+extern "C" int seg_dbg_set_swfilter(int ho, int k_pad, int n_pad) {
+  const int v[3] = {ho, k_pad, n_pad};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_swfilter), v, sizeof(v)) == hipSuccess ? 0 : -1;
+}
 extern "C" int seg_dbg_set_swstamps(void* p) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_swstamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
 }

@@ -731,12 +731,28 @@ class Net(object):
         self.ws_bytes = getattr(self, 'ws_bytes', 0) + nbytes.value
         plan.keep += [w, ws]
 
+    def _pick_wgrad_stream(self, cost_us):
+        """Side stream (1-based tag) of the next filter gradient: the one with the least work so far.  cost_us is the estimate
+        the models' measured in-step durations fit (15 us + FLOPs at 200 TFLOP/s + 10 us for a slab reduction); plain alternation
+        gave the conv*_2 layers (cin = cout, the heavier of each pair) to one stream: 567 against 478 us at C2.  Only the big steps
+        (> 2.5 M input pixels: the side streams are their tail) gain from it -- 512^2 4.04 against 4.07 ms; at C2, bound by the
+        critical stream, the balanced assignment measured 0.953 against 0.941 ms and the alternation stays (SEG_WGRAD_BALANCE=0/1)."""
+        n = self.n_wgrad_streams
+        big = getattr(self, 'input_pixels', None) is not None and self.input_pixels > 2500000
+        if n < 2 or os.environ.get('SEG_WGRAD_BALANCE', '1' if big else '0') == '0':
+            k = self._wg_rr % n
+            self._wg_rr += 1
+            return 1 + k
+        load = self.__dict__.setdefault('_wg_load', [0.0] * n)
+        k = min(range(n), key=lambda i: load[i])
+        load[k] += cost_us
+        return 1 + k
+
     def _add_wgrad(self, plan, name, w, fl, sid=None):
         """One plan op for the partial-sum kernel and, when K is split, a second one for the slab reduction (same side
         stream): two C-ABI calls so that each kernel is timed on its own."""
         if sid is None:
-            sid = 1 + self._wg_rr % self.n_wgrad_streams    # side stream of this layer's filter gradient
-            self._wg_rr += 1
+            sid = self._pick_wgrad_stream(15.0 + fl / 2e8 + (10.0 if w.ksplit > 1 else 0.0))
         if not self.side_enabled:
             sid = 0                                             # (experiments) keep it on the main stream
         if w.ksplit > 1:
@@ -1272,8 +1288,7 @@ class Net(object):
     def head_dw_reduce(self, plan, layer, ws, H, W, cin_pad, n_classes):
         """Workspace rows of head_xent(fuse_dw) -> the output layer's filter and bias gradient; a side stream, like the
         filter gradients it replaces."""
-        sid = 1 + self._wg_rr % self.n_wgrad_streams
-        self._wg_rr += 1
+        sid = self._pick_wgrad_stream(7.0)
         if not self.side_enabled:
             sid = 0
         plan.add(layer.name + '/dw', self.lib.seg_head_dw_reduce, ws.data_ptr(), ws.numel(), self.B, H, W, cin_pad, layer.cin, n_classes,

@@ -1,0 +1,10 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+run() { label=$1; shift; env "$@" python bench.py --steps ${STEPS:-200} --warmup 30 --no-cpu-baseline --no-roofline ${BENCH_ARGS} 2>/dev/null | tail -1 > gpurun_out/ab_$label.json; python -c "
+import json,sys
+j=json.load(open('gpurun_out/ab_$label.json')); print('%-28s' % '$label', j['value'], j['config']['ms_per_step_windows']['all'])"; }
+run new X=0
+run nobalance SEG_WGRAD_BALANCE=0
+run adam_overlap SEG_ADAM_OVERLAP=1
+run adam_overlap_nobal SEG_ADAM_OVERLAP=1 SEG_WGRAD_BALANCE=0
+run new2 X=0

@@ -28,6 +28,9 @@ for label, pat in [('full step', None),
                    ('- slab reductions', lambda n, md: n.endswith('/reduce')),
                    ('- filter gradients and reductions', lambda n, md: n.endswith('/reduce') or n.endswith('/dw')),
                    ('- every side-stream op', lambda n, md: md.get('side', 0) not in (0, None)),
+                   ('- side-stream ops and Adam', lambda n, md: md.get('side', 0) not in (0, None) or n.startswith('adam')),
+                   ('forward only (no loss head)', lambda n, md: md.get('side', 0) not in (0, None) or n.startswith('adam') or '/d' in n or n.startswith('pool/bwd') or n.startswith('output')),
+                   ('- data gradients (forward + filter gradients + Adam)', lambda n, md: ('/dx' in n or n.startswith('pool/bwd'))),
                    ('full step', None)]:
     SKIP['pat'] = pat
     for _ in range(10):
