@@ -1,8 +1,8 @@
 #!/bin/bash
-# GPU box: only the bench lines of tools/refresh_r02.sh (profiles/r02_bench_lines.jsonl)
+# GPU box: only the bench lines of tools/the round profiles (profiles/r03_bench_lines.jsonl)
 set -e
 cd $GRAFT_REPO_ROOT
-L=gpurun_out/r02_bench_lines.jsonl; rm -f $L
+L=gpurun_out/r03_bench_lines.jsonl; rm -f $L
 echo line; timeout -k 10 200 python bench.py >> $L 2>/dev/null
 echo line; timeout -k 10 200 python bench.py --host-data --no-cpu-baseline >> $L 2>/dev/null
 echo line; timeout -k 10 200 python bench.py --size 512 --steps 20 --warmup 5 --no-cpu-baseline >> $L 2>/dev/null
