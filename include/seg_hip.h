@@ -78,6 +78,16 @@ typedef struct seg_conv_desc {
   int32_t* sched;          /* nullable: two zero-initialised int32 words of device memory owned by this launch site (not shared with a
                             * launch that may run concurrently).  The persistent bf16 3x3 kernel hands its tiles out through them (an
                             * atomic ticket) and leaves them zero again when it ends; without them tiles are split statically. */
+  int32_t ksplit;          /* 0 / 1: one workgroup per output tile.  > 1 (tiled kernels; ask seg_conv2d_splitk_plan): the K chunks of a
+                            * tile are shared by `ksplit` workgroups; each stores its f32 partial tile to splitk_ws and takes a ticket;
+                            * the LAST to arrive adds the partials in split order (fixed association: reproducible bit for bit,
+                            * whichever workgroup does it) and runs the whole epilogue.  Meant for the layers whose grid leaves <= 2
+                            * workgroups per CU on maps of 8..28 pixels (conv4_x..conv7_x at 256^2 inputs and their dgrads); measured
+                            * slower than the unsplit launch on all of them but one, so seg_conv2d_splitk_plan only proposes a split
+                            * when asked to (SEG_CONV_SPLITK=n) -- DESIGN.md section 5. */
+  int32_t splitk_pad_;
+  float* splitk_ws;        /* ksplit > 1: workspace of seg_conv2d_splitk_plan's size, owned by this launch site */
+  int32_t* splitk_tickets; /* ksplit > 1: one zero-initialised int32 per (output tile x channel block); left zero again by the launch */
 } seg_conv_desc;
 
 /* slim.convolution2d / conv2d_transpose fwd, Conv2DBackpropInput: models/unet.py:111-166,
@@ -87,6 +97,10 @@ int seg_conv2d(const seg_conv_desc* d, void* stream);
  * "conv_fwd_kernel<bf16,8,16,64,4,1,3,3,1>" -- used by bench.py to key per-kernel roofline numbers
  * to the names rocprofv3 prints. */
 int seg_conv2d_kernel_name(const seg_conv_desc* d, char* buf, int32_t cap);
+/* Reports (without launching) whether seg_conv2d would gain from sharing the K loop of d among several workgroups per output
+ * tile: *ksplit (1 = no), the bytes of seg_conv_desc.splitk_ws and the number of int32 words of splitk_tickets a launch with that
+ * ksplit needs.  d->ksplit > 0 on entry asks for that split (clamped to the K chunks the layer has). */
+int seg_conv2d_splitk_plan(const seg_conv_desc* d, int32_t* ksplit, int64_t* ws_bytes, int32_t* tickets);
 
 /* Filter gradient (Conv2DBackpropFilter) + bias gradient (BiasAddGrad) for the same sites.
  * dw[tap][k][n] = sum_pixels src[b, y*s+u-pad_t, x*s+v-pad_l, k] * dz[b,y,x,n]   (f32, overwritten).

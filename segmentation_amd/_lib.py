@@ -29,7 +29,8 @@ class ConvDesc(C.Structure):
                 ('dst', View), ('up2', C.c_int32), ('up_cout', C.c_int32), ('mask', View), ('relu', C.c_int32),
                 ('out_f32', C.c_int32), ('dtype', C.c_int32), ('cfg', C.c_int32), ('accum', C.c_int32),
                 ('n_split', C.c_int32), ('dst1', View), ('mask1', View), ('pool', View), ('pool_h', C.c_int32), ('pool_w', C.c_int32),
-                ('signal', C.c_void_p), ('signal_value', C.c_uint32), ('sched', C.c_void_p)]
+                ('signal', C.c_void_p), ('signal_value', C.c_uint32), ('sched', C.c_void_p),
+                ('ksplit', C.c_int32), ('splitk_pad_', C.c_int32), ('splitk_ws', C.c_void_p), ('splitk_tickets', C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -67,6 +68,7 @@ SIGNATURES = {
     'seg_conv2d': [C.POINTER(ConvDesc), vp],
     'seg_conv2d_wgrad': [C.POINTER(WgradDesc), vp],
     'seg_conv2d_kernel_name': [C.POINTER(ConvDesc), C.c_char_p, i32],
+    'seg_conv2d_splitk_plan': [C.POINTER(ConvDesc), C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)],
     'seg_conv2d_wgrad_kernel_name': [C.POINTER(WgradDesc), C.c_char_p, i32],
     'seg_conv2d_wgrad_plan': [C.POINTER(WgradDesc), C.POINTER(i32), C.POINTER(i64)],
     'seg_wgrad_reduce_batch_plan': [C.POINTER(C.POINTER(WgradDesc)), i32, vp, i64, C.POINTER(i32), C.POINTER(i32)],

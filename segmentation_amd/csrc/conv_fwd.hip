@@ -237,6 +237,53 @@ extern "C" int seg_dbg_set_ablate(int bits) { return hipMemcpyToSymbol(HIP_SYMBO
 #define ABL(bit) false
 #endif
 
+// ---- split K: `ksplit` workgroups (blockIdx.z) share the K chunks of one output tile -------------------------------------
+// Every workgroup stores its partial accumulators (f32, lane-major: one 16-byte store per fragment and lane, 1 KB per wave
+// instruction), makes them visible to the other XCDs (agent-scope release: this part has one L2 per XCD) and takes a ticket; the
+// LAST arriver re-reads all partials -- its own included -- and adds them in split order, so the sum has ONE association whoever
+// does it (bitwise reproducible), then runs the ordinary epilogue.  Returns false for the workgroups that are done.
+template <int FN, int FM>
+SEG_DEV bool splitk_combine(const seg_conv_desc& d, f32x4 (&acc2)[FN][FM], int tile_lin, int kz, int tid, int nthreads, int* s_flag) {
+  constexpr int NA = FN * FM;
+#define acc(i) acc2[(i) / FM][(i) % FM]
+  typedef unsigned long long u64;
+  const int ks = d.ksplit;
+  // The partials travel as agent-scope relaxed atomics (sc1: written through / read past the XCD-local L2), so no cache-wide
+  // release (buffer_wbl2) or acquire (buffer_inv) is needed: those act on the WHOLE L2 of the XCD and, with 500-1000 workgroups
+  // each issuing one beside the filter gradients, made the train step 50 % slower (1.46 against 0.97 ms).
+  u64* wsb = reinterpret_cast<u64*>(d.splitk_ws) + (((int64_t)tile_lin * ks + kz) * (int64_t)(NA * nthreads)) * 2;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const f32x4 v = acc(i);
+    u64 lo, hi;
+    __builtin_memcpy(&lo, reinterpret_cast<const char*>(&v), 8); __builtin_memcpy(&hi, reinterpret_cast<const char*>(&v) + 8, 8);
+    u64* q = wsb + ((int64_t)i * nthreads + tid) * 2;
+    __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's partials have been performed at agent scope
+  __syncthreads();
+  if (tid == 0) *s_flag = __hip_atomic_fetch_add(d.splitk_tickets + tile_lin, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*s_flag != ks - 1) return false;
+  const u64* w0 = reinterpret_cast<const u64*>(d.splitk_ws) + ((int64_t)tile_lin * ks * (int64_t)(NA * nthreads)) * 2;
+  for (int z = 0; z < ks; ++z) {
+    const u64* wz = w0 + (int64_t)z * (NA * nthreads) * 2;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const u64* q = wz + ((int64_t)i * nthreads + tid) * 2;
+      const u64 lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u64 hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      f32x4 v;
+      __builtin_memcpy(reinterpret_cast<char*>(&v), &lo, 8); __builtin_memcpy(reinterpret_cast<char*>(&v) + 8, &hi, 8);
+      if (z == 0) acc(i) = v; else acc(i) += v;
+    }
+  }
+  if (tid == 0) __hip_atomic_store(d.splitk_tickets + tile_lin, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
+#undef acc
+  return true;
+}
+
 // Occupancy the register allocator must keep (waves per SIMD = workgroups per CU): what the LDS footprint allows for the
 // 128-pixel bf16 tiles (3 workgroups of 48 KB with 64 output channels, 4 of 30 KB with 32); the f32 parity mode is left alone.
 constexpr int conv_min_waves(int dt, int bm, int bn) { return dt != 1 || bm != 128 ? 1 : (bn == 64 ? 3 : 4); }
@@ -313,7 +360,7 @@ void conv_fwd_kernel(const ConvK P) {
     const T* sb = first ? src0 + c * 32 : src1 + (c - P.nchunks0) * 32;
 #pragma unroll
     for (int i = 0; i < NPP; ++i) {
-      const int off = first ? p_off0[i] : p_off1[i];
+      const int off = p_off1[i] ^ ((p_off0[i] ^ p_off1[i]) & -(int)first);     // (a select of two registers; hipcc turned `?:` into a scratch table)
       rp[i] = u32x4{0, 0, 0, 0};
       if (off >= 0 && !ABL(1)) rp[i] = *reinterpret_cast<const u32x4*>(sb + off);
     }
@@ -342,7 +389,10 @@ void conv_fwd_kernel(const ConvK P) {
     }
   };
 
-  prefetch(0);                                    // first: everything below runs in the shadow of this round trip
+  // split K (d.ksplit > 1): this workgroup walks chunks [c0, c1) of the tile; see splitk_combine
+  const int ksn = d.ksplit > 1 ? d.ksplit : 1, kz = d.ksplit > 1 ? (int)blockIdx.z : 0;
+  const int c0 = (int)((long)P.nchunks * kz / ksn), c1 = (int)((long)P.nchunks * (kz + 1) / ksn);
+  prefetch(c0);                                   // first: everything below runs in the shadow of this round trip
   bias_to_lds<BN>(bias_r, tid, sB);               // visible after the K loop's barriers
 
   // ---- per-lane operand addresses ----
@@ -403,7 +453,7 @@ void conv_fwd_kernel(const ConvK P) {
     }
   };
 
-  for (int c = 0; c + 1 < P.nchunks; ++c) {
+  for (int c = c0; c + 1 < c1; ++c) {
     __syncthreads();
     if (!ABL(16)) commit();
     __syncthreads();
@@ -419,6 +469,10 @@ void conv_fwd_kernel(const ConvK P) {
   EpiPre<T, FN / 2, FM> pre;
   epi_issue<T, TH, TW, BN, WM, FM, FN>(d, epi, b, oy0, ox0, wm, lr, pre);
   if (!ABL(4)) compute();
+  if (ksn > 1) {
+    int* s_flag = reinterpret_cast<int*>(sP);       // (the patch is dead: every wave is behind its last LDS read after the barrier inside)
+    if (!splitk_combine<FN, FM>(d, acc, (int)(blockIdx.x + gridDim.x * blockIdx.y), kz, tid, 256, s_flag)) return;
+  }
   epi_bias<BN, WN, FN / 2>(sB, wn, g, epi);
   if (ABL(8) && acc[0][0][0] != 12345.f) return;
   conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN, POOL>(d, acc, epi, pre, b, oy0, ox0, wm, lr);
@@ -511,7 +565,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_glds_kernel(const ConvK
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       if (i * NW + wave < PINST) {
-        const int off = first ? p_off0[i] : p_off1[i];
+        const int off = p_off1[i] ^ ((p_off0[i] ^ p_off1[i]) & -(int)first);   // (a select of two registers; hipcc turned `?:` into a scratch table)
         const void* gp = off >= 0 ? (const void*)(sb + off) : (const void*)g_zero16;
         glds16(gp, buf + (i * NW + wave) * 1024);
       }
@@ -545,22 +599,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_glds_kernel(const ConvK
 
   static_assert(NBUF == 1 || NBUF == 2, "single- or double-buffered");
   constexpr int PD = NBUF - 1;                             // chunks in flight ahead of the one being computed
+  // split K (d.ksplit > 1): this workgroup walks chunks [c0, c1) of the tile; see splitk_combine
+  const int ksn = d.ksplit > 1 ? d.ksplit : 1, kz = d.ksplit > 1 ? (int)blockIdx.z : 0;
+  const int c0 = (int)((long)P.nchunks * kz / ksn), c1 = (int)((long)P.nchunks * (kz + 1) / ksn);
   if (NBUF >= 2) {
 #pragma unroll
-    for (int i = 0; i < PD; ++i) if (i < P.nchunks) issue(i, smem + i * BUF);
+    for (int i = 0; i < PD; ++i) if (c0 + i < c1) issue(c0 + i, smem + i * BUF);
   }
   if (SBIAS && NBUF >= 2) bias_to_lds<BN>(bias_r, tid, sB);   // after the first fills were issued; visible after the K loop's barriers
   int slot = 0;                                            // c % NBUF
-  for (int c = 0; c < P.nchunks; ++c) {
+  for (int c = c0; c < c1; ++c) {
     char* cur = smem + (NBUF >= 2 ? slot * BUF : 0);
     if (NBUF == 1) {
-      if (c > 0) __syncthreads();                          // everyone finished reading the previous chunk
+      if (c > c0) __syncthreads();                         // everyone finished reading the previous chunk
       issue(c, smem);
-      if (SBIAS && c == 0) bias_to_lds<BN>(bias_r, tid, sB);
+      if (SBIAS && c == c0) bias_to_lds<BN>(bias_r, tid, sB);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of chunk c has landed
     __syncthreads();                                      // ... everyone's has, and nobody still reads the stage refilled next
-    if (NBUF >= 2 && c + PD < P.nchunks) {
+    if (NBUF >= 2 && c + PD < c1) {
       const int ns = slot == 0 ? NBUF - 1 : slot - 1;      // (c + PD) % NBUF == (c - 1) % NBUF
       issue(c + PD, smem + ns * BUF);
     }
@@ -585,6 +642,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_glds_kernel(const ConvK
         for (int fm = 0; fm < FM; ++fm) mma32(acc[fn][fm], fa[tap & 1][fn], fb[tap & 1][fm]);
     }
   }
+  if (ksn > 1) {
+    __syncthreads();                                 // every wave is behind its last LDS read: the first stage's bytes are free
+    int* s_flag = reinterpret_cast<int*>(smem);
+    if (!splitk_combine<FN, FM>(d, acc, (int)(blockIdx.x + gridDim.x * blockIdx.y), kz, tid, 64 * WM * WN, s_flag)) return;
+  }
   EpiCtx<FN / 2> epi;                              // all bias loads issued together (one latency), then the mask loads
   epi_setup<BN, WN, FN / 2>(d, n0, wn, g, epi, sB);
   if (SBIAS) epi_bias<BN, WN, FN / 2>(sB, wn, g, epi);
@@ -593,6 +655,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_glds_kernel(const ConvK
 
 thread_local char* g_name_out = nullptr;   // when set, launches are dry: only the kernel name is reported
 thread_local int g_name_cap = 0;
+struct TilePlan { int bm, bn; long wgs; };
+thread_local TilePlan* g_plan_out = nullptr;   // when set, launches are dry: the tile shape and grid are reported (split-K planning)
+
+// grid.z and argument checks of a split-K launch (seg_conv_desc.ksplit > 1)
+inline int splitk_grid(const ConvK& P, int* gz) {
+  *gz = 1;
+  if (P.d.ksplit <= 1) return SEG_OK;
+  if (!P.d.splitk_ws || !P.d.splitk_tickets) { seg_set_error("conv: ksplit %d without workspace / tickets", P.d.ksplit); return SEG_ERR_ARG; }
+  if (P.d.ksplit > P.nchunks || P.d.ksplit > 64) { seg_set_error("conv: ksplit %d exceeds the layer's %d K chunks", P.d.ksplit, P.nchunks); return SEG_ERR_ARG; }
+  *gz = P.d.ksplit;
+  return SEG_OK;
+}
 
 template <typename T, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, bool POOL = false>
 int launch_cfg(const ConvK& P0, hipStream_t st) {
@@ -609,6 +683,9 @@ int launch_cfg(const ConvK& P0, hipStream_t st) {
   P.tiles_x = cdiv(P.d.Wo, TW);
   P.tiles_y = cdiv(P.d.Ho, TH);
   if (P.d.n_count % BN != 0 || P.d.n_split % BN != 0) { seg_set_error("conv: n_count %d / n_split %d not a multiple of BN %d", P.d.n_count, P.d.n_split, BN); return SEG_ERR_ARG; }
+  if (g_plan_out) { g_plan_out->bm = TH * TW; g_plan_out->bn = BN; g_plan_out->wgs = (long)P.d.B * P.tiles_y * P.tiles_x * (P.d.n_count / BN); return SEG_OK; }
+  int gz;
+  if (int rc = splitk_grid(P, &gz)) return rc;
   auto kern = conv_fwd_kernel<Tr<T>::DT, TH, TW, BN, WM, WN, KH, KW, S, POOL>;
   static bool attr_done = false;
   if (!attr_done && LDS > 48 * 1024) {
@@ -617,7 +694,7 @@ int launch_cfg(const ConvK& P0, hipStream_t st) {
     }
     attr_done = true;
   }
-  dim3 grid(P.d.B * P.tiles_y * P.tiles_x, P.d.n_count / BN);
+  dim3 grid(P.d.B * P.tiles_y * P.tiles_x, P.d.n_count / BN, gz);
   SEG_LAUNCH(kern, grid, dim3(256), LDS, st, P);
   return seg_check_launch("conv_fwd");
 }
@@ -637,6 +714,9 @@ int launch_glds(const ConvK& P0, hipStream_t st) {
   P.tiles_x = cdiv(P.d.Wo, TW);
   P.tiles_y = cdiv(P.d.Ho, TH);
   if (P.d.n_count % BN != 0 || P.d.n_split % BN != 0) { seg_set_error("conv: n_count %d / n_split %d not a multiple of BN %d", P.d.n_count, P.d.n_split, BN); return SEG_ERR_ARG; }
+  if (g_plan_out) { g_plan_out->bm = TH * TW; g_plan_out->bn = BN; g_plan_out->wgs = (long)P.d.B * P.tiles_y * P.tiles_x * (P.d.n_count / BN); return SEG_OK; }
+  int gz;
+  if (int rc = splitk_grid(P, &gz)) return rc;
   auto kern = conv_fwd_glds_kernel<TH, TW, BN, WM, WN, KH, KW, S, NBUF>;
   static bool attr_done = false;
   if (!attr_done && LDS > 48 * 1024) {
@@ -645,7 +725,7 @@ int launch_glds(const ConvK& P0, hipStream_t st) {
     }
     attr_done = true;
   }
-  dim3 grid(P.d.B * P.tiles_y * P.tiles_x, P.d.n_count / BN);
+  dim3 grid(P.d.B * P.tiles_y * P.tiles_x, P.d.n_count / BN, gz);
   SEG_LAUNCH(kern, grid, dim3(64 * WM * WN), LDS, st, P);
   return seg_check_launch("conv_fwd_glds");
 }
@@ -747,6 +827,44 @@ extern "C" int seg_conv2d_kernel_name(const seg_conv_desc* dp, char* buf, int32_
   return rc;
 }
 
+extern "C" int seg_conv2d_splitk_plan(const seg_conv_desc* dp, int32_t* ksplit, int64_t* ws_bytes, int32_t* tickets) {
+  if (!dp || !ksplit || !ws_bytes || !tickets) { seg_set_error("splitk_plan: null argument"); return SEG_ERR_ARG; }
+  *ksplit = 1; *ws_bytes = 0; *tickets = 0;
+  if (dp->cfg >= 100) return SEG_OK;                 // an instance of the persistent kernel is forced: it has no K split
+  TilePlan tp = {0, 0, 0};
+  seg_conv_desc d = *dp;
+  d.ksplit = 0;
+  g_plan_out = &tp;
+  const int rc = seg_conv2d(&d, nullptr);
+  g_plan_out = nullptr;
+  if (rc != SEG_OK) return rc;
+  if (tp.wgs <= 0) return SEG_OK;                    // (a kernel without a tile plan: the persistent form)
+  const int nch = dp->src0.c / 32 + (dp->src1.ptr ? dp->src1.c / 32 : 0);
+  int ks = 1;
+  if (dp->ksplit > 0) {
+    ks = dp->ksplit < nch ? dp->ksplit : nch;
+  } else {
+    // SEG_CONV_SPLITK = n (>= 2) turns the automatic split on, capped at n parts: only where the grid leaves the chip short of
+    // workgroups AND the K loop is long enough to be worth sharing -- the deep, small-map layers (<= 640 workgroups, >= 8 chunks
+    // of 32 channels); each part keeps >= 4 chunks, about 1024 workgroups in all.  OFF by default: measured on the C2 layers
+    // (profiles/r03_split_k.txt) the exchange of the partials costs ~5 us per launch -- more than the shorter K walk saves on every
+    // layer but conv5_2 (15.4 -> 13.8 us) -- and the train step went from 0.963 to 1.067 ms with it.
+    static const int cap = getenv("SEG_CONV_SPLITK") ? atoi(getenv("SEG_CONV_SPLITK")) : 0;
+    if (cap > 1 && dp->dtype == SEG_BF16 && nch >= 8 && tp.wgs <= 640) {
+      ks = (int)(1024 / tp.wgs);
+      if (ks > nch / 4) ks = nch / 4;
+      if (ks > cap) ks = cap;
+      if (ks < 1) ks = 1;
+    }
+  }
+  if (ks > 1) {
+    *ksplit = ks;
+    *ws_bytes = (int64_t)tp.wgs * ks * tp.bm * tp.bn * 4;
+    *tickets = (int32_t)tp.wgs;
+  }
+  return SEG_OK;
+}
+
 extern "C" int seg_conv2d(const seg_conv_desc* dp, void* stream) {
   if (!dp) { seg_set_error("conv: null descriptor"); return SEG_ERR_ARG; }
   const seg_conv_desc& d = *dp;
@@ -786,7 +904,7 @@ extern "C" int seg_conv2d(const seg_conv_desc* dp, void* stream) {
   {
     // bf16 3x3 / stride 1 without the fused pool: the wave-specialised kernel (conv_sweep.hip) unless a tile of this file is forced
     int rc = SEG_OK;
-    if (seg_conv_sweep(d, g_name_out, g_name_cap, reinterpret_cast<hipStream_t>(stream), &rc)) return rc;
+    if (!g_plan_out && seg_conv_sweep(d, g_name_out, g_name_cap, reinterpret_cast<hipStream_t>(stream), &rc)) return rc;
   }
   ConvK P;
   P.d = d;

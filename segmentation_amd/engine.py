@@ -612,6 +612,26 @@ class Net(object):
         """bytes per activation element in HBM"""
         return 4 if self.dtype == L.SEG_F32 else 2
 
+    def _splitk(self, d, plan, ksplit=None):
+        """Asks the library whether this convolution launch should share its K loop among several workgroups per output tile
+        (seg_conv2d_splitk_plan: the deep, small-map layers) and gives the descriptor the workspace and tickets it then needs.
+        ksplit: None = automatic, 1 = off, n = ask for n parts (tests)."""
+        d.ksplit = 0 if ksplit is None else ksplit
+        d.splitk_ws = None; d.splitk_tickets = None
+        if ksplit == 1 or (ksplit is None and os.environ.get('SEG_CONV_SPLITK', '0') in ('', '0', '1')):
+            d.ksplit = 0                      # (off by default: measured slower, see seg_conv2d_splitk_plan)
+            return
+        ks, nbytes, nt = C.c_int32(0), C.c_int64(0), C.c_int32(0)
+        L.check(self.lib.seg_conv2d_splitk_plan(C.byref(d), C.byref(ks), C.byref(nbytes), C.byref(nt)), 'splitk_plan')
+        if ks.value <= 1:
+            d.ksplit = 0
+            return
+        ws = torch.empty(nbytes.value // 4, dtype=torch.float32, device=self.device)
+        tk = torch.zeros(nt.value, dtype=torch.int32, device=self.device)
+        d.ksplit = ks.value; d.splitk_ws = ws.data_ptr(); d.splitk_tickets = tk.data_ptr()
+        self.ws_bytes = getattr(self, 'ws_bytes', 0) + nbytes.value
+        plan.keep += [ws, tk]
+
     def sched_slot(self):
         """device address of a fresh pair of ticket words (None once the pool is used up: the kernel then splits statically)"""
         if os.environ.get('SEG_CONV_SCHED', '1') == '0' or 2 * self._sched_n + 2 > self._sched.numel():
@@ -651,7 +671,7 @@ class Net(object):
                  1 if layer.relu else 0, self.dtype, kernel=kern, flops=fl, bytes=by)
         return False
 
-    def conv_fwd(self, plan, layer, srcs, Hi, Wi, dst, dst_off=(0, 0), out_f32=False, cfg=0, pool=None):
+    def conv_fwd(self, plan, layer, srcs, Hi, Wi, dst, dst_off=(0, 0), out_f32=False, cfg=0, pool=None, ksplit=None):
         """srcs: list of (Act, oy, ox) (1 or 2 concat segments).  pool: Act of the 2x2 max-pool that consumes dst; when the
         layer's tile can carry it the pooled map is written by the same launch and `self.pool_fused` is set (else the
         caller emits pool_fwd)."""
@@ -682,6 +702,7 @@ class Net(object):
                 name += '+pool'
             else:
                 d.pool = L.null_view(); d.pool_h = d.pool_w = 0
+        self._splitk(d, plan, ksplit)
         plan.keep.append(d)
         fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
         # algorithmic HBM bytes: every tensor touched once (input window, output, filters; + the fused pooled map)
@@ -702,6 +723,7 @@ class Net(object):
         d.bias = self.store.p_ptr(layer.b_off); d.bias_n = layer.cout
         d.dst = dst.view(); d.up2 = 1; d.up_cout = layer.cout_p; d.mask = L.null_view()
         d.relu = 1 if layer.relu else 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
+        self._splitk(d, plan)
         plan.keep.append(d)
         fl = 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
         by = self.B * Hi * Wi * (layer.cin + 4 * layer.cout) * self.es + 4 * layer.cin * layer.cout * self.es
@@ -865,7 +887,7 @@ class Net(object):
         self._add_wgrad(plan, layer.name + '/dw', w, fl, sid='aux' if on_aux else (1 if (same_stream and col is not None) else None))
         plan.flops += fl
 
-    def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0, ksplit=0):
+    def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0, ksplit=0, dgrad_ksplit=None):
         """Filter + bias gradient, then one dgrad launch per entry of dsrcs.
         dsrcs: list aligned with srcs; each None (no input gradient wanted) or
         (dst_act, (oy,ox), mask_act_or_None, (moy,mox))."""
@@ -908,6 +930,7 @@ class Net(object):
             d.mask1 = mask1.view(moff1[0], moff1[1]) if mask1 is not None else L.null_view()
             d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
             d.sched = self.sched_slot()
+            self._splitk(d, plan, dgrad_ksplit)
             plan.keep.append(d)
             fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
             nmask = sum(layer.cin_segs[i] for i, m_ in enumerate((mask0, mask1)) if m_ is not None)
@@ -931,6 +954,7 @@ class Net(object):
                 d.mask = mask.view(moff[0], moff[1]) if mask is not None else L.null_view()
                 d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
                 d.sched = self.sched_slot()
+                self._splitk(d, plan, dgrad_ksplit)
                 plan.keep.append(d)
                 fl = 2 * self.B * Ho * Wo * k * k * layer.cin_segs[i] * layer.cout
                 by = (self.B * (Ho * Wo * layer.cout + Hi * Wi * layer.cin_segs[i] * (1 + (1 if mask is not None else 0) + (1 if d.accum else 0))) * self.es
@@ -966,6 +990,7 @@ class Net(object):
             d.dst = dsrc.view(); d.up2 = 0; d.up_cout = 0
             d.mask = mask.view() if mask is not None else L.null_view()
             d.relu = 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
+            self._splitk(d, plan)
             plan.keep.append(d)
             by = self.B * Hi * Wi * (4 * layer.cout + layer.cin * (2 if mask is not None else 1)) * self.es + 4 * layer.cin * layer.cout * self.es
             plan.add(layer.name + '/dx', self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl, bytes=by)

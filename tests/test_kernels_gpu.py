@@ -123,6 +123,74 @@ def test_conv_fwd_bwd(dtype, case):
         c0 += c
 
 
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('case', [
+    # k, padding, segs, cout, H, W, B, cfg, ksplit     split K (seg_conv_desc.ksplit): the deep small-map layers
+    (3, 'VALID', [256], 64, 10, 10, 3, 0, 2), (3, 'VALID', [256], 64, 10, 10, 3, 0, 4), (3, 'SAME', [128, 128], 96, 9, 13, 2, 0, 3),
+    (3, 'VALID', [512], 32, 8, 8, 2, 24, 4), (3, 'VALID', [256], 64, 12, 12, 2, 11, 2), (3, 'VALID', [256], 64, 12, 12, 2, 1, 8),
+    (1, 'SAME', [256], 64, 7, 9, 2, 0, 4), (3, 'VALID', [96], 32, 6, 6, 1, 4, 3),
+])
+def test_conv_split_k(dtype, case):
+    """ksplit workgroups share a tile's K chunks; the last arriver adds the f32 partials in split order and runs the epilogue:
+    forward (bias + ReLU) and data gradient (two-destination form with a ReLU-grad mask) against the oracle, bitwise reproducible
+    from run to run, tickets left zero."""
+    k, padding, segs, cout, H, W, B, cfg, ks = case
+    if cfg > 10 and dtype != L.SEG_BF16:
+        pytest.skip('direct-to-LDS variants are bf16 only')
+    rng = np.random.default_rng(k * 7 + sum(segs) + cout * 3 + H + ks)
+    layer = E.Layer('c', 'conv', k, segs, cout, padding, True)
+    p = {'c': _rand_params(layer, rng, dtype)}
+    p['c']['weights'] = U.round_dtype(p['c']['weights'], dtype).astype(np.float32)
+    store = U.make_store([layer], dtype, p)
+    net = E.Net(store, B, dtype, U.dev())
+    srcs, xs = [], []
+    for c in segs:
+        a = net.act(H, W, c)
+        full = U.round_dtype(rng.standard_normal((B, H, W, c)), dtype)
+        U.fill_act(a, full); srcs.append((a, 0, 0)); xs.append(full)
+    x = np.concatenate(xs, -1)
+    pad = layer.pad
+    Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
+    out = net.act(Ho, Wo, cout)
+    plan = E.Plan('t')
+    net.conv_fwd(plan, layer, srcs, H, W, out, cfg=cfg, ksplit=ks)
+    d = plan.meta[0]['desc']
+    assert d.ksplit == min(ks, sum(E.rup(c) for c in segs) // 32) and d.splitk_ws and d.splitk_tickets
+    tickets = [t for t in plan.keep if isinstance(t, torch.Tensor) and t.dtype == torch.int32][0]
+    plan.run(U.stream()); U.sync()
+    ref = ops.conv2d(x, p['c']['weights'], p['c']['biases'], padding, 1, True)
+    got = U.read_act(out)
+    assert U.rel_err(got, ref) < U.tol(dtype), 'fwd'
+    assert U.pad_channels_zero(out) and int(tickets.abs().sum().item()) == 0
+    first = out.t.clone()
+    for _ in range(3):
+        out.t.zero_()
+        plan.run(U.stream()); U.sync()
+        assert torch.equal(out.t, first), 'split-K sum must not depend on the arrival order'
+    # data gradient through the same kernels (K = cout chunks: only split when there are enough of them)
+    if E.rup(cout) // 32 >= 2:
+        dzv = U.round_dtype(rng.standard_normal((B, Ho, Wo, cout)) * 0.5, dtype)
+        dz = net.act(Ho, Wo, cout); U.fill_act(dz, dzv)
+        dspecs, dacts, masks = [], [], []
+        for c in segs:
+            da = net.act(H, W, c); mk = net.act(H, W, c)
+            mv = U.round_dtype(rng.standard_normal((B, H, W, c)), dtype)
+            U.fill_act(mk, mv); masks.append(mv); dacts.append(da)
+            dspecs.append((da, (0, 0), mk, (0, 0)))
+        bplan = E.Plan('b')
+        net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs, dgrad_ksplit=2)
+        net.flush_reduce(bplan)
+        dd = [m['desc'] for m in bplan.meta if isinstance(m.get('desc'), L.ConvDesc)]
+        assert dd and all(q.ksplit == 2 for q in dd)
+        bplan.run(U.stream()); U.sync()
+        dx_ref = ops.conv2d_dgrad(dzv, p['c']['weights'], (H, W), padding, 1)
+        c0 = 0
+        for i, c in enumerate(segs):
+            want = dx_ref[..., c0:c0 + c] * (masks[i] > 0)
+            assert U.rel_err(U.read_act(dacts[i]), want) < U.tol(dtype), 'dgrad seg %d' % i
+            c0 += c
+
+
 @pytest.mark.parametrize('case', [
     # k, padding, segs, cout, H, W, B, wcfg            filter-gradient layouts (bf16): 11/14 = 64 ci x 64 co, 12/15 = 32 ci x 64 co
     (3, 'VALID', [64], 64, 37, 35, 3, 11),
