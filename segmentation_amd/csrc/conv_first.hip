@@ -4,6 +4,8 @@
 // output anyway (25 FLOP/B), so it runs on the vector ALU: one thread per output pixel, 32 output
 // channels in registers, filters broadcast from LDS, 64-byte-per-lane coalesced stores.
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -271,6 +273,168 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const FirstK P) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Round 3: the same layer with a quarter of the vector instructions (counters on the kernel above: 10.0 M VALU
+// instructions per launch = 19 us of pure VALU issue at C2, the kernel was not HBM-bound but VALU-bound at 3 TB/s).
+//   * The tile's input patch is staged ONCE as bf16 RGB0 pixels (8 bytes each): an MFMA B fragment is then two 8-byte
+//     LDS reads instead of 8 float reads + 8 selects + 4 conversions.  K is laid out for that: k' = 32 s + 8 g + j with
+//     filter row ty = 2 s + (g >> 1), filter column tx = 2 (g & 1) + (j >> 2), channel j & 3 -- two 32-deep MFMA steps,
+//     the slots of the padding channel, of tx = 3 and of ty = 3 carry zero weights (the MFMAs are nowhere near a limit).
+//   * The bias is the MFMA's C operand, ReLU is one packed signed-integer max per two channels on the converted bf16 bits.
+//   * A wave owns 4 x 16 output pixels = 2 x 8 pool windows; MFMA block q holds window position q of all 16 windows, so a
+//     lane sees the four pixels of ITS window one after the other: the pool is three packed maxima (no cross-lane traffic)
+//     and the pooled row is stored by all 64 lanes (one 1 KB store per wave and tile; the DPP form stored with 16).
+// Same arithmetic as before (bf16 operands, f32 accumulation, one rounding), so parity bounds are unchanged.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int WPR = FTH + 3, WRS = 37;               // patch rows (+1: the ty = 3 slots read a row of zeros), row stride in pixels
+
+SEG_DEV unsigned pk_relu_bf16(unsigned a) {         // both halves: negative (sign bit set) -> +0
+  unsigned r;
+  asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(a));
+  return r;
+}
+
+template <int NG, bool RELU, bool POOL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG == 1 ? (RELU || !POOL ? 6 : 4) : 3, 8))) void conv_first_win_kernel(const FirstK P) {
+  __shared__ __attribute__((aligned(16))) uint32_t sp[WPR * WRS * 2];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, g = lane >> 4;
+  for (int i = tid; i < WPR * WRS * 2; i += 256) sp[i] = 0u;      // (borders / the extra row stay zero for the whole launch)
+
+  // filter fragments: MFMA m of channel group q, row i (= lane & 15) <-> channel 32 q + 8 (i >> 2) + 4 m + (i & 3)
+  Frag<bf16_t> fa[NG][2][2];
+  f32x4 bias4[NG][2];
+#pragma unroll
+  for (int q = 0; q < NG; ++q)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int ch = 32 * q + 8 * (p >> 2) + 4 * m + (p & 3);
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ty = 2 * s_ + (g >> 1), tx = 2 * (g & 1) + (j >> 2), c = j & 3;
+          const bool on = ty < 3 && tx < 3 && c < P.cin && ch < P.cout;
+          fa[q][m][s_].v[j] = (bf16_t)(on ? P.w[(int64_t)((ty * 3 + tx) * P.cin + c) * P.cout + ch] : 0.f);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cb = 32 * q + 8 * g + 4 * m + r;                 // D row 4 g + r of MFMA m <-> this channel
+        bias4[q][m][r] = (P.bias && cb < P.cout) ? P.bias[cb] : 0.f;
+      }
+    }
+  // everything above is loaded before the loop: make it land now (see the vmcnt note in the kernel above)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const int tiles_x = P.blocks_x, tiles_y = P.blocks_y;
+  const int per_img = tiles_x * tiles_y, total = P.B * per_img;
+  bf16_t* dstp = reinterpret_cast<bf16_t*>(P.dst.ptr);
+  bf16_t* poolp = POOL ? reinterpret_cast<bf16_t*>(P.pool.ptr) : nullptr;
+  // this lane's pool window inside the wave's 4 x 16 pixel region of the tile
+  const int r0 = 4 * (wave >> 1) + 2 * (p >> 3), c0 = 16 * (wave & 1) + 2 * (p & 7);
+  int baddr[2];                                                    // LDS byte address of the fragment of block 0, MFMA step s
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_) baddr[s_] = ((r0 + 2 * s_ + (g >> 1)) * WRS + c0 + 2 * (g & 1)) * 8;
+  const int dlane = (r0 * P.dst.W + c0) * P.dst.cs + 8 * g;
+  const int plane = ((r0 >> 1) * P.pool.W + (c0 >> 1)) * P.pool.cs + 8 * g;
+
+  constexpr int NPX = (FTH + 2) * (FTW + 2);                       // 340 staged pixels per tile
+  float pre[2][3];
+  auto patch_load = [&](int t) {
+    const int b = t / per_img; const int r = t - b * per_img;
+    const int ty = r / tiles_x, tx = r - ty * tiles_x;
+    const float* xb = P.x + (int64_t)b * P.H * P.W * P.cin;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int i = tid + n * 256;
+      const int py = i / (FTW + 2), px = i - py * (FTW + 2);
+      const int iy = ty * FTH - P.pad + py, ix = tx * FTW - P.pad + px;
+      const bool in = i < NPX && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+      const float* q = xb + ((int64_t)iy * P.W + ix) * P.cin;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pre[n][c] = (in && c < P.cin) ? q[c] : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < total) patch_load(blockIdx.x);
+  __syncthreads();                                                 // the zero fill is complete
+  for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    const int b = t / per_img; const int r = t - b * per_img;
+    const int ty = r / tiles_x, tx = r - ty * tiles_x;
+    const int oy0 = ty * FTH, ox0 = tx * FTW;
+    lds_barrier();                                                 // previous tile's reads are done
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int i = tid + n * 256;
+      if (i < NPX) {
+        const int py = i / (FTW + 2), px = i - py * (FTW + 2);
+        const bf16x4 v = bf16x4{(bf16_t)pre[n][0], (bf16_t)pre[n][1], (bf16_t)pre[n][2], (bf16_t)0.f};
+        *reinterpret_cast<u32x2*>(&sp[(py * WRS + px) * 2]) = __builtin_bit_cast(u32x2, v);
+      }
+    }
+    lds_barrier();
+    if (t + (int)gridDim.x < total) patch_load(t + gridDim.x);     // in flight behind this tile's arithmetic and in front of its stores
+    const int64_t dtile = view_off(P.dst, b, oy0, ox0);
+    const int64_t ptile = POOL ? view_off(P.pool, b, oy0 >> 1, ox0 >> 1) : 0;
+    const char* spb = reinterpret_cast<const char*>(sp);
+    u32x4 pm[NG];                                                   // running packed maximum (ReLU layers) ...
+    float pf[NG][8];                                                // ... or float maximum (no ReLU: bf16 bits do not order as integers)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int dy = q4 >> 1, dx = q4 & 1;
+      const int oy = oy0 + r0 + dy, ox = ox0 + c0 + dx;
+      const bool ok = oy < P.Ho && ox < P.Wo;
+      Frag<bf16_t> fb[2];
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const u32x2* src = reinterpret_cast<const u32x2*>(spb + baddr[s_] + (dy * WRS + dx) * 8);
+        const u32x2 lo = src[0], hi = src[1];
+        fb[s_].v = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+      }
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        f32x4 a0 = bias4[q][0], a1 = bias4[q][1];
+        mma32(a0, fa[q][0][0], fb[0]); mma32(a1, fa[q][1][0], fb[0]);
+        mma32(a0, fa[q][0][1], fb[1]); mma32(a1, fa[q][1][1], fb[1]);
+        const bf16x8 ob = bf16x8{(bf16_t)a0[0], (bf16_t)a0[1], (bf16_t)a0[2], (bf16_t)a0[3], (bf16_t)a1[0], (bf16_t)a1[1], (bf16_t)a1[2], (bf16_t)a1[3]};
+        u32x4 o = __builtin_bit_cast(u32x4, ob);
+        if (RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = pk_relu_bf16(o[e]);
+        }
+        if (ok) *reinterpret_cast<u32x4*>(dstp + dtile + dlane + (dy * P.dst.W + dx) * P.dst.cs + 32 * q) = o;
+        if (POOL) {
+          if (RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pm[q][e] = q4 == 0 ? o[e] : pk_max_u16(pm[q][e], o[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              pf[q][e] = q4 == 0 ? a0[e] : fmaxf(pf[q][e], a0[e]);
+              pf[q][4 + e] = q4 == 0 ? a1[e] : fmaxf(pf[q][4 + e], a1[e]);
+            }
+          }
+        }
+      }
+    }
+    if (POOL) {
+      const int py_ = (oy0 + r0) >> 1, px_ = (ox0 + c0) >> 1;
+      if (py_ < P.Hp && px_ < P.Wp) {
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+          u32x4 o = pm[q];
+          if (!RELU) {
+            const bf16x8 ob = bf16x8{(bf16_t)pf[q][0], (bf16_t)pf[q][1], (bf16_t)pf[q][2], (bf16_t)pf[q][3], (bf16_t)pf[q][4], (bf16_t)pf[q][5], (bf16_t)pf[q][6], (bf16_t)pf[q][7]};
+            o = __builtin_bit_cast(u32x4, ob);
+          }
+          *reinterpret_cast<u32x4*>(poolp + ptile + plane + 32 * q) = o;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 static int launch_first_mfma(const FirstK& P0, hipStream_t st) {
@@ -279,6 +443,26 @@ static int launch_first_mfma(const FirstK& P0, hipStream_t st) {
   const int64_t total = (int64_t)P.B * P.blocks_x * P.blocks_y;
   int grid = (int)total; if (grid > 256 * 6) grid = 256 * 6;      // persistent: 6 workgroups per CU
   const int ng = P.im2col ? 1 : cdiv(P.cout, 32);
+  const bool old_form = getenv("SEG_FIRST_IMPL") && !strcmp(getenv("SEG_FIRST_IMPL"), "old");      // (read per launch: tests flip it)
+  // The bf16-staged window form (round 3) for outputs that the 256 MB Infinity Cache absorbs: 23.0 against 31.1 us at C2 (16 x
+  // 254^2 x 32: 83 MB written, 4.1 TB/s).  Its full-resolution stores are 64-byte halves of a line per instruction (a lane's
+  // pixels are two apart) and once the writes really reach HBM -- 512^2 x 16: 332 MB -- it is the slower one (126-134 against
+  // 117 us), so the big maps and the im2col mode keep the kernel below (SEG_FIRST_IMPL=old / win forces either).
+  const bool win_form = getenv("SEG_FIRST_IMPL") && !strcmp(getenv("SEG_FIRST_IMPL"), "win");
+  const double out_mb = (double)P.B * P.Ho * P.Wo * (ng * 32) * 2 * (P.pool.ptr ? 1.25 : 1.0) / 1e6;
+  if (!P.im2col && !old_form && P.cin <= 3 && ng <= 2 && (win_form || out_mb <= 192.0)) {
+    static const int per_cu_env = getenv("SEG_FIRST_WGS_PER_CU") ? atoi(getenv("SEG_FIRST_WGS_PER_CU")) : 0;
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (ng == 1 ? 6 : 3);
+    int g2 = (int)total; if (g2 > 256 * per_cu) g2 = 256 * per_cu;      // persistent: what the register budget keeps resident
+    const int key = (ng - 1) * 4 + (P.relu ? 2 : 0) + (P.pool.ptr ? 1 : 0);
+    switch (key) {
+#define FW_CASE(K, NG_, R_, P_) case K: SEG_LAUNCH((conv_first_win_kernel<NG_, R_, P_>), dim3(g2), dim3(256), 0, st, P); break
+      FW_CASE(0, 1, false, false); FW_CASE(1, 1, false, true); FW_CASE(2, 1, true, false); FW_CASE(3, 1, true, true);
+      FW_CASE(4, 2, false, false); FW_CASE(5, 2, false, true); FW_CASE(6, 2, true, false); FW_CASE(7, 2, true, true);
+#undef FW_CASE
+    }
+    return seg_check_launch("conv_first_win");
+  }
   switch (ng) {
     case 1: SEG_LAUNCH(conv_first_mfma_kernel<1>, dim3(grid), dim3(256), 0, st, P); break;
     case 2: SEG_LAUNCH(conv_first_mfma_kernel<2>, dim3(grid), dim3(256), 0, st, P); break;
