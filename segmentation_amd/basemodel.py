@@ -105,8 +105,8 @@ class BaseModel(object):
         if wgrad_streams > 0 and os.environ.get('SEG_WGRAD_STREAMS'):
             wgrad_streams = max(1, int(os.environ['SEG_WGRAD_STREAMS']))
         self._side = [torch.cuda.Stream(self.device) for _ in range(wgrad_streams + 1)] if wgrad_streams > 0 else None
-        share = os.environ.get('SEG_SHARE_AUX', '1' if self.SHARE_AUX_STREAM else '0') == '1'
-        if self._side is not None and not self.pg.enabled and share:
+        share = os.environ.get('SEG_SHARE_AUX', '1' if (self.SHARE_AUX_STREAM and not self.pg.enabled) else '0') == '1'
+        if self._side is not None and share:
             # the auxiliary launches (step_begin, the weight re-pack beside the first layer) go onto a filter-gradient
             # stream, idle at that time: main + two side streams instead of four streams is 2.7 % faster at C2 (1.010 -> 0.983 ms
             # on one box, 512^2 unchanged; three filter-gradient streams gain nothing more -- profiles/r03_step_structure_ab.txt).

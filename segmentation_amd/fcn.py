@@ -168,7 +168,7 @@ class FCNModel(BaseModel):
         B, (H, W) = self.batch_size, self.input_dims
         net = self.net = E.Net(self.store, B, self.dtype, self.device)
         net.n_wgrad_streams = max(1, len(self._side) - 1) if self._side else 1
-        net.input_pixels = B * H * W
+        net.input_pixels = B * H * W if not self.pg.enabled else None      # (data parallel keeps the lone-launch filter-gradient target: 1.05 against 1.09 ms at world 1)
         net.tail_layers = ('conv2',)      # last tiled filter gradient of the backward pass: aims for the whole chip (see unet.py); +2 % at C3
         Ly, nc = self.store.layers, self.n_classes
         fwd = self.fwd_plan = E.Plan('fwd')
