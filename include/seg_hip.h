@@ -188,7 +188,8 @@ int seg_im2col(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, int
  * is the same memory, and that one is a 1x1 convolution over the strided im2col of its input.
  * seg_im2col_act: dst[b,oy,ox,(u*KW+v)*C + c] = src[b, oy*s - pad_t + u, ox*s - pad_l + v, c] (zero outside, zero-filled up to
  * dst->c, a multiple of 32).  seg_col2im: the adjoint gather, dst[b,Y,X,c] = relu?(bias[c] + sum of col[b,(Y+pad_t-u)/s,
- * (X+pad_l-v)/s,(u*KW+v)*C + c] over the taps that divide) -- C a multiple of 8. */
+ * (X+pad_l-v)/s,(u*KW+v)*C + c] over the taps that divide).  Any C (a multiple of 8 takes the 16-byte path).  The same pair runs
+ * the adversary's 3x3/s2 convolutions (models/basemodel.py:228-246) as 1x1 convolutions over an im2col: engine.Net.sconv_*. */
 int seg_im2col_act(const seg_view* src, int32_t B, int32_t Hs, int32_t Ws, int32_t C, int32_t KH, int32_t KW, int32_t stride,
                    int32_t pad_t, int32_t pad_l, const seg_view* dst, int32_t Ho, int32_t Wo, int32_t dtype, void* stream);
 int seg_col2im(const seg_view* col, int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t KH, int32_t KW, int32_t stride,

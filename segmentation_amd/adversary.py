@@ -12,6 +12,7 @@ whose statistics are per pass (two calls of the network in the reference), run p
 against the label "real", for the segmentation network -- is a data-gradient-only pass over the fake half.
 """
 import ctypes as C
+import os
 import numpy as np
 import torch
 from . import _lib as L
@@ -53,10 +54,14 @@ class Adversary(object):
         ph, pw = self.sz['pool2']
         self.F = F = ph * pw * 2 * nk
         mk = E.Layer
+        # the two 3x3/s2 convolutions run on the MFMA kernels as 1x1 convolutions over a strided im2col (engine.Net.sconv_*; the
+        # direct VALU kernels took 0.84 of the 2.82 ms adversarial FCN-8s step); SEG_ADV_SCONV=0 keeps the direct kernels
+        self.sconv = os.environ.get('SEG_ADV_SCONV', '1') != '0'
+        conv = (lambda n, ci, co: E.Net.sconv_layer(n, 3, ci, co, 2)) if self.sconv else (lambda n, ci, co: mk(n, 'direct', 3, [ci], co, 'VALID', True, stride=2))
         self.layers = Ly = {
-            'adv_conv1': mk('adv_conv1', 'direct', 3, [n_classes], nk, 'VALID', True, stride=2),
+            'adv_conv1': conv('adv_conv1', n_classes, nk),
             'adv_bn1': mk('adv_bn1', 'bn', 1, [nk], nk),
-            'adv_conv2': mk('adv_conv2', 'direct', 3, [nk], 2 * nk, 'VALID', True, stride=2),
+            'adv_conv2': conv('adv_conv2', nk, 2 * nk),
             'adv_bn2': mk('adv_bn2', 'bn', 1, [2 * nk], 2 * nk),
             'adv_bn3': mk('adv_bn3', 'bn', 1, [F], F),
             'adv_fc1': mk('adv_fc1', 'direct', 1, [F], 1024, 'VALID', True),
@@ -80,8 +85,9 @@ class Adversary(object):
             if l.kind == 'bn':
                 p[n] = {'beta': np.zeros(l.wshape, np.float32)}
             else:
-                k2 = l.k * l.k
-                lim = np.sqrt(6.0 / (k2 * l.cin + k2 * l.cout))
+                sc = getattr(l, 'sconv', None)
+                k2, cin = (sc[0] * sc[0], sc[2]) if sc else (l.k * l.k, l.cin)
+                lim = np.sqrt(6.0 / (k2 * cin + k2 * l.cout))
                 p[n] = {'weights': rng.uniform(-lim, lim, l.wshape).astype(np.float32), 'biases': np.zeros((l.cout,), np.float32)}
         self.store.set_params(p)
 
@@ -154,6 +160,8 @@ class Adversary(object):
         A = self.A = {}
         A['x'] = n2.act(self.h, self.w, self.nc, name='adv_in')
         A['r'] = n2.act(*sz['resize'], self.nc, name='adv_resize')
+        if self.sconv:                  # im2col of each convolution's input (kept for its filter gradient); G[...] = its gradient
+            A['c1'] = n2.act(*sz['conv1'], 9 * self.nc, name='adv_col1'); A['c2'] = n2.act(*sz['conv2'], 9 * nk, name='adv_col2')
         A['a1'] = n2.act(*sz['conv1'], nk, name='adv_conv1'); A['y1'] = n2.act(*sz['conv1'], nk, name='adv_bn1')
         A['p1'] = n2.act(*sz['pool1'], nk, name='adv_pool1')
         A['a2'] = n2.act(*sz['conv2'], 2 * nk, name='adv_conv2'); A['y2'] = n2.act(*sz['conv2'], 2 * nk, name='adv_bn2')
@@ -220,11 +228,18 @@ class Adversary(object):
         plan.add('adv_softmax', self.lib.seg_softmax_probs, C.byref(lv), B, h, w, self.nc, C.byref(fv), self.dtype, kernel='softmax_probs_kernel')
         # forward, 2B images at once; batch norms per half (real first: the order the moving averages see, basemodel.py:283-285)
         n2.resize_fwd(plan, A['x'], A['r'])
-        n2.dlayer_fwd(plan, Ly['adv_conv1'], A['r'], A['a1'])
+        if self.sconv:
+            n2.pack(plan)                # the MFMA-operand copies of the two filters (a few KB; whoever changed them last, they are current)
+            n2.sconv_fwd(plan, Ly['adv_conv1'], A['r'], A['a1'], A['c1'])
+        else:
+            n2.dlayer_fwd(plan, Ly['adv_conv1'], A['r'], A['a1'])
         for hf in (0, 1):
             n1.bn_fwd(plan, Ly['adv_bn1'], self.bn['adv_bn1']['half'][hf], H2[hf]['a1'], H2[hf]['y1'])
         n2.pool_k_fwd(plan, A['y1'], A['p1'], 2)
-        n2.dlayer_fwd(plan, Ly['adv_conv2'], A['p1'], A['a2'])
+        if self.sconv:
+            n2.sconv_fwd(plan, Ly['adv_conv2'], A['p1'], A['a2'], A['c2'])
+        else:
+            n2.dlayer_fwd(plan, Ly['adv_conv2'], A['p1'], A['a2'])
         for hf in (0, 1):
             n1.bn_fwd(plan, Ly['adv_bn2'], self.bn['adv_bn2']['half'][hf], H2[hf]['a2'], H2[hf]['y2'])
         n2.pool_k_fwd(plan, A['y2'], A['p2'], 2)
@@ -263,11 +278,17 @@ class Adversary(object):
         net.pool_k_bwd(plan, A['y2'], G['p2'], G['y2'], 2)
         for i, hf in enumerate(halves):
             n1.bn_relu_bwd(plan, Ly['adv_bn2'], self.bn['adv_bn2']['half'][hf], H2[hf]['a2'], GH[hf]['y2'], GH[hf]['a2'], dbeta_ptr=sc, dbeta_add=i > 0)
-        net.dlayer_bwd(plan, Ly['adv_conv2'], A['p1'], G['a2'], dsrc=G['p1'], wgrad=weights)
+        if self.sconv:
+            net.sconv_bwd(plan, Ly['adv_conv2'], A['c2'], G['a2'], dcol=G['c2'], dsrc=G['p1'], wgrad=weights)
+        else:
+            net.dlayer_bwd(plan, Ly['adv_conv2'], A['p1'], G['a2'], dsrc=G['p1'], wgrad=weights)
         net.pool_k_bwd(plan, A['y1'], G['p1'], G['y1'], 2)
         for i, hf in enumerate(halves):
             n1.bn_relu_bwd(plan, Ly['adv_bn1'], self.bn['adv_bn1']['half'][hf], H2[hf]['a1'], GH[hf]['y1'], GH[hf]['a1'], dbeta_ptr=sc, dbeta_add=i > 0)
-        net.dlayer_bwd(plan, Ly['adv_conv1'], A['r'], G['a1'], dsrc=None if weights else G['r'], wgrad=weights)
+        if self.sconv:
+            net.sconv_bwd(plan, Ly['adv_conv1'], A['c1'], G['a1'], dcol=G['c1'], dsrc=None if weights else G['r'], wgrad=weights)
+        else:
+            net.dlayer_bwd(plan, Ly['adv_conv1'], A['r'], G['a1'], dsrc=None if weights else G['r'], wgrad=weights)
 
     def emit_update(self, plan):
         """advAdam: the adversary's own Adam at adversarial_lr (basemodel.py:325-328,343), same step count as the model's"""

@@ -104,7 +104,8 @@ class BaseModel(object):
         # side streams: wgrad_streams for the filter gradients + one auxiliary (weight re-pack)
         if wgrad_streams > 0 and os.environ.get('SEG_WGRAD_STREAMS'):
             wgrad_streams = max(1, int(os.environ['SEG_WGRAD_STREAMS']))
-        self._side = [torch.cuda.Stream(self.device) for _ in range(wgrad_streams + 1)] if wgrad_streams > 0 else None
+        sp_ = int(os.environ.get('SEG_SIDE_PRIO', '0'))      # (experiment: stream priority of the side streams; 0 = normal)
+        self._side = [torch.cuda.Stream(self.device, priority=sp_) for _ in range(wgrad_streams + 1)] if wgrad_streams > 0 else None
         share = os.environ.get('SEG_SHARE_AUX', '1' if (self.SHARE_AUX_STREAM and not self.pg.enabled) else '0') == '1'
         if self._side is not None and share:
             # the auxiliary launches (step_begin, the weight re-pack beside the first layer) go onto a filter-gradient

@@ -909,7 +909,7 @@ extern "C" int seg_im2col_act(const seg_view* src, int32_t B, int32_t Hs, int32_
 }
 
 // out[b,Y,X,c] = relu?( bias[c] + sum over taps (u,v) with (Y + pad_t - u) % s == 0, (X + pad_l - v) % s == 0 of
-//                col[b, (Y + pad_t - u)/s, (X + pad_l - v)/s, (u*KW + v)*C + c] ),   C % 8 == 0, c < C (channels beyond: zero)
+//                col[b, (Y + pad_t - u)/s, (X + pad_l - v)/s, (u*KW + v)*C + c] ),   c < C (channels beyond: zero); C % 8 == 0 takes 16-byte loads
 template <typename T>
 __global__ void col2im_kernel(seg_view col, int B, int Hi, int Wi, int C_, int KH, int KW, int stride, int pad_t, int pad_l, const float* bias,
                               int relu, seg_view dst, int Ho, int Wo) {
@@ -924,20 +924,27 @@ __global__ void col2im_kernel(seg_view col, int B, int Hi, int Wi, int C_, int K
 #pragma unroll
     for (int e = 0; e < 8; ++e) a[e] = 0.f;
     if (c8 * 8 < C_) {
+      const int ne = C_ - c8 * 8 < 8 ? C_ - c8 * 8 : 8;           // live channels of this piece (the last piece of a ragged C)
       for (int u = (Y + pad_t) % stride; u < KH; u += stride) {
         const int iy = (Y + pad_t - u) / stride;
         if (Y + pad_t - u < 0 || iy >= Hi) continue;
         for (int v = (X + pad_l) % stride; v < KW; v += stride) {
           const int ix = (X + pad_l - v) / stride;
           if (X + pad_l - v < 0 || ix >= Wi) continue;
-          Vec8<T> s; s.load(reinterpret_cast<const T*>(col.ptr) + view_off(col, b, iy, ix) + (u * KW + v) * C_ + c8 * 8);
+          const T* sp = reinterpret_cast<const T*>(col.ptr) + view_off(col, b, iy, ix) + (u * KW + v) * C_ + c8 * 8;
+          if ((C_ & 7) == 0) {
+            Vec8<T> s; s.load(sp);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) a[e] += s.get(e);
+            for (int e = 0; e < 8; ++e) a[e] += s.get(e);
+          } else {                                                  // (a tap's channels are not 16-byte aligned: element loads)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < ne) a[e] += (float)sp[e];
+          }
         }
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        if (bias) a[e] += bias[c8 * 8 + e];
+        if (bias && e < ne) a[e] += bias[c8 * 8 + e];
         if (relu) a[e] = fmaxf(a[e], 0.f);
       }
     }
@@ -951,8 +958,8 @@ __global__ void col2im_kernel(seg_view col, int B, int Hi, int Wi, int C_, int K
 extern "C" int seg_col2im(const seg_view* col, int32_t B, int32_t Hi, int32_t Wi, int32_t C_, int32_t KH, int32_t KW, int32_t stride,
                           int32_t pad_t, int32_t pad_l, const float* bias, int32_t relu, const seg_view* dst, int32_t Ho, int32_t Wo,
                           int32_t dtype, void* stream) {
-  if (!col || !dst || C_ < 8 || C_ % 8 || KH < 1 || KW < 1 || stride < 1 || pad_t < 0 || pad_l < 0 || B <= 0 || !view_ok(*col, Hi, Wi, col->c) || KH * KW * C_ > col->c ||
-      !view_ok(*dst, Ho, Wo, dst->c) || C_ > dst->c) { seg_set_error("col2im: bad args (channel count a multiple of 8)"); return SEG_ERR_ARG; }
+  if (!col || !dst || C_ < 1 || KH < 1 || KW < 1 || stride < 1 || pad_t < 0 || pad_l < 0 || B <= 0 || !view_ok(*col, Hi, Wi, col->c) || KH * KW * C_ > col->c ||
+      !view_ok(*dst, Ho, Wo, dst->c) || C_ > dst->c) { seg_set_error("col2im: bad args"); return SEG_ERR_ARG; }
   const int64_t n = (int64_t)B * Ho * Wo * (dst->c / 8);
   if (dtype == SEG_F32) SEG_LAUNCH(col2im_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, *col, B, Hi, Wi, C_, KH, KW, stride, pad_t, pad_l, bias, relu, *dst, Ho, Wo);
   else if (dtype == SEG_BF16) SEG_LAUNCH(col2im_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, *col, B, Hi, Wi, C_, KH, KW, stride, pad_t, pad_l, bias, relu, *dst, Ho, Wo);

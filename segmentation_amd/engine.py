@@ -770,7 +770,7 @@ class Net(object):
         load[k] += cost_us
         return 1 + k
 
-    def _add_wgrad(self, plan, name, w, fl, sid=None):
+    def _add_wgrad(self, plan, name, w, fl, sid=None, own_reduce=False):
         """One plan op for the partial-sum kernel and, when K is split, a second one for the slab reduction (same side
         stream): two C-ABI calls so that each kernel is timed on its own."""
         if sid is None:
@@ -786,6 +786,10 @@ class Net(object):
             w2.phase = 2
             plan.keep.append(w2)
             plan.add(name, self.lib.seg_conv2d_wgrad, C.byref(w), desc=w, flops=fl, side=sid, bytes=getattr(self, '_wg_bytes', 0))
+            if own_reduce:
+                # a plan nobody flushes (the adversary's): the reduction right behind the partial sums, whatever flavour the step runs
+                plan.add(name + '/reduce', self.lib.seg_conv2d_wgrad, C.byref(w2), kernel='wgrad_reduce_kernel', side=sid)
+                return
             if self.batch_reduce is not True:
                 plan.add(name + '/reduce', self.lib.seg_conv2d_wgrad, C.byref(w2), kernel='wgrad_reduce_kernel', side=sid, flavor='per_layer')
             if self.batch_reduce is not False:
@@ -1169,6 +1173,63 @@ class Net(object):
             plan.keep += [d, dv]
             plan.add(layer.name + '/dx', self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl,
                      bytes=self.B * Hi * Wi * (layer.cout + k * k * co) * self.es + k * k * co * layer.cout * self.es)
+            plan.flops += fl
+
+    # ---- k x k / stride-s VALID convolutions on the MFMA kernels: a 1x1 convolution over the strided im2col (Layer.sconv) ----
+    @staticmethod
+    def sconv_layer(name, k, cin, cout, stride, relu=True):
+        """The layer object of a VALID k x k / stride-s convolution [k,k,Cin,Cout] run as a 1x1 convolution over its im2col: a
+        'conv' layer with K = k*k*Cin inputs over the same parameter memory (HWIO kept for get/set_params and snapshots).  The
+        adversary's two 3x3/s2 convolutions (models/basemodel.py:228-246); the direct VALU kernels ran them at 8 TFLOP/s."""
+        l = Layer(name, 'conv', 1, [k * k * cin], cout, 'VALID', relu)
+        l.wshape = (k, k, cin, cout)
+        l.sconv = (k, stride, cin)
+        return l
+
+    def sconv_fwd(self, plan, layer, src, dst, col):
+        """dst = relu?(bias + conv(src)); col ([B, Ho, Wo, k*k*Cin], kept for the filter gradient) is written first"""
+        k, s_, ci = layer.sconv
+        sv, cv, dv = src.view(), col.view(), dst.view()
+        plan.keep += [sv, cv, dv]
+        plan.add(layer.name + '/im2col', self.lib.seg_im2col_act, C.byref(sv), self.B, src.H, src.W, ci, k, k, s_, 0, 0, C.byref(cv), dst.H, dst.W,
+                 self.dtype, kernel='im2col_act_kernel')
+        d = self._conv1x1_desc(layer, cv, dv, dst.H, dst.W, dgrad=False)
+        d.bias = self.store.p_ptr(layer.b_off); d.bias_n = layer.cout; d.relu = 1 if layer.relu else 0
+        plan.keep.append(d)
+        fl = 2 * self.B * dst.H * dst.W * k * k * ci * layer.cout
+        plan.add(layer.name, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl,
+                 bytes=self.B * dst.H * dst.W * (k * k * ci + layer.cout) * self.es + k * k * ci * layer.cout * self.es)
+        plan.flops += fl
+
+    def sconv_bwd(self, plan, layer, col, dz, dcol=None, dsrc=None, wgrad=True):
+        """filter + bias gradient from (col, dz) and -- dsrc given -- the input gradient: 1x1 data gradient into dcol, then the
+        adjoint gather of the im2col (seg_col2im)"""
+        k, s_, ci = layer.sconv
+        Ho, Wo = dz.H, dz.W
+        cv, zv = col.view(), dz.view()
+        plan.keep += [cv, zv]
+        fl = 2 * self.B * Ho * Wo * k * k * ci * layer.cout
+        if wgrad:
+            w = L.WgradDesc()
+            w.src0 = cv; w.src1 = L.null_view(); w.src0_clog = k * k * ci; w.src1_clog = 0
+            w.B, w.Hi, w.Wi = self.B, Ho, Wo
+            w.KH = w.KW = 1; w.stride = 1; w.pad_t = w.pad_l = 0
+            w.Ho, w.Wo = Ho, Wo
+            w.dz = zv; w.n_log = layer.cout
+            w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = 0
+            w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
+            self._wgrad_ws(w, plan)
+            self._wg_bytes = self.B * Ho * Wo * (k * k * ci + layer.cout) * self.es + k * k * ci * layer.cout * 4
+            self._add_wgrad(plan, layer.name + '/dw', w, fl, sid=0, own_reduce=True)      # (the adversary's plan: one stream, never flushed)
+            plan.flops += fl
+        if dsrc is not None:
+            gv, xv = dcol.view(), dsrc.view()
+            d = self._conv1x1_desc(layer, zv, gv, Ho, Wo, dgrad=True)
+            plan.keep += [d, gv, xv]
+            plan.add(layer.name + '/dx', self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl,
+                     bytes=self.B * Ho * Wo * (k * k * ci + layer.cout) * self.es + k * k * ci * layer.cout * self.es)
+            plan.add(layer.name + '/col2im', self.lib.seg_col2im, C.byref(gv), self.B, Ho, Wo, ci, k, k, s_, 0, 0, None, 0, C.byref(xv), dsrc.H, dsrc.W,
+                     self.dtype, kernel='col2im_kernel')
             plan.flops += fl
 
     def dlayer_fwd(self, plan, layer, src, dst):
