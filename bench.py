@@ -448,6 +448,13 @@ def main():
         elif args.mode == 'mc' and args.model == 'unet' and (args.size, args.batch, args.classes) == (256, 32, 4):
             tag = 'c5'
         out['roofline'] = roofline_report(agg, ops, reps, args.dtype, dt / args.steps * 1e3, pmc_tag=tag)
+        if training and 'wgrad' in out['roofline']['kernel']:
+            # the filter gradients deliberately run on a SHARE of the chip (they overlap the critical stream's kernels): `frac` above is
+            # against the whole chip's peak, this is against the CUs a launch may hold (one workgroup per CU, 153 KB of LDS each)
+            from segmentation_amd import engine as _E
+            tw = _E._step_wgrad_wgs(getattr(model.net, 'input_pixels', None)) or 128
+            out['roofline']['launch_workgroup_target'] = tw
+            out['roofline']['frac_of_cus_held'] = round(out['roofline']['frac'] * 256.0 / tw, 4)
         if args.per_op:
             for op, kern, ms_, fl, by in ops:
                 sys.stderr.write('%-16s %-52s %9.2f us %8.1f TF/s %8.1f GB/s\n' % (op, kern, ms_ * 1e3, fl / (ms_ * 1e-3) / 1e12 if fl else 0, by / (ms_ * 1e-3) / 1e9 if by else 0))

@@ -383,20 +383,21 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(seg_view a, seg_view dy
 template <int MODE>
 __global__ void bn_final_kernel(const float* ws, int nb, int C, int c_log, double inv_n, float eps, float decay, int training,
                                 float* moving, float* stats, float* out2, float* dbeta, int dbeta_add) {
-  // 32 channels x 8 slices per workgroup: a thread sums every 8th partial row, the slices meet in LDS in a fixed order (one
-  // thread per channel walking all nb rows was 60 us of pure load latency per batch norm)
-  __shared__ double r1[8][32], r2[8][32];
-  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  // 8 channels x 32 slices per workgroup: a thread sums every 32nd partial row, the slices meet in LDS in a fixed order (one
+  // thread per channel walking all nb rows was 60 us of pure load latency per batch norm; 32 channels x 8 slices still 15 us --
+  // a 32-channel layer was ONE workgroup with 128 dependent loads per thread)
+  __shared__ double r1[32][8], r2[32][8];
+  const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int b = sl; b < nb; b += 8) { s1 += (double)ws[((int64_t)b * C + c) * 2]; s2 += (double)ws[((int64_t)b * C + c) * 2 + 1]; }
+    for (int b = sl; b < nb; b += 32) { s1 += (double)ws[((int64_t)b * C + c) * 2]; s2 += (double)ws[((int64_t)b * C + c) * 2 + 1]; }
   r1[sl][cl] = s1; r2[sl][cl] = s2;
   __syncthreads();
   if (sl != 0 || c >= C) return;
   s1 = 0.0; s2 = 0.0;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { s1 += r1[q][cl]; s2 += r2[q][cl]; }
+  for (int q = 0; q < 32; ++q) { s1 += r1[q][cl]; s2 += r2[q][cl]; }
   if (MODE == 0) {
     float mean, var;
     if (training) {
@@ -804,7 +805,7 @@ extern "C" int seg_bn_fwd(const seg_view* a, const seg_view* y, const float* bet
     else SEG_LAUNCH((bn_partial_kernel<bf16_t, 0>), dim3(nb), dim3(256), 0, st, *a, none, (const float*)nullptr, B, H, W, C, ws);
     if (int rc = seg_check_launch("bn_partial")) return rc;
   }
-  SEG_LAUNCH(bn_final_kernel<0>, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)ws, training ? nb : 0, C, c_log, 1.0 / (double)npix, eps, decay,
+  SEG_LAUNCH(bn_final_kernel<0>, dim3((C + 7) / 8), dim3(256), 0, st, (const float*)ws, training ? nb : 0, C, c_log, 1.0 / (double)npix, eps, decay,
              training, moving, stats, (float*)nullptr, (float*)nullptr, 0);
   if (int rc = seg_check_launch("bn_final")) return rc;
   const int g = grid_for(npix * (C / 8));
@@ -824,7 +825,7 @@ extern "C" int seg_bn_relu_bwd(const seg_view* a, const seg_view* dy, const seg_
   if (dtype == SEG_F32) SEG_LAUNCH((bn_partial_kernel<float, 1>), dim3(nb), dim3(256), 0, st, *a, *dy, stats, B, H, W, C, ws);
   else SEG_LAUNCH((bn_partial_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, st, *a, *dy, stats, B, H, W, C, ws);
   if (int rc = seg_check_launch("bn_partial_bwd")) return rc;
-  SEG_LAUNCH(bn_final_kernel<1>, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)ws, nb, C, c_log, 1.0 / (double)npix, 0.f, 0.f, 1,
+  SEG_LAUNCH(bn_final_kernel<1>, dim3((C + 7) / 8), dim3(256), 0, st, (const float*)ws, nb, C, c_log, 1.0 / (double)npix, 0.f, 0.f, 1,
              (float*)nullptr, (float*)nullptr, means, dbeta, dbeta_add);
   if (int rc = seg_check_launch("bn_final_bwd")) return rc;
   const int g = grid_for(npix * (C / 8));
