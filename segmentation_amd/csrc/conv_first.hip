@@ -506,16 +506,27 @@ __global__ void im2col_kernel(const float* x, int B, int H, int W, int cin, int 
     const int ox = (int)(t % Wo); t /= Wo;
     const int oy = (int)(t % Ho); const int b = (int)(t / Ho);
     Vec8<T> o;
+    // a filter ROW's KW * cin values are contiguous in the NHWC input: k = u * RW + j <-> x[(b, iy0 + u, ix0) * cin + j].  One
+    // division per piece, none per element; windows that lie inside the image take no bounds checks (the per-element form with
+    // two divisions and four compares ran the DeconvModel's first layer at 1.1 TB/s)
+    const int RW = KW * cin;
+    const int iy0 = oy * stride - pad_t, ix0 = ox * stride - pad_l;
+    int u = piece * 8 / RW, j = piece * 8 - u * RW;
+    const bool inside = iy0 >= 0 && iy0 + KH <= H && ix0 >= 0 && ix0 + KW <= W;
+    const float* xr = x + (((int64_t)b * H + iy0) * W + ix0) * cin;      // (only dereferenced at positions inside the image)
+    const int64_t rstride = (int64_t)W * cin;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int k = piece * 8 + e;
       float v = 0.f;
-      if (k < nk) {
-        const int tap = k / cin, c = k - tap * cin;
-        const int iy = oy * stride - pad_t + tap / KW, ix = ox * stride - pad_l + tap % KW;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((int64_t)b * H + iy) * W + ix) * cin + c];
+      if (u < KH) {
+        if (inside) v = xr[u * rstride + j];
+        else {
+          const int iy = iy0 + u, ix = ix0 + j / cin;
+          if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = xr[u * rstride + j];
+        }
       }
       o.set(e, v);
+      if (++j == RW) { j = 0; ++u; }
     }
     o.store(reinterpret_cast<T*>(dst.ptr) + view_off(dst, b, oy, ox) + piece * 8);
   }
