@@ -248,12 +248,19 @@ def main():
 
     import numpy as np
     import torch
+    # SEG_BENCH_BACKEND=gloo: REHEARSAL of the N > 1 control flow (launcher child, bucket-plan probe, exposure report, one JSON
+    # line) with the ranks sharing whatever GPUs exist -- the collectives then travel through the host, so its numbers mean nothing
+    backend = os.environ.get('SEG_BENCH_BACKEND', 'nccl')
+    local = local % max(1, torch.cuda.device_count()) if backend != 'nccl' else local
     torch.cuda.set_device(local)
     if world > 1 or args.force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29517')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
     from segmentation_amd import _build
     _build.build(verbose=False)

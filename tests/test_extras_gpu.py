@@ -277,3 +277,23 @@ def test_bench_force_dist_child_process_reports_the_allreduce():
     assert all(u >= 0 for u in ar['exposed_us']) and ar['exposed_total_us'] < 2000
     assert j['n_gpus'] == 1 and j['value'] > 0 and np.isfinite(j['config']['final_loss'])
     assert j['config']['ms_per_step_windows']['n'] == 2
+
+
+def test_bench_two_ranks_rehearsal_over_gloo():
+    """`bench.py --gpus 2` as the driver starts it from a plain shell -- launcher child, two ranks, bucket-plan probe, exposure
+    report on every rank, ONE JSON line from rank 0 -- rehearsed on this one GPU with SEG_BENCH_BACKEND=gloo (both ranks share
+    the card, the collectives travel through the host: the numbers mean nothing, the control flow is what an 8-GPU node runs)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SEG_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('MASTER_PORT', None); env.pop('RANK', None); env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--windows', '2',
+                        '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-500:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['config']['global_batch'] == 32 and j['config']['parallelism'] == 'dp2' and j['scaling'] == 'weak'
+    ar = j['config']['allreduce']
+    assert ar['world'] == 2 and len(ar['exposed_us']) == len(ar['buckets_mb']) and len(ar['bucket_plan_probe_ms']) == 3
+    assert abs(sum(ar['buckets_mb']) - 31.04) < 0.01 and j['value'] > 0 and np.isfinite(j['config']['final_loss'])
