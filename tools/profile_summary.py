@@ -11,6 +11,9 @@ import csv, glob, json, os, re, shutil, sys, collections
 def pretty(name):
     """rocprof kernel name -> bench.py naming, e.g. conv_fwd_kernel<bf16,8,16,64,4,1,3,3,1>.  The kernels take the dtype
     as an int template argument (0 = f32, 1 = bf16) so that the names demangle cleanly."""
+    m2 = re.search(r'(wgrad_sweep_kernel|conv_sweep_kernel|conv_first_win_kernel|conv_first_mfma_kernel)<([^>]*)>', name)
+    if m2:          # round-3 kernels: integer / bool template arguments only, kept as rocprof prints them (bench.py's naming)
+        return '%s<%s>' % (m2.group(1), ','.join(a.strip() for a in m2.group(2).split(',')))
     m = re.search(r'(conv_fwd_glds_kernel|conv_fwd_kernel|conv_wgrad_kernel)<([^>]*)>', name)
     if not m:
         mm = re.search(r'(conv_fwd_glds_kernel|conv_fwd_kernel|conv_wgrad_kernel)I((?:Li\d+E)+)', name)
