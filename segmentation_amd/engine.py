@@ -671,7 +671,7 @@ class Net(object):
                  1 if layer.relu else 0, self.dtype, kernel=kern, flops=fl, bytes=by)
         return False
 
-    def conv_fwd(self, plan, layer, srcs, Hi, Wi, dst, dst_off=(0, 0), out_f32=False, cfg=0, pool=None, ksplit=None):
+    def conv_fwd(self, plan, layer, srcs, Hi, Wi, dst, dst_off=(0, 0), out_f32=False, cfg=0, pool=None, ksplit=None, side=0):
         """srcs: list of (Act, oy, ox) (1 or 2 concat segments).  pool: Act of the 2x2 max-pool that consumes dst; when the
         layer's tile can carry it the pooled map is written by the same launch and `self.pool_fused` is set (else the
         caller emits pool_fwd)."""
@@ -708,7 +708,12 @@ class Net(object):
         # algorithmic HBM bytes: every tensor touched once (input window, output, filters; + the fused pooled map)
         by = (self.B * (Hi * Wi * layer.cin * self.es + Ho * Wo * layer.cout * (4 if out_f32 else self.es)) + k * k * layer.cin * layer.cout * self.es
               + (self.B * pool.H * pool.W * layer.cout * self.es if self.pool_fused else 0))
-        plan.add(name, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl, bytes=by)
+        if side and self.side_enabled:
+            # a forward launch nothing on the critical stream waits for soon (the U-Net's conv1_2 only feeds the last skip): a
+            # filter-gradient stream, idle during the forward pass; the consumer is emitted behind a join_wgrad
+            plan.add(name, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl, bytes=by, side=side)
+        else:
+            plan.add(name, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl, bytes=by)
         plan.flops += fl
         return Ho, Wo
 
