@@ -556,13 +556,16 @@ constexpr int FC_RB = 16;          // batch rows held in registers per pass
 // weight load and four broadcast ds_read_b128 instead of sixteen uniform global loads (the first form of this kernel spent
 // its time issuing those).  The k-lanes are reduced through LDS in lane order.
 constexpr int FC_KC = 256;
+// 16 columns x 64 k-lanes per workgroup (was 64 x 16: the adversary's [*, 3528] x [3528, 1024] layer was 16 workgroups on a
+// 256-CU chip and took 45 us for 14 MB of weights)
+constexpr int FC_NB = 16, FC_KL = 1024 / FC_NB;
 template <typename T>
 __global__ __launch_bounds__(1024) void fc_fwd_kernel(const seg_dconv_desc d) {
   extern __shared__ float fc_lds[];
   float* xs_ = fc_lds;                                  // [FC_KC][FC_RB]
-  float* red = fc_lds + FC_KC * FC_RB;                  // [16 k-lanes][64 n][FC_RB + 1]
-  const int tid = threadIdx.x, nl = tid & 63, kl = tid >> 6;
-  const int n = blockIdx.x * 64 + nl;
+  float* red = fc_lds + FC_KC * FC_RB;                  // [FC_KL k-lanes][FC_NB n][FC_RB + 1]
+  const int tid = threadIdx.x, nl = tid % FC_NB, kl = tid / FC_NB;
+  const int n = blockIdx.x * FC_NB + nl;
   const T* xp = reinterpret_cast<const T*>(d.x.ptr) + view_off(d.x, 0, 0, 0);
   T* yp = reinterpret_cast<T*>(d.y.ptr) + view_off(d.y, 0, 0, 0);
   const int64_t xs = (int64_t)d.x.H * d.x.W * d.x.cs, ys = (int64_t)d.y.H * d.y.W * d.y.cs;
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(1024) void fc_fwd_kernel(const seg_dconv_desc d) {
       if (n < d.yc) {
         const int kend = min(FC_KC, d.xc - k0);
 #pragma unroll 4
-        for (int kk = kl; kk < kend; kk += 16) {
+        for (int kk = kl; kk < kend; kk += FC_KL) {
           const float wv = d.w[(int64_t)(k0 + kk) * d.w_sk + n];
           const f32x4* xr = reinterpret_cast<const f32x4*>(xs_ + kk * FC_RB);
 #pragma unroll
@@ -594,16 +597,16 @@ __global__ __launch_bounds__(1024) void fc_fwd_kernel(const seg_dconv_desc d) {
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < FC_RB; ++r) red[(kl * 64 + nl) * (FC_RB + 1) + r] = acc[r];
+    for (int r = 0; r < FC_RB; ++r) red[(kl * FC_NB + nl) * (FC_RB + 1) + r] = acc[r];
     __syncthreads();
-    {                                                   // thread (nl, r = kl): one output element, k-lanes added in order
-      const int r = kl;
+    if (tid < FC_NB * FC_RB) {                          // thread (n2, r): one output element, k-lanes added in order
+      const int n2l = tid % FC_NB, r = tid / FC_NB, n2 = blockIdx.x * FC_NB + n2l;
       float s = 0.f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) s += red[(q * 64 + nl) * (FC_RB + 1) + r];
-      if (b0 + r < d.B && n < d.y.c) {
-        if (n < d.yc) { if (d.bias != nullptr && n < d.bias_n) s += d.bias[n]; if (d.relu) s = fmaxf(s, 0.f); } else s = 0.f;
-        yp[(b0 + r) * ys + n] = from_f32<T>(s);
+#pragma unroll 8
+      for (int q = 0; q < FC_KL; ++q) s += red[(q * FC_NB + n2l) * (FC_RB + 1) + r];
+      if (b0 + r < d.B && n2 < d.y.c) {
+        if (n2 < d.yc) { if (d.bias != nullptr && n2 < d.bias_n) s += d.bias[n2]; if (d.relu) s = fmaxf(s, 0.f); } else s = 0.f;
+        yp[(b0 + r) * ys + n2] = from_f32<T>(s);
       }
     }
   }
@@ -687,8 +690,8 @@ extern "C" int seg_dconv_fwd(const seg_dconv_desc* dp, void* stream) {
   const seg_dconv_desc& d = *dp;
   if (d.mask.ptr && !view_ok(d.mask, d.Hy, d.Wy, d.y.c)) { seg_set_error("dconv_fwd: bad mask view"); return SEG_ERR_ARG; }
   if (is_dense(d)) {
-    const dim3 g((d.y.c + 63) / 64);
-    constexpr int lds = (FC_KC * FC_RB + 16 * 64 * (FC_RB + 1)) * 4;      // 84 KB
+    const dim3 g((d.y.c + FC_NB - 1) / FC_NB);
+    constexpr int lds = (FC_KC * FC_RB + FC_KL * FC_NB * (FC_RB + 1)) * 4;      // 84 KB
     static bool attr_done = false;
     if (!attr_done) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(fc_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
