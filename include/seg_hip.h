@@ -85,9 +85,17 @@ typedef struct seg_conv_desc {
                             * workgroups per CU on maps of 8..28 pixels (conv4_x..conv7_x at 256^2 inputs and their dgrads); measured
                             * slower than the unsplit launch on all of them but one, so seg_conv2d_splitk_plan only proposes a split
                             * when asked to (SEG_CONV_SPLITK=n) -- DESIGN.md section 5. */
-  int32_t splitk_pad_;
+  int32_t n_store;         /* 0: every computed channel is stored.  8: THIN destination -- a tensor of <= 8 logical channels kept at a
+                            * channel stride of 8 (dst.cs == 8) instead of 32: only the lanes of channels [0, 8) store (per
+                            * transposed-conv tap with up2); mask must then be thin as well.  No n_split / pool / accum. */
   float* splitk_ws;        /* ksplit > 1: workspace of seg_conv2d_splitk_plan's size, owned by this launch site */
   int32_t* splitk_tickets; /* ksplit > 1: one zero-initialised int32 per (output tile x channel block); left zero again by the launch */
+  int32_t thin_src;        /* 1: THIN source(s) -- src0 (and src1) have cs == 8, coff == 0 and c == 32: the kernel reads 32 channels
+                            * per pixel, i.e. the pixel's 8 and the next pixels' values, and relies on the packed filters being ZERO
+                            * for every channel >= 8 (they are: pad channels of a layer with <= 8 logical inputs).  The buffer must
+                            * extend 64 elements behind its last pixel and hold finite values throughout.  The DeconvModel's 2-class
+                            * tail (deconv3_0 / bn8 / conv_out at 512^2) moves a quarter of the bytes this way. */
+  int32_t thin_pad_;
 } seg_conv_desc;
 
 /* slim.convolution2d / conv2d_transpose fwd, Conv2DBackpropInput: models/unet.py:111-166,
@@ -147,6 +155,9 @@ typedef struct seg_wgrad_desc {
    * share it with the data gradients of the critical stream).  The last filter gradients of a backward pass run after the
    * critical stream has finished: the caller marks them with 256. */
   int32_t target_wgs;
+  /* THIN operands (see seg_conv_desc.thin_src): bit 0 = src0 (and src1), bit 1 = dz have cs == 8, coff == 0 and c == 32; the
+   * channels read beyond 8 only meet filter-gradient entries that are never stored (src*_clog, n_log <= 8). */
+  int32_t thin;
 } seg_wgrad_desc;
 int seg_conv2d_wgrad(const seg_wgrad_desc* d, void* stream);
 int seg_conv2d_wgrad_plan(const seg_wgrad_desc* d, int32_t* ksplit, int64_t* ws_bytes);

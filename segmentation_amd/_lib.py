@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
                 ('out_f32', C.c_int32), ('dtype', C.c_int32), ('cfg', C.c_int32), ('accum', C.c_int32),
                 ('n_split', C.c_int32), ('dst1', View), ('mask1', View), ('pool', View), ('pool_h', C.c_int32), ('pool_w', C.c_int32),
                 ('signal', C.c_void_p), ('signal_value', C.c_uint32), ('sched', C.c_void_p),
-                ('ksplit', C.c_int32), ('splitk_pad_', C.c_int32), ('splitk_ws', C.c_void_p), ('splitk_tickets', C.c_void_p)]
+                ('ksplit', C.c_int32), ('n_store', C.c_int32), ('splitk_ws', C.c_void_p), ('splitk_tickets', C.c_void_p),
+                ('thin_src', C.c_int32), ('thin_pad_', C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -43,7 +44,7 @@ class WgradDesc(C.Structure):
                 ('im2col_x', C.c_void_p), ('im2col_h', C.c_int32), ('im2col_w', C.c_int32), ('im2col_cin', C.c_int32),
                 ('im2col_pad', C.c_int32), ('pool_y', View), ('pool_dp', View), ('pool_add', View),
                 ('pool_add_h', C.c_int32), ('pool_add_w', C.c_int32), ('pool_add_y0', C.c_int32), ('pool_add_x0', C.c_int32),
-                ('target_wgs', C.c_int32)]
+                ('target_wgs', C.c_int32), ('thin', C.c_int32)]
 
 
 class DconvDesc(C.Structure):

@@ -66,6 +66,7 @@ SEG_DEV void epi_setup(const seg_conv_desc& d, int n0, int wn, int g, EpiCtx<NJ>
     E.on[j] = nl < d.n_count;
     E.co[j] = nl; E.ua[j] = 0; E.uc[j] = 0;
     if (d.up2) { const int tp = np / d.up_cout; E.co[j] = np - tp * d.up_cout; E.ua[j] = tp >> 1; E.uc[j] = tp & 1; }
+    if (d.n_store > 0 && E.co[j] >= d.n_store) E.on[j] = false;        // thin destination: the pixel's record is n_store channels wide
     if (sb != nullptr) continue;                               // bias comes from LDS: epi_bias, after the last MFMAs
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -876,9 +877,19 @@ extern "C" int seg_conv2d(const seg_conv_desc* dp, void* stream) {
     seg_set_error("conv: bad n range off %d count %d total %d", d.n_off, d.n_count, d.n_total); return SEG_ERR_ARG;
   }
   if (d.B <= 0 || d.Ho <= 0 || d.Wo <= 0 || d.Hi <= 0 || d.Wi <= 0) { seg_set_error("conv: empty extent"); return SEG_ERR_ARG; }
-  if (d.src0.oy + d.Hi > d.src0.H || d.src0.ox + d.Wi > d.src0.W || d.src0.coff + d.src0.c > d.src0.cs ||
+  if (d.thin_src) {
+    if (d.src0.cs != 8 || d.src0.coff != 0 || d.src0.c != 32 || (d.src1.ptr && (d.src1.cs != 8 || d.src1.coff != 0 || d.src1.c != 32))) {
+      seg_set_error("conv: a thin source has cs 8, coff 0, c 32 (got cs %d coff %d c %d)", d.src0.cs, d.src0.coff, d.src0.c); return SEG_ERR_ARG;
+    }
+    if (d.src0.oy + d.Hi > d.src0.H || d.src0.ox + d.Wi > d.src0.W || (d.src1.ptr && (d.src1.oy + d.Hi > d.src1.H || d.src1.ox + d.Wi > d.src1.W))) {
+      seg_set_error("conv: source window exceeds its buffer"); return SEG_ERR_ARG;
+    }
+  } else if (d.src0.oy + d.Hi > d.src0.H || d.src0.ox + d.Wi > d.src0.W || d.src0.coff + d.src0.c > d.src0.cs ||
       (d.src1.ptr && (d.src1.oy + d.Hi > d.src1.H || d.src1.ox + d.Wi > d.src1.W || d.src1.coff + d.src1.c > d.src1.cs))) {
     seg_set_error("conv: source window exceeds its buffer"); return SEG_ERR_ARG;
+  }
+  if (d.n_store != 0 && (d.n_store != 8 || d.n_split != 0 || d.pool.ptr || d.accum || d.dst.cs % 8 || d.dst.coff % 8)) {
+    seg_set_error("conv: n_store is 0 or 8 and excludes n_split / pool / accum"); return SEG_ERR_ARG;
   }
   if (d.pool.ptr) {
     if (d.pool_h != d.Ho / 2 || d.pool_w != d.Wo / 2 || d.pool_h < 1 || d.pool_w < 1 || d.pool.oy + d.pool_h > d.pool.H || d.pool.ox + d.pool_w > d.pool.W ||
@@ -892,7 +903,7 @@ extern "C" int seg_conv2d(const seg_conv_desc* dp, void* stream) {
   }
   {
     const int sc = d.up2 ? 2 : 1;
-    const int nch = d.up2 ? d.up_cout : (d.n_split > 0 ? d.n_split : d.n_count);
+    const int nch = d.n_store > 0 ? d.n_store : (d.up2 ? d.up_cout : (d.n_split > 0 ? d.n_split : d.n_count));
     if (d.dst.oy + sc * d.Ho > d.dst.H || d.dst.ox + sc * d.Wo > d.dst.W || d.dst.coff + nch > d.dst.cs) {
       seg_set_error("conv: destination window exceeds its buffer"); return SEG_ERR_ARG;
     }

@@ -390,7 +390,7 @@ int seg_conv_sweep(const seg_conv_desc& d, char* name_out, int name_cap, hipStre
   static const char* impl = getenv("SEG_CONV_IMPL");
   const bool opt_in = impl && !strcmp(impl, "sweep");
   if (!opt_in && d.cfg < 100) return 0;
-  if (d.dtype != SEG_BF16 || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.up2 || d.pool.ptr) return 0;
+  if (d.dtype != SEG_BF16 || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.up2 || d.pool.ptr || d.n_store || d.thin_src) return 0;
   if (d.cfg > 0 && d.cfg < 100) return 0;                     // an explicit tile of the 4-wave kernel
   if (d.n_count % 32 || (d.n_split % 32)) return 0;
   const int BN = (d.n_count % 64 == 0 && d.n_split % 64 == 0) ? 64 : 32;

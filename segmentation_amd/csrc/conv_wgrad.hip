@@ -1033,9 +1033,17 @@ extern "C" int seg_conv2d_wgrad(const seg_wgrad_desc* dp, void* stream) {
       (d.src1.ptr && (int64_t)d.src1.H * d.src1.W * d.src1.cs >= ((int64_t)1 << 31))) {
     seg_set_error("wgrad: an image plane of 2^31 elements or more is not supported"); return SEG_ERR_UNSUPPORTED;
   }
-  if (d.src0.oy + d.Hi > d.src0.H || d.src0.ox + d.Wi > d.src0.W || d.src0.coff + d.src0.c > d.src0.cs ||
-      (d.src1.ptr && (d.src1.oy + d.Hi > d.src1.H || d.src1.ox + d.Wi > d.src1.W || d.src1.coff + d.src1.c > d.src1.cs)) ||
-      d.dz.oy + d.Ho > d.dz.H || d.dz.ox + d.Wo > d.dz.W || d.dz.coff + d.dz.c > d.dz.cs) {
+  // thin operands (seg_wgrad_desc.thin): 8-channel records read as 32 channels -- what lies beyond channel 8 only reaches
+  // filter-gradient entries that are never stored
+  auto thin_ok = [](const seg_view& v, int clog) { return v.cs == 8 && v.coff == 0 && v.c == 32 && clog <= 8; };
+  const bool ts = (d.thin & 1) != 0, tz = (d.thin & 2) != 0;
+  if ((ts && (!thin_ok(d.src0, d.src0_clog) || (d.src1.ptr && !thin_ok(d.src1, d.src1_clog)) || d.im2col_x || d.bias_mode == 2 && d.bias_n > 8)) ||
+      (tz && (!thin_ok(d.dz, d.n_log) || d.pool_y.ptr || (d.bias_mode == 1 && d.bias_n > 8)))) {
+    seg_set_error("wgrad: a thin operand has cs 8, coff 0, c 32 and <= 8 logical channels"); return SEG_ERR_ARG;
+  }
+  if (d.src0.oy + d.Hi > d.src0.H || d.src0.ox + d.Wi > d.src0.W || (!ts && d.src0.coff + d.src0.c > d.src0.cs) ||
+      (d.src1.ptr && (d.src1.oy + d.Hi > d.src1.H || d.src1.ox + d.Wi > d.src1.W || (!ts && d.src1.coff + d.src1.c > d.src1.cs))) ||
+      d.dz.oy + d.Ho > d.dz.H || d.dz.ox + d.Wo > d.dz.W || (!tz && d.dz.coff + d.dz.c > d.dz.cs)) {
     seg_set_error("wgrad: window exceeds its buffer"); return SEG_ERR_ARG;
   }
   {

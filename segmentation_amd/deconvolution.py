@@ -35,6 +35,13 @@ TEST_SEED_INC = 64                                            # test() draws fro
 DROP_SITES = {'bn2': 1, 'bn4': 2, 'bn5': 3}                    # batch norm followed by a `bayesian` dropout -> seed increment
 
 
+def thin_tail(n_classes):
+    """The full-resolution tail (deconv3_0 -> bn8 -> conv_out -> logits, their gradients) carries n_classes channels.  Up to 8
+    classes the tensors are kept THIN: 8 channels per pixel instead of 32 (engine.Act(thin=True), seg_conv_desc.thin_src /
+    n_store) -- at 512^2 x 16 every pass over one of them moves 67 MB instead of 268 MB.  SEG_THIN_TAIL=0: padded to 32."""
+    return n_classes <= 8 and os.environ.get('SEG_THIN_TAIL', '1') != '0'
+
+
 def deconv_layers(n_classes, nk, cin):
     Ly = {}
 
@@ -58,6 +65,8 @@ def deconv_layers(n_classes, nk, cin):
     addt('deconv2_1', nk, nk); add('bn7', 'bn', 1, nk, nk)
     add('deconv3_0', 'up', 2, nk, n_classes); add('bn8', 'bn', 1, n_classes, n_classes)
     add('conv_out', 'conv', 3, n_classes, n_classes, 'SAME', relu=False)
+    if thin_tail(n_classes):
+        Ly['bn8'].cout_p = 8            # (its statistics vectors follow the 8-channel stride of the tensors it normalises)
     Ly['conv1_0'].need_dgrad = False
     return [Ly[n] for n in BWD_ORDER]
 
@@ -188,11 +197,11 @@ class DeconvModel(BaseModel):
             """ReLU output of `name` -> batch norm (-> dropout)"""
             b = 'bn' + str(GRAPH.index(name) // 2 + 1)
             A[name] = a
-            Y[b] = net.act(a.H, a.W, a.C, name=b)
+            Y[b] = net.act(a.H, a.W, a.C, name=b, thin=a.thin)
             net.bn_fwd(plan, Ly[b], bn[b], a, Y[b], training=bn_training, update_moving=update_moving)
             out = Y[b]
             if self.bayesian and b in DROP_SITES:
-                Y[b + '/drop'] = net.act(a.H, a.W, a.C, name=b + '/drop')
+                Y[b + '/drop'] = net.act(a.H, a.W, a.C, name=b + '/drop', thin=a.thin)
                 if dropout_step:
                     net.dropout_step(plan, Y[b], Y[b + '/drop'], self.keep_prob, self.drop_seed + seed_inc + DROP_SITES[b], 0)
                 else:
@@ -226,10 +235,11 @@ class DeconvModel(BaseModel):
             t = act_bn(dn, a)
         R = net.act(sz['resize'], sz['resize'], t.C, name='resize')
         net.resize_fwd(plan, t, R)
-        a = net.act(sz['deconv3_0'], sz['deconv3_0'], self.n_classes, name='deconv3_0')
+        thin = thin_tail(self.n_classes)
+        a = net.act(sz['deconv3_0'], sz['deconv3_0'], self.n_classes, name='deconv3_0', thin=thin)
         net.up_fwd(plan, Ly['deconv3_0'], R, R.H, R.W, a)
         t = act_bn('deconv3_0', a)             # (resize_image_with_crop_or_pad to (H, W) is the identity for even H)
-        A['logits'] = net.act(H, W, self.n_classes, f32=True, name='logits')
+        A['logits'] = net.act(H, W, self.n_classes, f32=True, name='logits', thin=thin)
         net.conv_fwd(plan, Ly['conv_out'], [(t, 0, 0)], H, W, A['logits'], out_f32=True)
         A['x'], A['resize'] = xin, R
         return A, Y, P, sz
@@ -248,7 +258,7 @@ class DeconvModel(BaseModel):
         A, Y, P, sz = self._emit_forward(net, fwd, self.input_x, H, W, bn_training=True, update_moving=True, dropout_step=True)
         self.acts, self.bn_out = A, Y
         self.out_hw, self.label_off = (H, W), (0, 0)
-        dlog = net.act(H, W, nc, name='dlogits')
+        dlog = net.act(H, W, nc, name='dlogits', thin=thin_tail(nc))
         net.softmax_xent(fwd, A['logits'], self.input_y, H, W, (0, 0), H, W, nc, self.loss_buf, dlog)
         self.dlogits = dlog
         # the test() graph: moving averages, no update; dropout (if bayesian) stays on, exactly as in the reference's test graph
@@ -256,13 +266,13 @@ class DeconvModel(BaseModel):
         self.test_plan = E.Plan('test')
         TA, _, _, _ = self._emit_forward(tnet, self.test_plan, self.input_x, H, W, bn_training=False, update_moving=False, dropout_step=True,
                                          seed_inc=TEST_SEED_INC)
-        tdl = tnet.act(H, W, nc, name='dlogits_test')
+        tdl = tnet.act(H, W, nc, name='dlogits_test', thin=thin_tail(nc))
         tnet.softmax_xent(self.test_plan, TA['logits'], self.input_y, H, W, (0, 0), H, W, nc, self.loss_buf, tdl)
 
         seg = E.Plan('bwd0')
 
         def like(a, name):
-            return net.act(a.H, a.W, a.C, name=name)
+            return net.act(a.H, a.W, a.C, name=name, thin=a.thin)
 
         G = {}
 

@@ -25,13 +25,23 @@ def torch_dtype(dtype):
 class Act(object):
     """NHWC activation buffer [B,H,W,Cp]; Cp = channels padded to 32, pad channels stay zero."""
 
-    def __init__(self, B, H, W, C, dtype, device, f32=False, name=''):
-        self.B, self.H, self.W, self.C, self.Cp = B, H, W, C, rup(C)
+    def __init__(self, B, H, W, C, dtype, device, f32=False, name='', thin=False):
+        # thin: <= 8 logical channels kept at a channel stride of 8 (16 bytes per bf16 pixel instead of 64).  The MFMA kernels
+        # read such a tensor as 32 channels per pixel (view_wide: the next pixels' values meet zero filter rows) and store only
+        # the first 8 (seg_conv_desc.n_store); the buffer carries 64 elements of zeroed slack for the reads past its last pixel.
+        self.thin = bool(thin) and C <= 8
+        self.B, self.H, self.W, self.C, self.Cp = B, H, W, C, (8 if self.thin else rup(C))
         self.name = name
-        self.t = torch.zeros((B, H, W, self.Cp), dtype=torch.float32 if f32 else torch_dtype(dtype), device=device)
+        n = B * H * W * self.Cp
+        self._buf = torch.zeros(n + (64 if self.thin else 0), dtype=torch.float32 if f32 else torch_dtype(dtype), device=device)
+        self.t = self._buf[:n].view(B, H, W, self.Cp)
 
     def view(self, oy=0, ox=0):
         return L.View(self.t.data_ptr(), self.H, self.W, self.Cp, 0, oy, ox, self.Cp)
+
+    def view_wide(self, oy=0, ox=0):
+        """a thin activation as a 32-channel operand of the MFMA kernels (thin_src / seg_wgrad_desc.thin)"""
+        return L.View(self.t.data_ptr(), self.H, self.W, self.Cp, 0, oy, ox, 32) if self.thin else self.view(oy, ox)
 
     def nbytes(self):
         return self.t.numel() * self.t.element_size()
@@ -612,6 +622,10 @@ class Net(object):
         """bytes per activation element in HBM"""
         return 4 if self.dtype == L.SEG_F32 else 2
 
+    @staticmethod
+    def _thin(*acts):
+        return any(getattr(a, 'thin', False) for a in acts if a is not None)
+
     def _splitk(self, d, plan, ksplit=None):
         """Asks the library whether this convolution launch should share its K loop among several workgroups per output tile
         (seg_conv2d_splitk_plan: the deep, small-map layers) and gives the descriptor the workspace and tickets it then needs.
@@ -639,8 +653,8 @@ class Net(object):
         self._sched_n += 1
         return self._sched.data_ptr() + 8 * (self._sched_n - 1)
 
-    def act(self, H, W, C, f32=False, name=''):
-        a = Act(self.B, H, W, C, self.dtype, self.device, f32=f32, name=name)
+    def act(self, H, W, C, f32=False, name='', thin=False):
+        a = Act(self.B, H, W, C, self.dtype, self.device, f32=f32, name=name, thin=thin)
         self.acts.append(a)
         return a
 
@@ -679,8 +693,10 @@ class Net(object):
         k, pad = layer.k, layer.pad
         Ho, Wo = Hi + 2 * pad - k + 1, Wi + 2 * pad - k + 1
         d = L.ConvDesc()
-        d.src0 = srcs[0][0].view(srcs[0][1], srcs[0][2])
-        d.src1 = srcs[1][0].view(srcs[1][1], srcs[1][2]) if len(srcs) > 1 else L.null_view()
+        d.src0 = srcs[0][0].view_wide(srcs[0][1], srcs[0][2])
+        d.src1 = srcs[1][0].view_wide(srcs[1][1], srcs[1][2]) if len(srcs) > 1 else L.null_view()
+        d.thin_src = 1 if self._thin(*[s_[0] for s_ in srcs]) else 0
+        assert not d.thin_src or all(s_[0].thin for s_ in srcs), 'thin and wide sources cannot be concatenated'
         d.B, d.Hi, d.Wi = self.B, Hi, Wi
         d.KH = d.KW = k; d.stride = 1; d.pad_t = d.pad_l = pad
         d.Ho, d.Wo = Ho, Wo
@@ -688,6 +704,7 @@ class Net(object):
         d.n_total = layer.cout_p; d.n_off = 0; d.n_count = layer.cout_p
         d.bias = self.store.p_ptr(layer.b_off); d.bias_n = layer.cout
         d.dst = dst.view(dst_off[0], dst_off[1])
+        d.n_store = 8 if dst.thin else 0
         d.up2 = 0; d.up_cout = 0; d.mask = L.null_view()
         d.relu = 1 if layer.relu else 0
         d.out_f32 = 1 if out_f32 else 0
@@ -727,6 +744,7 @@ class Net(object):
         d.n_total = 4 * layer.cout_p; d.n_off = 0; d.n_count = 4 * layer.cout_p
         d.bias = self.store.p_ptr(layer.b_off); d.bias_n = layer.cout
         d.dst = dst.view(); d.up2 = 1; d.up_cout = layer.cout_p; d.mask = L.null_view()
+        d.n_store = 8 if dst.thin else 0
         d.relu = 1 if layer.relu else 0; d.out_f32 = 0; d.dtype = self.dtype; d.cfg = cfg
         self._splitk(d, plan)
         plan.keep.append(d)
@@ -903,13 +921,14 @@ class Net(object):
         k, pad = layer.k, layer.pad
         Ho, Wo = Hi + 2 * pad - k + 1, Wi + 2 * pad - k + 1
         w = L.WgradDesc()
-        w.src0 = srcs[0][0].view(srcs[0][1], srcs[0][2])
-        w.src1 = srcs[1][0].view(srcs[1][1], srcs[1][2]) if len(srcs) > 1 else L.null_view()
+        w.src0 = srcs[0][0].view_wide(srcs[0][1], srcs[0][2])
+        w.src1 = srcs[1][0].view_wide(srcs[1][1], srcs[1][2]) if len(srcs) > 1 else L.null_view()
         w.src0_clog = layer.cin_segs[0]; w.src1_clog = layer.cin_segs[1] if len(srcs) > 1 else 0
         w.B, w.Hi, w.Wi = self.B, Hi, Wi
         w.KH = w.KW = k; w.stride = 1; w.pad_t = w.pad_l = pad
         w.Ho, w.Wo = Ho, Wo
-        w.dz = dz.view(dz_off[0], dz_off[1]); w.n_log = layer.cout
+        w.dz = dz.view_wide(dz_off[0], dz_off[1]); w.n_log = layer.cout
+        w.thin = (1 if self._thin(*[s_[0] for s_ in srcs]) else 0) | (2 if dz.thin else 0)
         w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = wcfg
         w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
         if layer.name in _tail_layers(getattr(self, 'tail_layers', ())):
@@ -924,6 +943,7 @@ class Net(object):
                   and os.environ.get('SEG_MERGE_DGRAD', '1') != '0')
         if merged:
             # both halves of a channel-concat input in ONE launch (seg_conv_desc.n_split): one kernel less per decoder level
+            assert not dz.thin and not self._thin(dsrcs[0][0], dsrcs[1][0]), 'thin tensors have one source'
             d = L.ConvDesc()
             d.accum = 0
             d.src0 = dz.view(dz_off[0], dz_off[1]); d.src1 = L.null_view()
@@ -952,7 +972,10 @@ class Net(object):
                 dst, doff, mask, moff = ds[:4]
                 d = L.ConvDesc()
                 d.accum = 1 if (len(ds) > 4 and ds[4]) else 0
-                d.src0 = dz.view(dz_off[0], dz_off[1]); d.src1 = L.null_view()
+                d.src0 = dz.view_wide(dz_off[0], dz_off[1]); d.src1 = L.null_view()
+                d.thin_src = 1 if dz.thin else 0
+                d.n_store = 8 if dst.thin else 0
+                assert not dst.thin or mask is None or mask.thin
                 d.B, d.Hi, d.Wi = self.B, Ho, Wo
                 d.KH = d.KW = k; d.stride = 1; d.pad_t = d.pad_l = k - 1 - pad
                 d.Ho, d.Wo = Hi, Wi
@@ -975,7 +998,8 @@ class Net(object):
     def up_bwd(self, plan, layer, src, Hi, Wi, dzu, dsrc, mask, cfg=0, wcfg=0, ksplit=0):
         """src: input Act [Hi,Wi,cin]; dzu: masked grad of the upsampled output [2Hi,2Wi,cout]."""
         w = L.WgradDesc()
-        w.src0 = dzu.view(); w.src1 = L.null_view(); w.src0_clog = layer.cout; w.src1_clog = 0
+        w.src0 = dzu.view_wide(); w.src1 = L.null_view(); w.src0_clog = layer.cout; w.src1_clog = 0
+        w.thin = 1 if dzu.thin else 0
         w.B, w.Hi, w.Wi = self.B, 2 * Hi, 2 * Wi
         w.KH = w.KW = 2; w.stride = 2; w.pad_t = w.pad_l = 0
         w.Ho, w.Wo = Hi, Wi
@@ -989,7 +1013,8 @@ class Net(object):
         plan.flops += fl
         if dsrc is not None:
             d = L.ConvDesc()
-            d.src0 = dzu.view(); d.src1 = L.null_view()
+            d.src0 = dzu.view_wide(); d.src1 = L.null_view()
+            d.thin_src = 1 if dzu.thin else 0
             d.B, d.Hi, d.Wi = self.B, 2 * Hi, 2 * Wi
             d.KH = d.KW = 2; d.stride = 2; d.pad_t = d.pad_l = 0
             d.Ho, d.Wo = Hi, Wi
