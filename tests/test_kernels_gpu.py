@@ -191,6 +191,60 @@ def test_conv_split_k(dtype, case):
             c0 += c
 
 
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('nc,H,W,B', [(2, 19, 23, 2), (5, 12, 40, 3), (8, 33, 9, 1)])
+def test_thin_tensors_through_the_mfma_kernels(dtype, nc, H, W, B):
+    """<= 8-channel tensors at a channel stride of 8 (engine.Act(thin=True)): a 2x2/s2 transposed conv INTO a thin tensor, a 3x3
+    SAME conv FROM a thin tensor into a thin float tensor, and every gradient of both (thin dZ, thin sources, thin data-gradient
+    destinations with a thin ReLU mask) against the oracle -- the DeconvModel's deconv3_0 / conv_out tail."""
+    rng = np.random.default_rng(nc * 100 + H)
+    up = E.Layer('u', 'up', 2, [32], nc, 'VALID', True)
+    cv = E.Layer('c', 'conv', 3, [nc], nc, 'SAME', False)
+    p = {'u': _rand_params(up, rng, dtype), 'c': _rand_params(cv, rng, dtype)}
+    for n in p:
+        p[n]['weights'] = U.round_dtype(p[n]['weights'], dtype).astype(np.float32)
+    store = U.make_store([cv, up], dtype, p)
+    net = E.Net(store, B, dtype, U.dev())
+    xs = U.round_dtype(rng.standard_normal((B, H, W, 32)), dtype)
+    x = net.act(H, W, 32); U.fill_act(x, xs)
+    a = net.act(2 * H, 2 * W, nc, thin=True)
+    lg = net.act(2 * H, 2 * W, nc, f32=True, thin=True)
+    assert a.thin and a.Cp == 8 and a.t.shape[-1] == 8 and lg.t.dtype == torch.float32
+    plan = E.Plan('t')
+    net.up_fwd(plan, up, x, H, W, a)
+    net.conv_fwd(plan, cv, [(a, 0, 0)], 2 * H, 2 * W, lg, out_f32=True)
+    plan.run(U.stream()); U.sync()
+    a_ref = ops.conv2d_transpose(xs, p['u']['weights'], p['u']['biases'], stride=2, padding='VALID', relu=True)
+    assert U.rel_err(U.read_act(a), a_ref) < U.tol(dtype)
+    a_got = U.round_dtype(U.read_act(a), dtype)
+    lg_ref = ops.conv2d(a_got, p['c']['weights'], p['c']['biases'], 'SAME', 1, False)
+    assert U.rel_err(lg.t[..., :nc].cpu().numpy().astype(np.float64), lg_ref) < U.tol(dtype)
+    assert bool((a.t[..., nc:].float() == 0).all().item())
+    # backward of the conv: thin dZ, thin source, thin destination
+    dzv = U.round_dtype(rng.standard_normal((B, 2 * H, 2 * W, nc)) * 0.5, dtype)
+    dz = net.act(2 * H, 2 * W, nc, thin=True); U.fill_act(dz, dzv)
+    da = net.act(2 * H, 2 * W, nc, thin=True)
+    store.g.zero_()
+    bp = E.Plan('b')
+    net.conv_bwd(bp, cv, [(a, 0, 0)], 2 * H, 2 * W, dz, [(da, (0, 0), a, (0, 0))])
+    # ... and of the transposed conv from the (thin) gradient of its output
+    dx = net.act(H, W, 32)
+    net.up_bwd(bp, up, x, H, W, da, dx, None)
+    net.flush_reduce(bp)
+    bp.run(U.stream()); U.sync()
+    g = store.get_grads()
+    dw_ref, db_ref = ops.conv2d_wgrad(a_got, dzv, (3, 3), 'SAME', 1)
+    assert U.rel_err(g['c']['weights'], dw_ref) < U.tol(dtype, 2e-5, 1e-2) and U.rel_err(g['c']['biases'], db_ref) < U.tol(dtype, 2e-5, 1e-2)
+    da_ref = ops.conv2d_dgrad(dzv, p['c']['weights'], (2 * H, 2 * W), 'SAME', 1) * (a_got > 0)
+    assert U.rel_err(U.read_act(da), da_ref) < U.tol(dtype)
+    assert bool((da.t[..., nc:].float() == 0).all().item())
+    da_got = U.round_dtype(U.read_act(da), dtype)
+    uw_ref, ub_ref = ops.conv2d_transpose_wgrad(xs, da_got, (2, 2), stride=2, padding='VALID')
+    assert U.rel_err(g['u']['weights'], uw_ref) < U.tol(dtype, 2e-5, 1e-2) and U.rel_err(g['u']['biases'], ub_ref) < U.tol(dtype, 2e-5, 1e-2)
+    dx_ref = ops.conv2d_transpose_dgrad(da_got, p['u']['weights'], (H, W), stride=2, padding='VALID')
+    assert U.rel_err(U.read_act(dx), dx_ref) < U.tol(dtype)
+
+
 @pytest.mark.parametrize('case', [
     # k, padding, segs, cout, H, W, B, wcfg            filter-gradient layouts (bf16): 11/14 = 64 ci x 64 co, 12/15 = 32 ci x 64 co
     (3, 'VALID', [64], 64, 37, 35, 3, 11),
