@@ -41,14 +41,18 @@ def _sub(act, b0, B):
     s = object.__new__(E.Act)
     s.B, s.H, s.W, s.C, s.Cp, s.name = B, act.H, act.W, act.C, act.Cp, act.name + '[%d:%d]' % (b0, b0 + B)
     s.t = act.t[b0:b0 + B]
+    s.thin = getattr(act, 'thin', False)       # (a thin half is followed by the other half or by the parent's slack)
     return s
 
 
 class Adversary(object):
-    def __init__(self, B, h, w, n_classes, dtype, device, step_ptr, lr=1e-5, lam=2.0, seed=7777):
+    def __init__(self, B, h, w, n_classes, dtype, device, step_ptr, lr=1e-5, lam=2.0, seed=7777, thin=None):
         self.lib = L.load()
         self.B, self.h, self.w, self.nc, self.dtype, self.device = B, h, w, n_classes, dtype, device
         self.lr, self.lam, self.step_ptr = float(lr), float(lam), step_ptr
+        # class-probability maps as THIN tensors (8 channels per pixel): the same kind as the dlogits tensor the model hands over
+        # (None: up to 8 classes, unless SEG_THIN_TAIL=0)
+        self.thin_maps = (n_classes <= 8 and os.environ.get('SEG_THIN_TAIL', '1') != '0') if thin is None else (bool(thin) and n_classes <= 8)
         self.sz = ladder(h, w)
         nk = N_KERNELS
         ph, pw = self.sz['pool2']
@@ -158,8 +162,10 @@ class Adversary(object):
         n2, Ly, sz = self.net2, self.layers, self.sz
         nk, F = N_KERNELS, self.F
         A = self.A = {}
-        A['x'] = n2.act(self.h, self.w, self.nc, name='adv_in')
-        A['r'] = n2.act(*sz['resize'], self.nc, name='adv_resize')
+        # (up to 8 classes the class-probability maps are thin tensors: 8 channels per pixel instead of 32)
+        thin = self.thin_maps
+        A['x'] = n2.act(self.h, self.w, self.nc, name='adv_in', thin=thin)
+        A['r'] = n2.act(*sz['resize'], self.nc, name='adv_resize', thin=thin)
         if self.sconv:                  # im2col of each convolution's input (kept for its filter gradient); G[...] = its gradient
             A['c1'] = n2.act(*sz['conv1'], 9 * self.nc, name='adv_col1'); A['c2'] = n2.act(*sz['conv2'], 9 * nk, name='adv_col2')
         A['a1'] = n2.act(*sz['conv1'], nk, name='adv_conv1'); A['y1'] = n2.act(*sz['conv1'], nk, name='adv_bn1')
@@ -169,8 +175,8 @@ class Adversary(object):
         A['f'] = n2.act(1, 1, F, name='adv_flat'); A['y3'] = n2.act(1, 1, F, name='adv_bn3')
         A['h'] = n2.act(1, 1, 1024, name='adv_fc1'); A['y4'] = n2.act(1, 1, 1024, name='adv_bn4')
         A['lg'] = n2.act(1, 1, 2, name='adv_logits')
-        G = self.G = {k: n2.act(a.H, a.W, a.C, name='d' + a.name) for k, a in A.items() if k != 'x'}
-        G['x'] = self.net1.act(self.h, self.w, self.nc, name='dadv_in')          # only the fake half has an input gradient
+        G = self.G = {k: n2.act(a.H, a.W, a.C, name='d' + a.name, thin=a.thin) for k, a in A.items() if k != 'x'}
+        G['x'] = self.net1.act(self.h, self.w, self.nc, name='dadv_in', thin=thin)          # only the fake half has an input gradient
         B = self.B
         self.half = [{k: _sub(a, b0, B) for k, a in A.items()} for b0 in (0, B)]
         self.ghalf = [{k: _sub(a, b0, B) for k, a in G.items() if k != 'x'} for b0 in (0, B)]

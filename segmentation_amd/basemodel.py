@@ -473,7 +473,7 @@ class BaseModel(object):
         of the first backward segment, so the forward plan alone -- test() -- leaves the adversary untouched."""
         from .adversary import Adversary
         self.adversary = Adversary(self.batch_size, oh, ow, self.n_classes, self.dtype, self.device, self.store.step.data_ptr() + 8,
-                                   lr=self.adversarial_lr, lam=self.adv_lambda, seed=self.seed + 2222)
+                                   lr=self.adversarial_lr, lam=self.adv_lambda, seed=self.seed + 2222, thin=bool(getattr(dlogits, 'thin', False)))
         self.adv_plan = E.Plan('adversary')
         self.adversary.emit(self.adv_plan, logits, self.input_y, LH, LW, self.label_off, dlogits)
 

@@ -200,7 +200,9 @@ class UNetModel(BaseModel):
             if dropout is not None and cb in dropout['sites']:
                 net.dropout(plan, A[cb], dropout['keep'], dropout['seed'] + 10 + i, dropout['offset'])
             prev = A[cb]
-        A['logits'] = net.act(sh['output'], sw['output'], self.n_classes, f32=True, name='logits')
+        # (written by the 1x1 output convolution as a tensor of its own -- inference, adversarial training: thin up to 8 classes)
+        A['logits'] = net.act(sh['output'], sw['output'], self.n_classes, f32=True, name='logits',
+                              thin=head and self.n_classes <= 8 and os.environ.get('SEG_THIN_TAIL', '1') != '0')
         if head:        # (the training plan fuses this 1x1 conv with the loss and its input gradient: Net.head_xent)
             net.conv_fwd(plan, Ly['output'], [(prev, 0, 0)], prev.H, prev.W, A['logits'], out_f32=True)
         return A, sh, sw, skip_off, (o4h, o4w)
@@ -228,7 +230,7 @@ class UNetModel(BaseModel):
         self.acts = A
         oh, ow = sh['output'], sw['output']
         self.out_hw = (oh, ow)
-        dlog = net.act(oh, ow, self.n_classes, name='dlogits')
+        dlog = net.act(oh, ow, self.n_classes, name='dlogits', thin=A['logits'].thin)
         # label crop: resize_image_with_crop_or_pad(input_y, target, target) -> floor offsets (unet.py:171-174)
         self.label_off = ((H - oh) // 2, (W - ow) // 2)
         G = {}                                    # masked gradients dZ (same shape as the activation)

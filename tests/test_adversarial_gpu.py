@@ -157,9 +157,10 @@ def test_adversary_f32_vs_oracle(hw):
     LH, LW, off = h + 5, w + 2, (3, 1)
     z = (rng.standard_normal((B, h, w, nc)) * 2).astype(np.float32)
     y = rng.integers(0, nc, (B, LH, LW, 1)).astype(np.uint8)
-    lg = E.Act(B, h, w, nc, dt, U.dev(), f32=True); U.fill_act(lg, z)
+    thin = adv.A['x'].thin            # (the models hand the adversary class maps of its own kind: thin up to 8 classes)
+    lg = E.Act(B, h, w, nc, dt, U.dev(), f32=True, thin=thin); U.fill_act(lg, z)
     d0 = (rng.standard_normal((B, h, w, nc)) * 1e-3).astype(np.float32)
-    dl = E.Act(B, h, w, nc, dt, U.dev()); U.fill_act(dl, d0)
+    dl = E.Act(B, h, w, nc, dt, U.dev(), thin=thin); U.fill_act(dl, d0)
     yd = torch.from_numpy(y).to(U.dev())
     plan = E.Plan('adv')
     adv.store.g.fill_(float('nan'))
