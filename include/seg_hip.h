@@ -255,6 +255,11 @@ int seg_sigmoid_argmax(const seg_view* logits, int32_t B, int32_t H, int32_t W, 
 /* BiasAddGrad: db[c] = sum over B*H*W of dz[...,c] for c < n_log (overwritten; one workgroup per 8 channels, fixed order). */
 int seg_bias_grad(const seg_view* dz, int32_t B, int32_t H, int32_t W, int32_t n_log, float* db,
                   int32_t dtype, void* stream);
+/* The same in two stages for big maps (512 workgroups of partial sums + a fixed-order final pass; bitwise reproducible):
+ * ws of seg_bias_grad_ws_bytes(dz->c) bytes (0: this channel count is not supported, use seg_bias_grad). */
+int64_t seg_bias_grad_ws_bytes(int32_t C);
+int seg_bias_grad_ws(const seg_view* dz, int32_t B, int32_t H, int32_t W, int32_t n_log, float* db, float* ws, int64_t ws_bytes,
+                     int32_t dtype, void* stream);
 
 /* tf.train.AdamOptimizer(lr, name='segAdam') on one flat fp32 parameter arena: models/basemodel.py:321,366.
  * TF variant: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;

@@ -87,6 +87,7 @@ SIGNATURES = {
     'seg_head_dw_reduce': [vp, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     'seg_sigmoid_argmax': [PV, i32, i32, i32, i32, vp, vp, vp],
     'seg_bias_grad': [PV, i32, i32, i32, i32, vp, i32, vp],
+    'seg_bias_grad_ws': [PV, i32, i32, i32, i32, vp, vp, i64, i32, vp],
     'seg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp],
     'seg_step_increment': [vp, vp],
     'seg_step_begin': [vp, vp, vp],
@@ -152,6 +153,8 @@ def load():
     lib.seg_dconv_wgrad_ws_bytes.argtypes = [C.POINTER(DconvDesc)]
     lib.seg_head_xent_ws_bytes.restype = C.c_int64
     lib.seg_head_xent_ws_bytes.argtypes = [C.c_int32] * 5
+    lib.seg_bias_grad_ws_bytes.restype = C.c_int64
+    lib.seg_bias_grad_ws_bytes.argtypes = [C.c_int32]
     lib.seg_bilinear_up_bwd_ws_bytes.restype = C.c_int64
     lib.seg_bilinear_up_bwd_ws_bytes.argtypes = [C.c_int32] * 4
     _lib = lib

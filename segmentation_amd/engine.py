@@ -762,7 +762,7 @@ class Net(object):
     def bias_grad(self, plan, layer, dz, H, W, dz_off=(0, 0)):
         zv = dz.view(dz_off[0], dz_off[1])
         plan.keep.append(zv)
-        plan.add(layer.name + '/db', self.lib.seg_bias_grad, C.byref(zv), self.B, H, W, layer.cout, self.store.g_ptr(layer.b_off), self.dtype, kernel='bias_grad_kernel')
+        self.bias_grad(plan, layer.name + '/db', zv, H, W, layer.cout, layer.b_off)
 
     def _wgrad_ws(self, w, plan, ksplit=0):
         """Asks the library for the K split / partial-slab workspace of this wgrad and allocates it."""
@@ -1180,8 +1180,7 @@ class Net(object):
         col = self.act(Hi, Wi, k * k * co, name=layer.name + '/dzcol')
         cv = col.view()
         plan.keep += [zv, sv, cv]
-        plan.add(layer.name + '/db', self.lib.seg_bias_grad, C.byref(zv), self.B, dz.H, dz.W, co, self.store.g_ptr(layer.b_off), self.dtype,
-                 kernel='bias_grad_kernel')
+        self.bias_grad(plan, layer.name + '/db', zv, dz.H, dz.W, co, layer.b_off)
         plan.add(layer.name + '/im2col', self.lib.seg_im2col_act, C.byref(zv), self.B, dz.H, dz.W, co, k, k, s_, 0, 0, C.byref(cv), Hi, Wi,
                  self.dtype, kernel='im2col_act_kernel')
         w = L.WgradDesc()
@@ -1433,6 +1432,18 @@ class Net(object):
             return
         plan.add('pack', self.lib.seg_pack_weights, s.p.data_ptr(), s.packed.data_ptr(), s.pack_table.data_ptr(),
                  s.n_pack_entries, s.pack_blocks, self.dtype, **meta)
+
+    def bias_grad(self, plan, name, zv, H, W, n_log, b_off):
+        """BiasAddGrad of a tensor view as a launch of its own: two-stage (512 partial rows + a fixed-order final pass) on maps of
+        >= 64 k pixels, where the one-workgroup-per-8-channels kernel is a handful of workgroups (51 -> ~15 us at 256^2 x 16 x 32)"""
+        nb = int(self.lib.seg_bias_grad_ws_bytes(zv.c))
+        if nb and self.B * H * W >= 65536:
+            ws = torch.empty(nb // 4, dtype=torch.float32, device=self.device)
+            plan.keep.append(ws)
+            plan.add(name, self.lib.seg_bias_grad_ws, C.byref(zv), self.B, H, W, n_log, self.store.g_ptr(b_off), ws.data_ptr(), nb, self.dtype,
+                     kernel='bias_grad_partial_kernel')
+        else:
+            plan.add(name, self.lib.seg_bias_grad, C.byref(zv), self.B, H, W, n_log, self.store.g_ptr(b_off), self.dtype, kernel='bias_grad_kernel')
 
     def dp_marker(self, plan, kind, **kw):
         """data-parallel marker: 'bucket' (lo, hi: this slice of the gradient arena is complete once everything in front of the

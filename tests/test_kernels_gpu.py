@@ -192,6 +192,36 @@ def test_conv_split_k(dtype, case):
 
 
 @pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('C_,nlog,H,W,B', [(32, 32, 190, 177, 2), (64, 40, 130, 257, 2), (8, 2, 300, 220, 1), (128, 128, 96, 96, 8)])
+def test_bias_grad_two_stage(dtype, C_, nlog, H, W, B):
+    """seg_bias_grad_ws (512 partial rows + a fixed-order final pass) against the column sums and the one-stage kernel;
+    bitwise reproducible from run to run"""
+    rng = np.random.default_rng(C_ + H)
+    layer = E.Layer('c', 'conv', 1, [32], 32, 'VALID', True)
+    net = E.Net(U.make_store([layer], dtype, {'c': _rand_params(layer, rng, dtype)}), B, dtype, U.dev())
+    a = net.act(H, W, nlog, thin=(C_ == 8)) if C_ in (8,) else net.act(H, W, C_)
+    v = U.round_dtype(rng.standard_normal((B, H, W, nlog)), dtype)
+    U.fill_act(a, v)
+    lib = L.load()
+    zv = a.view()
+    nb = int(lib.seg_bias_grad_ws_bytes(zv.c))
+    assert nb == 512 * zv.c * 4
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=U.dev())
+    db = torch.full((zv.c,), float('nan'), dtype=torch.float32, device=U.dev())
+    L.check(lib.seg_bias_grad_ws(C.byref(zv), B, H, W, nlog, db.data_ptr(), ws.data_ptr(), nb, dtype, U.stream()), 'bias_grad_ws'); U.sync()
+    want = v.reshape(-1, nlog).sum(0)
+    got = db[:nlog].cpu().numpy().astype(np.float64)
+    assert np.abs(got - want).max() < 2e-4 * np.abs(v).sum(axis=(0, 1, 2)).max()
+    first = db[:nlog].clone()
+    ws.fill_(float('nan')); db.fill_(float('nan'))
+    L.check(lib.seg_bias_grad_ws(C.byref(zv), B, H, W, nlog, db.data_ptr(), ws.data_ptr(), nb, dtype, U.stream()), 'bias_grad_ws'); U.sync()
+    assert torch.equal(db[:nlog], first)
+    db1 = torch.zeros(zv.c, dtype=torch.float32, device=U.dev())
+    L.check(lib.seg_bias_grad(C.byref(zv), B, H, W, nlog, db1.data_ptr(), dtype, U.stream()), 'bias_grad'); U.sync()
+    assert np.abs(db1[:nlog].cpu().numpy() - got).max() < 2e-4 * np.abs(v).sum(axis=(0, 1, 2)).max()
+
+
+@pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('nc,H,W,B', [(2, 19, 23, 2), (5, 12, 40, 3), (8, 33, 9, 1)])
 def test_thin_tensors_through_the_mfma_kernels(dtype, nc, H, W, B):
     """<= 8-channel tensors at a channel stride of 8 (engine.Act(thin=True)): a 2x2/s2 transposed conv INTO a thin tensor, a 3x3
