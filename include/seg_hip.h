@@ -255,6 +255,13 @@ int seg_sigmoid_argmax(const seg_view* logits, int32_t B, int32_t H, int32_t W, 
 /* BiasAddGrad: db[c] = sum over B*H*W of dz[...,c] for c < n_log (overwritten; one workgroup per 8 channels, fixed order). */
 int seg_bias_grad(const seg_view* dz, int32_t B, int32_t H, int32_t W, int32_t n_log, float* db,
                   int32_t dtype, void* stream);
+/* 3x3 / stride-1 convolution between THIN tensors (<= 8 channels, cs == 8, coff == 0: seg_conv_desc.thin_src) on the vector ALU:
+ * dst = relu?(bias + conv(src, w_hwio[3][3][cin][cout])) with `pad` zeros around the input (Ho = Hi + 2 pad - 2), float output
+ * when out_f32; dgrad != 0: the data gradient of that layer instead -- src is dZ [.., cout], dst is dX [.., cin], pad is
+ * 2 - (the layer's pad), mask (nullable) the layer input's ReLU output.  The DeconvModel's conv_out (models/deconvolution.py:170). */
+int seg_thin_conv3x3(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, const float* w_hwio, const float* bias, int32_t cin,
+                     int32_t cout, int32_t pad, int32_t relu, int32_t dgrad, const seg_view* mask, const seg_view* dst, int32_t Ho,
+                     int32_t Wo, int32_t out_f32, int32_t dtype, void* stream);
 /* The same in two stages for big maps (512 workgroups of partial sums + a fixed-order final pass; bitwise reproducible):
  * ws of seg_bias_grad_ws_bytes(dz->c) bytes (0: this channel count is not supported, use seg_bias_grad). */
 int64_t seg_bias_grad_ws_bytes(int32_t C);

@@ -1171,6 +1171,102 @@ extern "C" int seg_sigmoid_argmax(const seg_view* logits, int32_t B, int32_t H, 
   return seg_check_launch("sigmoid_argmax");
 }
 
+// ------------------------------------------------------------------------------------------
+// 3x3 / stride-1 convolution of THIN tensors (<= 8 channels at a channel stride of 8; engine.Act(thin=True)) on the vector ALU:
+// the DeconvModel's conv_out (n_classes -> n_classes at full resolution, models/deconvolution.py:170).  On the MFMA kernels the
+// layer is 32 x 32 padded channels of matrix work for 2 x 2 real ones (146 us forward, 207 us data gradient at 512^2 x 16); here a
+// thread owns an output pixel, reads its nine 16-byte neighbours and runs NC x NC x 9 FMAs -- HBM-bound (one read + one write of the
+// map).  DGRAD: the same walk with the filter flipped and transposed (dX = dZ (*) rot180(W)^T), optional ReLU-grad mask.
+// ------------------------------------------------------------------------------------------
+template <typename T, int NC, bool OUT_F32>
+__global__ __launch_bounds__(256) void thin_conv3x3_kernel(seg_view src, const float* w, const float* bias, int cin, int cout, int pad, int relu,
+                                                           int dgrad, seg_view mask, seg_view dst, int B, int Ho, int Wo, int Hi, int Wi) {
+  __shared__ float sw[9 * NC * NC];          // [tap][ci][co] as THIS launch consumes it (zero above the logical counts)
+  __shared__ float sb[NC];
+  for (int i = threadIdx.x; i < 9 * NC * NC; i += 256) {
+    const int tap = i / (NC * NC), ci = (i / NC) % NC, co = i % NC;
+    float v = 0.f;
+    if (!dgrad) { if (ci < cin && co < cout) v = w[((int64_t)tap * cin + ci) * cout + co]; }
+    else { if (ci < cout && co < cin) v = w[((int64_t)(8 - tap) * cin + co) * cout + ci]; }      // input channel of this walk = the layer's output channel
+    sw[i] = to_f32(from_f32<T>(v));          // (the compute dtype's weight grid, as the packed MFMA operands of every other layer)
+  }
+  if (threadIdx.x < NC) sb[threadIdx.x] = (bias != nullptr && !dgrad && (int)threadIdx.x < cout) ? bias[threadIdx.x] : 0.f;
+  __syncthreads();
+  const int64_t total = (int64_t)B * Ho * Wo;
+  const T* sp = reinterpret_cast<const T*>(src.ptr);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const Idx3 q_ = split3(i, Wo, Ho);
+    float acc[NC];
+#pragma unroll
+    for (int co = 0; co < NC; ++co) acc[co] = sb[co];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int iy = q_.y - pad + u;
+      if (iy < 0 || iy >= Hi) continue;
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        const int ix = q_.x - pad + v;
+        if (ix < 0 || ix >= Wi) continue;
+        Vec8<T> xv;
+        xv.load(sp + view_off(src, q_.b, iy, ix));
+        const float* wt = sw + (u * 3 + v) * NC * NC;
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) {
+          const float xf = xv.get(ci);
+#pragma unroll
+          for (int co = 0; co < NC; ++co) acc[co] = fmaf(xf, wt[ci * NC + co], acc[co]);
+        }
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int co = 0; co < NC; ++co) acc[co] = fmaxf(acc[co], 0.f);
+    }
+    if (mask.ptr != nullptr) {
+      Vec8<T> mv;
+      mv.load(reinterpret_cast<const T*>(mask.ptr) + view_off(mask, q_.b, q_.y, q_.x));
+#pragma unroll
+      for (int co = 0; co < NC; ++co) acc[co] = mv.get(co) > 0.f ? acc[co] : 0.f;
+    }
+    const int64_t doff = view_off(dst, q_.b, q_.y, q_.x);
+    if (OUT_F32) {
+      Vec8<float> o; o.zero();
+#pragma unroll
+      for (int co = 0; co < NC; ++co) o.set(co, acc[co]);
+      o.store(reinterpret_cast<float*>(dst.ptr) + doff);
+    } else {
+      Vec8<T> o; o.zero();
+#pragma unroll
+      for (int co = 0; co < NC; ++co) o.set(co, acc[co]);
+      o.store(reinterpret_cast<T*>(dst.ptr) + doff);
+    }
+  }
+}
+
+extern "C" int seg_thin_conv3x3(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, const float* w_hwio, const float* bias, int32_t cin,
+                                int32_t cout, int32_t pad, int32_t relu, int32_t dgrad, const seg_view* mask, const seg_view* dst, int32_t Ho,
+                                int32_t Wo, int32_t out_f32, int32_t dtype, void* stream) {
+  const int ci_w = dgrad ? cout : cin, co_w = dgrad ? cin : cout;             // channels this walk reads / writes
+  if (!src || !src->ptr || !dst || !dst->ptr || !w_hwio || cin < 1 || cin > 8 || cout < 1 || cout > 8 || pad < 0 || pad > 2 || B <= 0 ||
+      src->cs != 8 || src->coff != 0 || dst->cs != 8 || dst->coff != 0 || !view_ok(dst, Ho, Wo, 8) ||
+      src->oy + Hi > src->H || src->ox + Wi > src->W || Ho != Hi + 2 * pad - 2 || Wo != Wi + 2 * pad - 2 || Ho < 1 || Wo < 1 ||
+      (mask && mask->ptr && (mask->cs != 8 || mask->coff != 0 || !view_ok(mask, Ho, Wo, 8))) || (out_f32 && dgrad)) {
+    seg_set_error("thin_conv3x3: thin views (cs 8, coff 0), 1..8 channels, Ho = Hi + 2 pad - 2"); return SEG_ERR_ARG;
+  }
+  (void)ci_w; (void)co_w;
+  const seg_view mk = (mask && mask->ptr) ? *mask : seg_view{nullptr, 0, 0, 0, 0, 0, 0, 0};
+  const int m = cin > cout ? cin : cout;
+  const int g = grid_for((int64_t)B * Ho * Wo, 256, 16384);
+#define TC_ARGS dim3(g), dim3(256), 0, ST(stream), *src, w_hwio, bias, cin, cout, pad, relu, dgrad, mk, *dst, B, Ho, Wo, Hi, Wi
+#define TC_NC(TT, F32) do { if (m <= 2) SEG_LAUNCH((thin_conv3x3_kernel<TT, 2, F32>), TC_ARGS); \
+    else if (m <= 4) SEG_LAUNCH((thin_conv3x3_kernel<TT, 4, F32>), TC_ARGS); else SEG_LAUNCH((thin_conv3x3_kernel<TT, 8, F32>), TC_ARGS); } while (0)
+  if (out_f32) { DISPATCH(dtype, TC_NC(float, true), TC_NC(bf16_t, true)); }
+  else { DISPATCH(dtype, TC_NC(float, false), TC_NC(bf16_t, false)); }
+#undef TC_NC
+#undef TC_ARGS
+  return seg_check_launch("thin_conv3x3");
+}
+
 // Two-stage form for the big maps (the one-workgroup-per-8-channels kernel above is 4 workgroups for a 32-channel tensor: 51 us
 // for 67 MB at 256^2 x 16): BG_NB workgroups sum whole pixels (all channel groups, consecutive lanes = consecutive 16-byte
 // pieces) into one row of partial sums each, a second launch adds the rows in a fixed order.

@@ -692,6 +692,17 @@ class Net(object):
         self.pool_fused = False
         k, pad = layer.k, layer.pad
         Ho, Wo = Hi + 2 * pad - k + 1, Wi + 2 * pad - k + 1
+        if (k == 3 and len(srcs) == 1 and srcs[0][0].thin and dst.thin and pool is None and dst_off == (0, 0) and srcs[0][1:] == (0, 0)
+                and layer.cin <= 8 and layer.cout <= 8 and os.environ.get('SEG_THIN_VALU', '1') != '0'):
+            # thin -> thin: the vector-ALU kernel (seg_thin_conv3x3) instead of 32 x 32 padded channels of MFMA work
+            sv, dv = srcs[0][0].view(), dst.view()
+            plan.keep += [sv, dv]
+            fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
+            plan.add(layer.name, self.lib.seg_thin_conv3x3, C.byref(sv), self.B, Hi, Wi, self.store.p_ptr(layer.w_off), self.store.p_ptr(layer.b_off),
+                     layer.cin, layer.cout, pad, 1 if layer.relu else 0, 0, None, C.byref(dv), Ho, Wo, 1 if out_f32 else 0, self.dtype,
+                     kernel='thin_conv3x3_kernel', flops=fl, bytes=self.B * (Hi * Wi + Ho * Wo) * 8 * (self.es if not out_f32 else (self.es + 4) // 2))
+            plan.flops += fl
+            return Ho, Wo
         d = L.ConvDesc()
         d.src0 = srcs[0][0].view_wide(srcs[0][1], srcs[0][2])
         d.src1 = srcs[1][0].view_wide(srcs[1][1], srcs[1][2]) if len(srcs) > 1 else L.null_view()
@@ -970,6 +981,18 @@ class Net(object):
         for i, ds in enumerate(dsrcs):
             if ds is not None:
                 dst, doff, mask, moff = ds[:4]
+                if (k == 3 and dz.thin and dst.thin and dz_off == (0, 0) and doff == (0, 0) and moff == (0, 0) and len(srcs) == 1 and not (len(ds) > 4 and ds[4])
+                        and layer.cin <= 8 and layer.cout <= 8 and (mask is None or mask.thin) and os.environ.get('SEG_THIN_VALU', '1') != '0'):
+                    zv2, xv2 = dz.view(), dst.view()
+                    mv2 = mask.view() if mask is not None else None
+                    plan.keep += [zv2, xv2] + ([mv2] if mv2 is not None else [])
+                    fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
+                    plan.add(layer.name + '/dx%d' % i, self.lib.seg_thin_conv3x3, C.byref(zv2), self.B, Ho, Wo, self.store.p_ptr(layer.w_off), None,
+                             layer.cin, layer.cout, k - 1 - pad, 0, 1, C.byref(mv2) if mv2 is not None else None, C.byref(xv2), Hi, Wi, 0, self.dtype,
+                             kernel='thin_conv3x3_kernel', flops=fl, bytes=self.B * (Hi * Wi + Ho * Wo) * 8 * self.es)
+                    plan.flops += fl
+                    n_off += layer.cin_p[i]
+                    continue
                 d = L.ConvDesc()
                 d.accum = 1 if (len(ds) > 4 and ds[4]) else 0
                 d.src0 = dz.view_wide(dz_off[0], dz_off[1]); d.src1 = L.null_view()

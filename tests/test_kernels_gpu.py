@@ -222,11 +222,14 @@ def test_bias_grad_two_stage(dtype, C_, nlog, H, W, B):
 
 
 @pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('valu', ['1', '0'])
 @pytest.mark.parametrize('nc,H,W,B', [(2, 19, 23, 2), (5, 12, 40, 3), (8, 33, 9, 1)])
-def test_thin_tensors_through_the_mfma_kernels(dtype, nc, H, W, B):
+def test_thin_tensors_through_the_mfma_kernels(dtype, nc, H, W, B, valu, monkeypatch):
     """<= 8-channel tensors at a channel stride of 8 (engine.Act(thin=True)): a 2x2/s2 transposed conv INTO a thin tensor, a 3x3
     SAME conv FROM a thin tensor into a thin float tensor, and every gradient of both (thin dZ, thin sources, thin data-gradient
-    destinations with a thin ReLU mask) against the oracle -- the DeconvModel's deconv3_0 / conv_out tail."""
+    destinations with a thin ReLU mask) against the oracle -- the DeconvModel's deconv3_0 / conv_out tail.  valu '1': the 3x3
+    convolution and its data gradient on the vector-ALU kernel (seg_thin_conv3x3, the default); '0': on the MFMA kernels."""
+    monkeypatch.setenv('SEG_THIN_VALU', valu)
     rng = np.random.default_rng(nc * 100 + H)
     up = E.Layer('u', 'up', 2, [32], nc, 'VALID', True)
     cv = E.Layer('c', 'conv', 3, [nc], nc, 'SAME', False)
@@ -243,6 +246,7 @@ def test_thin_tensors_through_the_mfma_kernels(dtype, nc, H, W, B):
     plan = E.Plan('t')
     net.up_fwd(plan, up, x, H, W, a)
     net.conv_fwd(plan, cv, [(a, 0, 0)], 2 * H, 2 * W, lg, out_f32=True)
+    assert plan.meta[1]['kernel' if valu == '1' else 'desc'] is not None and (plan.meta[1].get('kernel') == 'thin_conv3x3_kernel') == (valu == '1')
     plan.run(U.stream()); U.sync()
     a_ref = ops.conv2d_transpose(xs, p['u']['weights'], p['u']['biases'], stride=2, padding='VALID', relu=True)
     assert U.rel_err(U.read_act(a), a_ref) < U.tol(dtype)

@@ -22,6 +22,9 @@ kw = dict(sess=None, dataset=ds, n_classes=a.classes, input_dims=a.size, log_dir
 if a.model == 'unet':
     from segmentation_amd.unet import UNetModel
     m = UNetModel(**kw)
+elif a.model == 'deconv':
+    from segmentation_amd.deconvolution import DeconvModel
+    m = DeconvModel(**kw)
 else:
     from segmentation_amd.fcn import FCNModel
     m = FCNModel(fcn_type=a.model[3:], **kw)
