@@ -262,6 +262,11 @@ int seg_bias_grad(const seg_view* dz, int32_t B, int32_t H, int32_t W, int32_t n
 int seg_thin_conv3x3(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, const float* w_hwio, const float* bias, int32_t cin,
                      int32_t cout, int32_t pad, int32_t relu, int32_t dgrad, const seg_view* mask, const seg_view* dst, int32_t Ho,
                      int32_t Wo, int32_t out_f32, int32_t dtype, void* stream);
+/* 2x2 / stride-2 transposed convolution from a [H,W,cin] tensor INTO a thin [2H,2W,cout <= 8] tensor (dgrad == 0: `big` written,
+ * bias + optional ReLU) and its data gradient (dgrad != 0: `small` written from the thin gradient `big`, optional ReLU-grad mask
+ * over `small`'s layout), filter in the TF layout [2,2,cout,cin] -- the DeconvModel's deconv3_0 on the vector ALU. */
+int seg_thin_up2x2(const seg_view* small, const seg_view* big, int32_t B, int32_t H, int32_t W, const float* w_tf, const float* bias,
+                   int32_t cin, int32_t cout, int32_t relu, int32_t dgrad, const seg_view* mask, int32_t dtype, void* stream);
 /* The same in two stages for big maps (512 workgroups of partial sums + a fixed-order final pass; bitwise reproducible):
  * ws of seg_bias_grad_ws_bytes(dz->c) bytes (0: this channel count is not supported, use seg_bias_grad). */
 int64_t seg_bias_grad_ws_bytes(int32_t C);

@@ -88,6 +88,7 @@ SIGNATURES = {
     'seg_sigmoid_argmax': [PV, i32, i32, i32, i32, vp, vp, vp],
     'seg_bias_grad': [PV, i32, i32, i32, i32, vp, i32, vp],
     'seg_bias_grad_ws': [PV, i32, i32, i32, i32, vp, vp, i64, i32, vp],
+    'seg_thin_up2x2': [PV, PV, i32, i32, i32, vp, vp, i32, i32, i32, i32, PV, i32, vp],
     'seg_thin_conv3x3': [PV, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, PV, PV, i32, i32, i32, i32, vp],
     'seg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp],
     'seg_step_increment': [vp, vp],

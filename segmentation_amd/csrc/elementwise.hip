@@ -1267,6 +1267,109 @@ extern "C" int seg_thin_conv3x3(const seg_view* src, int32_t B, int32_t Hi, int3
   return seg_check_launch("thin_conv3x3");
 }
 
+// 2x2 / stride-2 transposed convolution INTO a thin tensor and its data gradient, on the vector ALU (the DeconvModel's deconv3_0:
+// 32 -> n_classes channels, models/deconvolution.py:166): a thread owns one pixel of the SMALL map, i.e. a 2x2 block of the big one.
+//   forward : big[b, 2y+a, 2x+c, co] = relu?(bias[co] + sum_ci small[b,y,x,ci] * w[a][c][co][ci])          (TF filter [2,2,Cout,Cin])
+//   dgrad   : dsmall[b,y,x,ci] = (mask > 0) * sum_{a,c,co} dbig[b, 2y+a, 2x+c, co] * w[a][c][co][ci]
+template <typename T, int NC, bool DGRAD>
+__global__ __launch_bounds__(256) void thin_up2x2_kernel(seg_view small, seg_view big, const float* w, const float* bias, int cin, int cout,
+                                                         int relu, seg_view mask, int B, int H, int W) {
+  extern __shared__ float sw_up[];            // [tap][co < NC][ci < cp]  (zero above the logical counts), then bias[NC]
+  const int cp = small.c;                     // padded input channels of the layer (a multiple of 8)
+  for (int i = threadIdx.x; i < 4 * NC * cp; i += 256) {
+    const int tap = i / (NC * cp), co = (i / cp) % NC, ci = i % cp;
+    const float v = (co < cout && ci < cin) ? w[((int64_t)tap * cout + co) * cin + ci] : 0.f;
+    sw_up[i] = to_f32(from_f32<T>(v));
+  }
+  float* sb = sw_up + 4 * NC * cp;
+  if (threadIdx.x < NC) sb[threadIdx.x] = (bias != nullptr && (int)threadIdx.x < cout) ? bias[threadIdx.x] : 0.f;
+  __syncthreads();
+  const int64_t total = (int64_t)B * H * W;
+  const int G = cp / 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const Idx3 q_ = split3(i, W, H);
+    const T* sp = reinterpret_cast<const T*>(small.ptr) + view_off(small, q_.b, q_.y, q_.x);
+    T* bp = reinterpret_cast<T*>(big.ptr);
+    if (!DGRAD) {
+      float acc[4][NC];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int co = 0; co < NC; ++co) acc[t][co] = sb[co];
+      for (int g = 0; g < G; ++g) {
+        Vec8<T> xv; xv.load(sp + g * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xf = xv.get(e);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int co = 0; co < NC; ++co) acc[t][co] = fmaf(xf, sw_up[(t * NC + co) * cp + g * 8 + e], acc[t][co]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        Vec8<T> o; o.zero();
+#pragma unroll
+        for (int co = 0; co < NC; ++co) o.set(co, relu ? fmaxf(acc[t][co], 0.f) : acc[t][co]);
+        o.store(bp + view_off(big, q_.b, 2 * q_.y + (t >> 1), 2 * q_.x + (t & 1)));
+      }
+    } else {
+      float z[4][NC];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        Vec8<T> zv; zv.load(bp + view_off(big, q_.b, 2 * q_.y + (t >> 1), 2 * q_.x + (t & 1)));
+#pragma unroll
+        for (int co = 0; co < NC; ++co) z[t][co] = zv.get(co);
+      }
+      T* dp = reinterpret_cast<T*>(small.ptr) + view_off(small, q_.b, q_.y, q_.x);
+      const T* mp = mask.ptr ? reinterpret_cast<const T*>(mask.ptr) + view_off(mask, q_.b, q_.y, q_.x) : nullptr;
+      for (int g = 0; g < G; ++g) {
+        float a8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float a = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int co = 0; co < NC; ++co) a = fmaf(z[t][co], sw_up[(t * NC + co) * cp + g * 8 + e], a);
+          a8[e] = a;
+        }
+        if (mp) {
+          Vec8<T> mv; mv.load(mp + g * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a8[e] = mv.get(e) > 0.f ? a8[e] : 0.f;
+        }
+        Vec8<T> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, a8[e]);
+        o.store(dp + g * 8);
+      }
+    }
+  }
+}
+
+extern "C" int seg_thin_up2x2(const seg_view* small, const seg_view* big, int32_t B, int32_t H, int32_t W, const float* w_tf, const float* bias,
+                              int32_t cin, int32_t cout, int32_t relu, int32_t dgrad, const seg_view* mask, int32_t dtype, void* stream) {
+  if (!small || !small->ptr || !big || !big->ptr || !w_tf || cin < 1 || cout < 1 || cout > 8 || B <= 0 || small->c % 8 || cin > small->c || small->c > 512 ||
+      !view_ok(small, H, W, small->c) || big->cs != 8 || big->coff != 0 || !view_ok(big, 2 * H, 2 * W, 8) ||
+      (mask && mask->ptr && (!dgrad || !view_ok(mask, H, W, small->c)))) {
+    seg_set_error("thin_up2x2: small [H,W,cin padded to 8..512], big thin [2H,2W,<= 8]; mask only with dgrad"); return SEG_ERR_ARG;
+  }
+  const seg_view mk = (mask && mask->ptr) ? *mask : seg_view{nullptr, 0, 0, 0, 0, 0, 0, 0};
+  const int g = grid_for((int64_t)B * H * W, 256, 16384);
+  const int nc = cout <= 2 ? 2 : cout <= 4 ? 4 : 8;
+  const size_t lds = (size_t)(4 * nc * small->c + nc) * sizeof(float);
+#define TU_ARGS dim3(g), dim3(256), lds, ST(stream), *small, *big, w_tf, dgrad ? (const float*)nullptr : bias, cin, cout, relu, mk, B, H, W
+#define TU_NC(TT, DG) do { if (nc == 2) SEG_LAUNCH((thin_up2x2_kernel<TT, 2, DG>), TU_ARGS); else if (nc == 4) SEG_LAUNCH((thin_up2x2_kernel<TT, 4, DG>), TU_ARGS); \
+    else SEG_LAUNCH((thin_up2x2_kernel<TT, 8, DG>), TU_ARGS); } while (0)
+  if (dgrad) { DISPATCH(dtype, TU_NC(float, true), TU_NC(bf16_t, true)); }
+  else { DISPATCH(dtype, TU_NC(float, false), TU_NC(bf16_t, false)); }
+#undef TU_NC
+#undef TU_ARGS
+  return seg_check_launch("thin_up2x2");
+}
+
 // Two-stage form for the big maps (the one-workgroup-per-8-channels kernel above is 4 workgroups for a 32-channel tensor: 51 us
 // for 67 MB at 256^2 x 16): BG_NB workgroups sum whole pixels (all channel groups, consecutive lanes = consecutive 16-byte
 // pieces) into one row of partial sums each, a second launch adds the rows in a fixed order.

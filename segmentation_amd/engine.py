@@ -746,6 +746,16 @@ class Net(object):
         return Ho, Wo
 
     def up_fwd(self, plan, layer, src, Hi, Wi, dst, cfg=0):
+        if dst.thin and not src.thin and layer.cout <= 8 and os.environ.get('SEG_THIN_VALU', '1') != '0':
+            # into a thin tensor: the vector-ALU kernel (a thread per input pixel writes its 2x2 block of <= 8-channel records)
+            sv, dv = src.view(), dst.view()
+            plan.keep += [sv, dv]
+            fl = 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
+            plan.add(layer.name, self.lib.seg_thin_up2x2, C.byref(sv), C.byref(dv), self.B, Hi, Wi, self.store.p_ptr(layer.w_off), self.store.p_ptr(layer.b_off),
+                     layer.cin, layer.cout, 1 if layer.relu else 0, 0, None, self.dtype, kernel='thin_up2x2_kernel', flops=fl,
+                     bytes=self.B * Hi * Wi * (src.Cp + 4 * 8) * self.es)
+            plan.flops += fl
+            return
         d = L.ConvDesc()
         d.src0 = src.view(); d.src1 = L.null_view()
         d.B, d.Hi, d.Wi = self.B, Hi, Wi
@@ -1034,7 +1044,15 @@ class Net(object):
         self._wg_bytes = self.B * Hi * Wi * (layer.cin + 4 * layer.cout) * self.es + 4 * layer.cin * layer.cout * 4
         self._add_wgrad(plan, layer.name + '/dw', w, fl)
         plan.flops += fl
-        if dsrc is not None:
+        if dsrc is not None and dzu.thin and not dsrc.thin and layer.cout <= 8 and os.environ.get('SEG_THIN_VALU', '1') != '0':
+            xv, zv_ = dsrc.view(), dzu.view()
+            mv = mask.view() if mask is not None else None
+            plan.keep += [xv, zv_] + ([mv] if mv is not None else [])
+            plan.add(layer.name + '/dx', self.lib.seg_thin_up2x2, C.byref(xv), C.byref(zv_), self.B, Hi, Wi, self.store.p_ptr(layer.w_off), None,
+                     layer.cin, layer.cout, 0, 1, C.byref(mv) if mv is not None else None, self.dtype, kernel='thin_up2x2_kernel', flops=fl,
+                     bytes=self.B * Hi * Wi * (dsrc.Cp * (2 if mask is not None else 1) + 4 * 8) * self.es)
+            plan.flops += fl
+        elif dsrc is not None:
             d = L.ConvDesc()
             d.src0 = dzu.view_wide(); d.src1 = L.null_view()
             d.thin_src = 1 if dzu.thin else 0
