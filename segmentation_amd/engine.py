@@ -1476,9 +1476,9 @@ class Net(object):
 
     def bias_grad(self, plan, name, zv, H, W, n_log, b_off):
         """BiasAddGrad of a tensor view as a launch of its own: two-stage (512 partial rows + a fixed-order final pass) on maps of
-        >= 64 k pixels, where the one-workgroup-per-8-channels kernel is a handful of workgroups (51 -> ~15 us at 256^2 x 16 x 32)"""
+        >= 8 k pixels, where the one-workgroup-per-8-channels kernel is a handful of workgroups (51 -> ~15 us at 256^2 x 16 x 32)"""
         nb = int(self.lib.seg_bias_grad_ws_bytes(zv.c))
-        if nb and self.B * H * W >= 65536:
+        if nb and self.B * H * W >= 8192:
             ws = torch.empty(nb // 4, dtype=torch.float32, device=self.device)
             plan.keep.append(ws)
             plan.add(name, self.lib.seg_bias_grad_ws, C.byref(zv), self.B, H, W, n_log, self.store.g_ptr(b_off), ws.data_ptr(), nb, self.dtype,
