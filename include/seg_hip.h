@@ -230,6 +230,11 @@ int seg_softmax_xent(const seg_view* logits, const uint8_t* labels, int32_t LH, 
                      int32_t ly0, int32_t lx0, int32_t B, int32_t H, int32_t W, int32_t n_classes,
                      float inv_n, float grad_scale, float* loss_sum, const seg_view* dlogits,
                      int32_t dtype, void* stream);
+/* The same launch also writing softmax(logits) as a tensor of the compute dtype (probs; NULL: seg_softmax_xent): the adversary's
+ * "fake" input (models/basemodel.py:285) without a second pass over the float logits. */
+int seg_softmax_xent_probs(const seg_view* logits, const uint8_t* labels, int32_t LH, int32_t LW, int32_t ly0, int32_t lx0,
+                           int32_t B, int32_t H, int32_t W, int32_t n_classes, float inv_n, float grad_scale, float* loss_sum,
+                           const seg_view* dlogits, const seg_view* probs, int32_t dtype, void* stream);
 
 /* Fused U-Net training head: the 1x1 'output' convolution (models/unet.py:166; float32 logits), the per-pixel softmax
  * cross-entropy + gradient above, and the 1x1 convolution's input gradient masked by its input's ReLU (dact), in one

@@ -83,6 +83,7 @@ SIGNATURES = {
     'seg_maxpool2x2_fwd': [PV, PV, vp, i32, i32, i32, i32, i32, vp],
     'seg_maxpool2x2_bwd': [PV, PV, PV, i32, i32, i32, i32, PV, i32, i32, i32, i32, i32, vp],
     'seg_softmax_xent': [PV, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, PV, i32, vp],
+    'seg_softmax_xent_probs': [PV, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp, PV, PV, i32, vp],
     'seg_head_xent': [PV, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, PV, PV, PV, vp, i64, i32, vp],
     'seg_head_dw_reduce': [vp, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     'seg_sigmoid_argmax': [PV, i32, i32, i32, i32, vp, vp, vp],

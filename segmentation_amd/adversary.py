@@ -221,7 +221,7 @@ class Adversary(object):
         plan.add('adv_bce[%d]' % slot, self.lib.seg_bce2, C.byref(lv), self.B, label, 1.0, self.losses.data_ptr() + 4 * slot, C.byref(dv), self.dtype,
                  kernel='bce2_kernel')
 
-    def emit(self, plan, logits, labels_u8, LH, LW, loff, dlogits):
+    def emit(self, plan, logits, labels_u8, LH, LW, loff, dlogits, probs_given=False):
         """Appends the adversary's part of a train step to `plan`, behind the x-entropy launch that filled `dlogits`:
         real / fake maps, the forward pass of both, the adversary's own gradients (into its arena), and
         dlogits += lambda * d l_bce_fake_one / d logits."""
@@ -231,7 +231,8 @@ class Adversary(object):
         rv, fv, lv = H2[0]['x'].view(), H2[1]['x'].view(), logits.view()
         plan.keep += [rv, fv, lv]
         plan.add('adv_onehot', self.lib.seg_onehot, labels_u8.data_ptr(), LH, LW, loff[0], loff[1], B, h, w, C.byref(rv), self.dtype, kernel='onehot_kernel')
-        plan.add('adv_softmax', self.lib.seg_softmax_probs, C.byref(lv), B, h, w, self.nc, C.byref(fv), self.dtype, kernel='softmax_probs_kernel')
+        if not probs_given:              # (else the x-entropy launch has written softmax(logits) into the fake half already)
+            plan.add('adv_softmax', self.lib.seg_softmax_probs, C.byref(lv), B, h, w, self.nc, C.byref(fv), self.dtype, kernel='softmax_probs_kernel')
         # forward, 2B images at once; batch norms per half (real first: the order the moving averages see, basemodel.py:283-285)
         n2.resize_fwd(plan, A['x'], A['r'])
         if self.sconv:

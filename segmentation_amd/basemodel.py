@@ -466,16 +466,25 @@ class BaseModel(object):
         v = float(self.loss_buf.item())
         return v / self.pg.world if getattr(self, '_loss_is_sum', False) else v
 
-    def _attach_adversary(self, logits, oh, ow, LH, LW, dlogits):
-        """adversarial_training: builds the adversary and its plan (forward on one_hot(labels) and softmax(logits), its own
-        gradients, and the adversarial term of the segmentation gradient added into `dlogits`).  The plan runs between the
-        x-entropy launch (end of the forward plan) and the output layer's backward: _finish_training_plans puts it at the head
-        of the first backward segment, so the forward plan alone -- test() -- leaves the adversary untouched."""
+    def _make_adversary(self, oh, ow, dlogits):
+        """adversarial_training: the adversary itself; returns the view its "fake" half reads softmax(logits) from when the
+        x-entropy launch is to write it (SEG_ADV_FUSE_PROBS=0: the adversary's own softmax launch), else None."""
         from .adversary import Adversary
         self.adversary = Adversary(self.batch_size, oh, ow, self.n_classes, self.dtype, self.device, self.store.step.data_ptr() + 8,
                                    lr=self.adversarial_lr, lam=self.adv_lambda, seed=self.seed + 2222, thin=bool(getattr(dlogits, 'thin', False)))
+        self._adv_probs_fused = os.environ.get('SEG_ADV_FUSE_PROBS', '1') != '0'
+        return self.adversary.half[1]['x'].view() if self._adv_probs_fused else None
+
+    def _attach_adversary(self, logits, oh, ow, LH, LW, dlogits):
+        """Builds the adversary's plan (forward on one_hot(labels) and softmax(logits), its own gradients, and the adversarial
+        term of the segmentation gradient added into `dlogits`).  The plan runs between the x-entropy launch (end of the
+        forward plan) and the output layer's backward: _finish_training_plans puts it at the head of the first backward
+        segment, so the forward plan alone -- test() -- leaves the adversary's parameters untouched."""
+        if self.adversary is None:
+            self._make_adversary(oh, ow, dlogits)
+            self._adv_probs_fused = False
         self.adv_plan = E.Plan('adversary')
-        self.adversary.emit(self.adv_plan, logits, self.input_y, LH, LW, self.label_off, dlogits)
+        self.adversary.emit(self.adv_plan, logits, self.input_y, LH, LW, self.label_off, dlogits, probs_given=self._adv_probs_fused)
 
     def last_losses(self):
         """The scalars the reference writes as summaries (models/basemodel.py:299-301,347-351), of the most recent train_step."""

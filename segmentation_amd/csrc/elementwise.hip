@@ -225,7 +225,7 @@ __global__ void dropout_kernel(seg_view xin, seg_view yout, int B, int H, int W,
 // ------------------------------------------------------------------------------------------
 template <typename T, int NCP>     // NCP = classes rounded up to 4/8/16/32: bounds every unrolled loop
 __global__ void softmax_xent_kernel(seg_view lg, const uint8_t* labels, int LH, int LW, int ly0, int lx0, int B, int H, int W,
-                                    int nc, float inv_n, float gscale, float* loss_sum, seg_view dl) {
+                                    int nc, float inv_n, float gscale, float* loss_sum, seg_view dl, seg_view pr) {
   const int64_t total = (int64_t)B * H * W;
   float local = 0.f;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -264,6 +264,20 @@ __global__ void softmax_xent_kernel(seg_view lg, const uint8_t* labels, int LH, 
         ov.set(e, gv);
       }
       ov.store(o + c8 * 8);
+    }
+    if (pr.ptr != nullptr) {                 // (adversarial training: the class probabilities the adversary reads, from the same pass)
+      T* po = reinterpret_cast<T*>(pr.ptr) + view_off(pr, b, y, x);
+#pragma unroll
+      for (int c8 = 0; c8 < 4; ++c8) {
+        if (c8 * 8 >= pr.c) break;
+        Vec8<T> ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = c8 * 8 + e;
+          ov.set(e, c < NCP ? zv[c < NCP ? c : 0] * rs : 0.f);
+        }
+        ov.store(po + c8 * 8);
+      }
     }
   }
   // one atomic per block (hundreds of waves adding to one address serialise at the memory side: ~20 us measured)
@@ -1075,9 +1089,19 @@ extern "C" int seg_dropout_step(const seg_view* x, const seg_view* y, int32_t B,
   return dropout_launch(x, y, B, H, W, C, keep, seed, offset, step_dev, dtype, stream);
 }
 
+extern "C" int seg_softmax_xent_probs(const seg_view* logits, const uint8_t* labels, int32_t LH, int32_t LW, int32_t ly0, int32_t lx0,
+                                      int32_t B, int32_t H, int32_t W, int32_t n_classes, float inv_n, float grad_scale, float* loss_sum,
+                                      const seg_view* dlogits, const seg_view* probs, int32_t dtype, void* stream);
 extern "C" int seg_softmax_xent(const seg_view* logits, const uint8_t* labels, int32_t LH, int32_t LW, int32_t ly0, int32_t lx0,
                                 int32_t B, int32_t H, int32_t W, int32_t n_classes, float inv_n, float grad_scale, float* loss_sum,
                                 const seg_view* dlogits, int32_t dtype, void* stream) {
+  return seg_softmax_xent_probs(logits, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, grad_scale, loss_sum, dlogits, nullptr, dtype, stream);
+}
+extern "C" int seg_softmax_xent_probs(const seg_view* logits, const uint8_t* labels, int32_t LH, int32_t LW, int32_t ly0, int32_t lx0,
+                                      int32_t B, int32_t H, int32_t W, int32_t n_classes, float inv_n, float grad_scale, float* loss_sum,
+                                      const seg_view* dlogits, const seg_view* probs, int32_t dtype, void* stream) {
+  if (probs && probs->ptr && (!view_ok(probs, H, W, probs->c) || probs->c % 8 || probs->c > 32 || n_classes > probs->c)) { seg_set_error("softmax_xent: bad probs view"); return SEG_ERR_ARG; }
+  const seg_view prv = (probs && probs->ptr) ? *probs : seg_view{nullptr, 0, 0, 0, 0, 0, 0, 0};
   if (!logits || !logits->ptr || !labels || !loss_sum || !view_ok(dlogits, H, W, dlogits ? dlogits->c : 0)) { seg_set_error("softmax_xent: bad args"); return SEG_ERR_ARG; }
   if (n_classes < 1 || n_classes > 32 || n_classes > dlogits->c || dlogits->c % 8 || dlogits->c > 32) { seg_set_error("softmax_xent: n_classes %d unsupported (1..32)", n_classes); return SEG_ERR_UNSUPPORTED; }
   if (ly0 < 0 || lx0 < 0 || ly0 + H > LH || lx0 + W > LW) { seg_set_error("softmax_xent: label window out of range"); return SEG_ERR_ARG; }
@@ -1089,7 +1113,7 @@ extern "C" int seg_softmax_xent(const seg_view* logits, const uint8_t* labels, i
   }
   const int64_t n = (int64_t)B * H * W;
   const int g = grid_for(n, 256, 1024);
-#define XENT_ARGS dim3(g), dim3(256), 0, ST(stream), *logits, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, grad_scale, loss_sum, *dlogits
+#define XENT_ARGS dim3(g), dim3(256), 0, ST(stream), *logits, labels, LH, LW, ly0, lx0, B, H, W, n_classes, inv_n, grad_scale, loss_sum, *dlogits, prv
 #define XENT_NCP(TT) do { if (n_classes <= 4) SEG_LAUNCH((softmax_xent_kernel<TT, 4>), XENT_ARGS); \
     else if (n_classes <= 8) SEG_LAUNCH((softmax_xent_kernel<TT, 8>), XENT_ARGS); \
     else if (n_classes <= 16) SEG_LAUNCH((softmax_xent_kernel<TT, 16>), XENT_ARGS); \

@@ -1411,10 +1411,17 @@ class Net(object):
         plan.add('cast_pad', self.lib.seg_cast_pad, x_f32.data_ptr(), self.B * dst.H * dst.W, dst.C, C.byref(dv), self.dtype, kernel='cast_pad_kernel')
 
     # ---------------- loss / outputs / update ----------------
-    def softmax_xent(self, plan, logits, labels_u8, LH, LW, loff, H, W, n_classes, loss_buf, dlogits):
+    def softmax_xent(self, plan, logits, labels_u8, LH, LW, loff, H, W, n_classes, loss_buf, dlogits, probs=None):
+        """probs (a view of the compute dtype, adversarial training): softmax(logits) leaves the same launch as a tensor -- the
+        adversary's "fake" input (models/basemodel.py:285)."""
         lv, dv = logits.view(), dlogits.view()
         plan.keep += [lv, dv]
         inv_n = 1.0 / float(self.B * H * W)
+        if probs is not None:
+            plan.keep.append(probs)
+            plan.add('xent+probs', self.lib.seg_softmax_xent_probs, C.byref(lv), labels_u8.data_ptr(), LH, LW, loff[0], loff[1], self.B, H, W,
+                     n_classes, inv_n, 1.0, loss_buf.data_ptr(), C.byref(dv), C.byref(probs), self.dtype, kernel='softmax_xent_kernel')
+            return
         plan.add('xent', self.lib.seg_softmax_xent, C.byref(lv), labels_u8.data_ptr(), LH, LW, loff[0], loff[1], self.B, H, W,
                  n_classes, inv_n, 1.0, loss_buf.data_ptr(), C.byref(dv), self.dtype, kernel='softmax_xent_kernel')
 

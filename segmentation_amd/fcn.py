@@ -189,7 +189,8 @@ class FCNModel(BaseModel):
             net.bilinear_xent(fwd, src, src.H, src.W, geo['final'][1], self._filt(geo['final'][1]), self.input_y, H, W, (0, 0), H, W, nc,
                               self.loss_buf, dlog, logits=A.get('logits'))
         else:
-            net.softmax_xent(fwd, A['logits'], self.input_y, H, W, (0, 0), H, W, nc, self.loss_buf, dlog)
+            probs = self._make_adversary(H, W, dlog) if self.adversarial_training else None
+            net.softmax_xent(fwd, A['logits'], self.input_y, H, W, (0, 0), H, W, nc, self.loss_buf, dlog, probs=probs)
         if self.adversarial_training:
             self._attach_adversary(A['logits'], H, W, H, W, dlog)
         self.dlogits = dlog

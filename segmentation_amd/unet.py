@@ -241,7 +241,8 @@ class UNetModel(BaseModel):
             head_ws = net.head_xent(fwd, Ly['output'], a92, self.input_y, H, W, self.label_off, oh, ow, self.n_classes, self.loss_buf,
                                     A['logits'], dlog, G['conv9_2'], fuse_dw=os.environ.get('SEG_FUSE_HEAD_DW', '1') != '0')
         else:
-            net.softmax_xent(fwd, A['logits'], self.input_y, H, W, self.label_off, oh, ow, self.n_classes, self.loss_buf, dlog)
+            probs = self._make_adversary(oh, ow, dlog) if self.adversarial_training else None
+            net.softmax_xent(fwd, A['logits'], self.input_y, H, W, self.label_off, oh, ow, self.n_classes, self.loss_buf, dlog, probs=probs)
         if self.adversarial_training:
             self._attach_adversary(A['logits'], oh, ow, H, W, dlog)
         self.dlogits = dlog
