@@ -177,6 +177,12 @@ int seg_wgrad_reduce_batch(const void* jobs_dev, int32_t njobs, int32_t total_bl
 int seg_conv_first_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin,
                        const float* w_hwio, const float* bias, int32_t cout, int32_t pad,
                        const seg_view* dst, int32_t Ho, int32_t Wo, int32_t relu, int32_t dtype, void* stream);
+/* A small KH x KW filter at any stride on the raw image in one pass (bf16, cin <= 3, cout <= 64; 5x5/s2, 3x3/s1, 3x3/s2, 7x7/s2
+ * are instantiated): slim.convolution2d(images, n_kernels, 5, 2, padding='SAME') of models/deconvolution.py:44-46 without the
+ * im2col tensor.  pad_t / pad_l: the leading pads (TF SAME: total // 2); w_hwio float32 [KH][KW][cin][cout]. */
+int seg_conv_first_gen(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const float* w_hwio, const float* bias,
+                       int32_t cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad_t, int32_t pad_l, const seg_view* dst,
+                       int32_t Ho, int32_t Wo, int32_t relu, int32_t dtype, void* stream);
 
 /* Same layer fused with the 2x2/s2 VALID max-pool that consumes it (models/unet.py pool1 over conv1_1, models/fcn.py:116
  * pool1 over conv1): one pass writes the activation and its pooled map [Hp = Ho/2, Wp = Wo/2].  bf16, cin <= 3, cout <= 64. */

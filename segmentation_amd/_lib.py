@@ -75,6 +75,7 @@ SIGNATURES = {
     'seg_wgrad_reduce_batch_plan': [C.POINTER(C.POINTER(WgradDesc)), i32, vp, i64, C.POINTER(i32), C.POINTER(i32)],
     'seg_wgrad_reduce_batch': [vp, i32, i32, vp],
     'seg_conv_first_fwd': [vp, i32, i32, i32, i32, vp, vp, i32, i32, PV, i32, i32, i32, i32, vp],
+    'seg_conv_first_gen': [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, PV, i32, i32, i32, i32, vp],
     'seg_conv_first_pool_fwd': [vp, i32, i32, i32, i32, vp, vp, i32, i32, PV, i32, i32, i32, PV, i32, i32, i32, vp],
     'seg_im2col3x3': [vp, i32, i32, i32, i32, i32, PV, i32, i32, i32, vp],
     'seg_im2col': [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, PV, i32, i32, i32, vp],

@@ -435,6 +435,137 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG == 1 ? (
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The window kernel for any small filter and stride on the raw image: K is laid out in PAIRS of horizontally adjacent taps
+// (a pair = 2 RGB0 pixels = 16 contiguous LDS bytes = one lane's 8 k-slots): pair pi = 4 s + g of MFMA step s sits at filter row
+// pi / PPR, columns 2 (pi % PPR) and + 1, PPR = ceil(KW / 2) pairs per filter row (3x3: the layout of the kernel above).  Slots
+// past the filter (the odd column, the rows past KH) carry zero weights and read zero-filled / real pixels, never garbage.
+// The DeconvModel's first layer (/root/reference/models/deconvolution.py:44-46, 5x5 / stride 2 SAME on RGB, 64 filters: 16 pairs =
+// 4 MFMA steps) ran as im2col (250 MB) + a 1x1 convolution over it (335 MB): 131 + 53 us on the critical stream at 16 x 512^2; this
+// reads the image once and writes the activation once (50 + 134 MB).
+// ---------------------------------------------------------------------------------------------------------
+struct GenK {
+  const float* x; const float* w; const float* bias;
+  int B, H, W, cin, cout, pad_t, pad_l, Ho, Wo;
+  seg_view dst;
+  int blocks_x, blocks_y;
+};
+
+template <int KH, int KW, int S, int NG, bool RELU>
+__global__ __launch_bounds__(256) void conv_first_gen_kernel(const GenK P) {
+  constexpr int PPR = (KW + 1) / 2, NP = KH * PPR, NS = (NP + 3) / 4;
+  constexpr int PRL = (FTH - 1) * S + KH, PCL = (FTW - 1) * S + KW;               // patch rows / columns that are loaded
+  constexpr int PR = (FTH - 1) * S + (4 * NS - 1) / PPR + 1, PC = (FTW - 1) * S + 2 * PPR;   // ... that the fragments may read
+  constexpr int RS = PC | 1;                                                      // row stride in pixels (odd: rows start in different banks)
+  constexpr int NPX = PRL * PCL, NLD = (NPX + 255) / 256;
+  __shared__ __attribute__((aligned(16))) uint32_t sp[PR * RS * 2];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = lane & 15, g = lane >> 4;
+  for (int i = tid; i < PR * RS * 2; i += 256) sp[i] = 0u;        // (the slots no load covers stay zero for the whole launch)
+
+  Frag<bf16_t> fa[NG][2][NS];
+  f32x4 bias4[NG][2];
+#pragma unroll
+  for (int q = 0; q < NG; ++q)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int ch = 32 * q + 8 * (p >> 2) + 4 * m + (p & 3);     // MFMA m of channel group q, A row p <-> this channel
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int pi = 4 * s_ + g;
+          const int ty = pi / PPR, tx = 2 * (pi - ty * PPR) + (j >> 2), c = j & 3;
+          const bool on = ty < KH && tx < KW && c < P.cin && ch < P.cout;
+          fa[q][m][s_].v[j] = (bf16_t)(on ? P.w[(int64_t)((ty * KW + tx) * P.cin + c) * P.cout + ch] : 0.f);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cb = 32 * q + 8 * g + 4 * m + r;                 // D row 4 g + r of MFMA m <-> this channel
+        bias4[q][m][r] = (P.bias && cb < P.cout) ? P.bias[cb] : 0.f;
+      }
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const int tiles_x = P.blocks_x, tiles_y = P.blocks_y;
+  const int per_img = tiles_x * tiles_y, total = P.B * per_img;
+  bf16_t* dstp = reinterpret_cast<bf16_t*>(P.dst.ptr);
+  // this lane's 2 x 2 output pixels inside the wave's 4 x 16 region of the tile (as above)
+  const int r0 = 4 * (wave >> 1) + 2 * (p >> 3), c0 = 16 * (wave & 1) + 2 * (p & 7);
+  int baddr[NS];                                                   // LDS byte address of the pair of pixel (r0, c0), step s
+#pragma unroll
+  for (int s_ = 0; s_ < NS; ++s_) {
+    const int pi = 4 * s_ + g, ty = pi / PPR, tx = 2 * (pi - ty * PPR);
+    baddr[s_] = ((r0 * S + ty) * RS + c0 * S + tx) * 8;
+  }
+  const int dlane = (r0 * P.dst.W + c0) * P.dst.cs + 8 * g;
+
+  float pre[NLD][3];
+  auto patch_load = [&](int t) {
+    const int b = t / per_img; const int r = t - b * per_img;
+    const int ty = r / tiles_x, tx = r - ty * tiles_x;
+    const float* xb = P.x + (int64_t)b * P.H * P.W * P.cin;
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) {
+      const int i = tid + n * 256;
+      const int py = i / PCL, px = i - py * PCL;
+      const int iy = ty * FTH * S - P.pad_t + py, ix = tx * FTW * S - P.pad_l + px;
+      const bool in = i < NPX && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+      const float* q = xb + ((int64_t)iy * P.W + ix) * P.cin;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pre[n][c] = (in && c < P.cin) ? q[c] : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < total) patch_load(blockIdx.x);
+  __syncthreads();                                                 // the zero fill is complete
+  for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    const int b = t / per_img; const int r = t - b * per_img;
+    const int ty = r / tiles_x, tx = r - ty * tiles_x;
+    const int oy0 = ty * FTH, ox0 = tx * FTW;
+    lds_barrier();                                                 // previous tile's reads are done
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) {
+      const int i = tid + n * 256;
+      if (i < NPX) {
+        const int py = i / PCL, px = i - py * PCL;
+        const bf16x4 v = bf16x4{(bf16_t)pre[n][0], (bf16_t)pre[n][1], (bf16_t)pre[n][2], (bf16_t)0.f};
+        *reinterpret_cast<u32x2*>(&sp[(py * RS + px) * 2]) = __builtin_bit_cast(u32x2, v);
+      }
+    }
+    lds_barrier();
+    if (t + (int)gridDim.x < total) patch_load(t + gridDim.x);     // in flight behind this tile's arithmetic and in front of its stores
+    const int64_t dtile = view_off(P.dst, b, oy0, ox0);
+    const char* spb = reinterpret_cast<const char*>(sp);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int dy = q4 >> 1, dx = q4 & 1;
+      const int oy = oy0 + r0 + dy, ox = ox0 + c0 + dx;
+      const bool ok = oy < P.Ho && ox < P.Wo;
+      Frag<bf16_t> fb[NS];
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) {
+        const u32x2* src = reinterpret_cast<const u32x2*>(spb + baddr[s_] + (dy * S * RS + dx * S) * 8);
+        const u32x2 lo = src[0], hi = src[1];
+        fb[s_].v = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+      }
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        f32x4 a0 = bias4[q][0], a1 = bias4[q][1];
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) { mma32(a0, fa[q][0][s_], fb[s_]); mma32(a1, fa[q][1][s_], fb[s_]); }
+        const bf16x8 ob = bf16x8{(bf16_t)a0[0], (bf16_t)a0[1], (bf16_t)a0[2], (bf16_t)a0[3], (bf16_t)a1[0], (bf16_t)a1[1], (bf16_t)a1[2], (bf16_t)a1[3]};
+        u32x4 o = __builtin_bit_cast(u32x4, ob);
+        if (RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = pk_relu_bf16(o[e]);
+        }
+        if (ok) *reinterpret_cast<u32x4*>(dstp + dtile + dlane + (dy * P.dst.W + dx) * P.dst.cs + 32 * q) = o;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 static int launch_first_mfma(const FirstK& P0, hipStream_t st) {
@@ -630,6 +761,40 @@ extern "C" int seg_conv_first_fwd(const float* x, int32_t B, int32_t H, int32_t 
   else if (dtype == SEG_BF16) SEG_LAUNCH(conv_first_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, x, B, H, W, cin, w_hwio, bias, cout, pad, *dst, Ho, Wo, relu, tiles_x, tiles_y);
   else { seg_set_error("conv_first_fwd: bad dtype"); return SEG_ERR_ARG; }
   return seg_check_launch("conv_first_fwd");
+}
+
+/* Small filter of any size / stride on the raw image as ONE pass (bf16, cin <= 3, cout <= 64): the DeconvModel's conv1_0
+ * (/root/reference/models/deconvolution.py:44-46).  Instantiated: 5x5/s2, 3x3/s2, 3x3/s1, 7x7/s2. */
+extern "C" int seg_conv_first_gen(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const float* w_hwio, const float* bias,
+                                  int32_t cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad_t, int32_t pad_l, const seg_view* dst,
+                                  int32_t Ho, int32_t Wo, int32_t relu, int32_t dtype, void* stream) {
+  if (!x || !w_hwio || !dst || !dst->ptr || cin < 1 || cin > 3 || cout < 1 || cout > 64 || B <= 0 || Ho <= 0 || Wo <= 0 || pad_t < 0 || pad_l < 0) {
+    seg_set_error("conv_first_gen: bad args (cin 1..3, cout <= 64)"); return SEG_ERR_ARG; }
+  if (dtype != SEG_BF16) { seg_set_error("conv_first_gen: bf16 only (f32: seg_im2col + the 1x1 convolution)"); return SEG_ERR_UNSUPPORTED; }
+  const int cp = cdiv(cout, 32) * 32;
+  if (dst->oy + Ho > dst->H || dst->ox + Wo > dst->W || dst->coff + cp > dst->cs || dst->cs % 8 || dst->coff % 8) { seg_set_error("conv_first_gen: destination window exceeds buffer"); return SEG_ERR_ARG; }
+  if ((int64_t)(Ho - 1) * stride - pad_t >= H || (int64_t)(Wo - 1) * stride - pad_l >= W) { seg_set_error("conv_first_gen: output extent reaches past the input"); return SEG_ERR_ARG; }
+  if ((int64_t)B * dst->H * dst->W * dst->cs >= ((int64_t)1 << 31) || (int64_t)B * H * W * cin >= ((int64_t)1 << 31)) { seg_set_error("conv_first_gen: tensor exceeds the 32-bit index range"); return SEG_ERR_UNSUPPORTED; }
+  GenK P = {};
+  P.x = x; P.w = w_hwio; P.bias = bias; P.B = B; P.H = H; P.W = W; P.cin = cin; P.cout = cout; P.pad_t = pad_t; P.pad_l = pad_l; P.Ho = Ho; P.Wo = Wo;
+  P.dst = *dst; P.blocks_x = cdiv(Wo, FTW); P.blocks_y = cdiv(Ho, FTH);
+  const int64_t total = (int64_t)B * P.blocks_x * P.blocks_y;
+  static const int per_cu_env = getenv("SEG_FIRST_WGS_PER_CU") ? atoi(getenv("SEG_FIRST_WGS_PER_CU")) : 0;
+  const int ng = cdiv(cout, 32);
+  const int per_cu = per_cu_env > 0 ? per_cu_env : (ng == 1 ? 4 : 2);      // (what the filter fragments in registers leave resident)
+  int g = (int)total; if (g > 256 * per_cu) g = 256 * per_cu;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int key = KH * 1000 + KW * 100 + stride * 10 + ng;
+#define FG_CASE(KH_, KW_, S_, NG_) case KH_ * 1000 + KW_ * 100 + S_ * 10 + NG_: \
+    if (relu) SEG_LAUNCH((conv_first_gen_kernel<KH_, KW_, S_, NG_, true>), dim3(g), dim3(256), 0, st, P); \
+    else SEG_LAUNCH((conv_first_gen_kernel<KH_, KW_, S_, NG_, false>), dim3(g), dim3(256), 0, st, P); break
+  switch (key) {
+    FG_CASE(5, 5, 2, 1); FG_CASE(5, 5, 2, 2); FG_CASE(3, 3, 2, 1); FG_CASE(3, 3, 2, 2); FG_CASE(3, 3, 1, 1); FG_CASE(3, 3, 1, 2);
+    FG_CASE(7, 7, 2, 1); FG_CASE(7, 7, 2, 2);
+    default: seg_set_error("conv_first_gen: %dx%d / stride %d is not instantiated", KH, KW, stride); return SEG_ERR_UNSUPPORTED;
+  }
+#undef FG_CASE
+  return seg_check_launch("conv_first_gen");
 }
 
 /* First layer + the 2x2/s2 max-pool (VALID) that consumes it, in one pass (bf16, cin <= 3, cout <= 64): writes both

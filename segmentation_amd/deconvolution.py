@@ -176,7 +176,7 @@ class DeconvModel(BaseModel):
         return {n: (v[n + '/moving_mean'], v[n + '/moving_variance']) for v in [self._state_blob()] for n in self.bn}
 
     # ---- forward graph (training / test / inference plans share it) ----
-    def _emit_forward(self, net, plan, x_in, H, W, bn_training, update_moving, dropout_step, seed_inc=0):
+    def _emit_forward(self, net, plan, x_in, H, W, bn_training, update_moving, dropout_step, seed_inc=0, want_col=True):
         """dropout_step: True -> masks keyed by the device-side global step (train / test plans); False -> by a host offset
         (ctypes c_uint64 in self._infer_off: one fresh mask per infer() call)"""
         if H != W:
@@ -185,12 +185,26 @@ class DeconvModel(BaseModel):
         sz = deconv_sizes(H)
         bn = self._bn_states(net)
         A, Y = {}, {}
-        xin = net.act(sz['conv1_0'], sz['conv1_0'], 25 * self.input_channel, name='x_im2col')
         pad = max((sz['conv1_0'] - 1) * 2 + 5 - H, 0) // 2           # TF SAME, stride 2: leading pad = total // 2
-        cv = xin.view()
-        plan.keep.append(cv)
-        plan.add('conv1_0/im2col', net.lib.seg_im2col, x_in.data_ptr(), net.B, H, W, self.input_channel, 5, 5, 2, pad, pad, E.C.byref(cv),
-                 sz['conv1_0'], sz['conv1_0'], net.dtype, kernel='im2col_kernel')
+        # bf16, <= 3 input channels: conv1_0 straight from the image (seg_conv_first_gen); its im2col tensor is then only the filter
+        # gradient's operand -- a side stream writes it behind the forward pass (training plan), nobody else asks for it
+        mode = os.environ.get('SEG_FIRST_GEN', '1')
+        direct = net.dtype == L.SEG_BF16 and self.input_channel <= 3 and nk <= 64 and mode != '0'
+        xin = None
+        self._col_late = None
+        if want_col or not direct:
+            xin = net.act(sz['conv1_0'], sz['conv1_0'], 25 * self.input_channel, name='x_im2col')
+            cv = xin.view()
+            plan.keep.append(cv)
+            col_args = ('conv1_0/im2col', net.lib.seg_im2col, x_in.data_ptr(), net.B, H, W, self.input_channel, 5, 5, 2, pad, pad, E.C.byref(cv),
+                        sz['conv1_0'], sz['conv1_0'], net.dtype)
+            if direct and mode != 'fwd' and net.side_enabled:
+                # emitted by the backward plan on the filter gradient's stream, half a backward pass ahead of it: 16 x 512^2 step
+                # 1.76 (im2col + 1x1 convolution) -> 1.65 ms; written during the forward pass -- whose kernels are all HBM-bound --
+                # it gave the direct kernel's gain back (1.76 on the main stream, 1.78 on a side stream: SEG_FIRST_GEN=fwd)
+                self._col_late = col_args
+            else:
+                plan.add(*col_args, kernel='im2col_kernel')
         net.join_aux(plan)                     # packed weights (re-packed on the aux stream in training) are needed from here on
 
         def act_bn(name, a):
@@ -213,7 +227,10 @@ class DeconvModel(BaseModel):
             return out
 
         a = net.act(sz['conv1_0'], sz['conv1_0'], nk, name='conv1_0')
-        net.conv_fwd(plan, Ly['conv1_0'], [(xin, 0, 0)], xin.H, xin.W, a)
+        if direct:
+            net.first_gen_fwd(plan, Ly['conv1_0'], x_in, H, W, self.input_channel, 5, 5, 2, pad, pad, a)
+        else:
+            net.conv_fwd(plan, Ly['conv1_0'], [(xin, 0, 0)], xin.H, xin.W, a)
         t = act_bn('conv1_0', a)
         P = {}
         P[1] = net.act(sz['pool1'], sz['pool1'], nk, name='pool1'); net.pool_k_fwd(plan, t, P[1], 2)
@@ -264,7 +281,7 @@ class DeconvModel(BaseModel):
         # the test() graph: moving averages, no update; dropout (if bayesian) stays on, exactly as in the reference's test graph
         tnet = self.test_net = E.Net(self.store, B, self.dtype, self.device)
         self.test_plan = E.Plan('test')
-        TA, _, _, _ = self._emit_forward(tnet, self.test_plan, self.input_x, H, W, bn_training=False, update_moving=False, dropout_step=True,
+        TA, _, _, _ = self._emit_forward(tnet, self.test_plan, self.input_x, H, W, bn_training=False, update_moving=False, dropout_step=True, want_col=False,
                                          seed_inc=TEST_SEED_INC)
         tdl = tnet.act(H, W, nc, name='dlogits_test', thin=thin_tail(nc))
         tnet.softmax_xent(self.test_plan, TA['logits'], self.input_y, H, W, (0, 0), H, W, nc, self.loss_buf, tdl)
@@ -305,6 +322,10 @@ class DeconvModel(BaseModel):
             else:
                 net.dlayer_bwd(seg, Ly[dn], src, dz, dsrc=d, mask=None)
         dz = bn_bwd('bn4', 'conv4_0', d)
+        col_sid = None
+        if self._col_late is not None:
+            col_sid = 2 if net.n_wgrad_streams >= 2 else 1
+            seg.add(*self._col_late, kernel='im2col_kernel', side=col_sid)
         dP = {3: like(P[3], 'dpool3')}
         net.conv_bwd(seg, Ly['conv4_0'], [(P[3], 0, 0)], P[3].H, P[3].W, dz, [(dP[3], (0, 0), None, (0, 0))])
         for i, (cn, b, k) in ((3, ('conv3_0', 'bn3', 3)), (2, ('conv2_0', 'bn2', 3))):
@@ -317,7 +338,7 @@ class DeconvModel(BaseModel):
         d = like(Y['bn1'], 'd_bn1')
         net.pool_k_bwd(seg, Y['bn1'], dP[1], d, 2)
         dz = bn_bwd('bn1', 'conv1_0', d)
-        net.conv_bwd(seg, Ly['conv1_0'], [(A['x'], 0, 0)], A['x'].H, A['x'].W, dz, [None])
+        net.conv_bwd(seg, Ly['conv1_0'], [(A['x'], 0, 0)], A['x'].H, A['x'].W, dz, [None], wgrad_sid=col_sid)
         self.grads_act = G
         net.flush_reduce(seg)
         l = Ly['conv1_0']
@@ -352,7 +373,7 @@ class DeconvModel(BaseModel):
         if not hasattr(self, '_infer_off'):
             self._infer_off = C.c_uint64(0)
         plan.keep.append(self._infer_off)
-        A, _, _, _ = self._emit_forward(net, plan, x_in, H, W, bn_training=True, update_moving=False, dropout_step=False)
+        A, _, _, _ = self._emit_forward(net, plan, x_in, H, W, bn_training=True, update_moving=False, dropout_step=False, want_col=False)
         sig = torch.zeros((B, H, W, self.n_classes), dtype=torch.float32, device=self.device)
         out = torch.zeros((B, H, W, 1), dtype=torch.float32, device=self.device)
         net.sigmoid_argmax(plan, A['logits'], H, W, self.n_classes, sig, out)

@@ -685,6 +685,18 @@ class Net(object):
                  1 if layer.relu else 0, self.dtype, kernel=kern, flops=fl, bytes=by)
         return False
 
+    def first_gen_fwd(self, plan, layer, x_f32, H, W, cin, KH, KW, stride, pad_t, pad_l, dst):
+        """A KH x KW / stride filter on the raw float image in one pass (seg_conv_first_gen: bf16, cin <= 3, cout <= 64).  `layer`
+        holds the filter as [KH*KW*cin][cout] = HWIO (the DeconvModel keeps conv1_0 as a 1x1 layer over its im2col)."""
+        dv = dst.view()
+        plan.keep.append(dv)
+        fl = 2 * self.B * dst.H * dst.W * KH * KW * cin * layer.cout
+        plan.flops += fl
+        by = self.B * (H * W * cin * 4 + dst.H * dst.W * layer.cout * self.es)
+        plan.add(layer.name, self.lib.seg_conv_first_gen, x_f32.data_ptr(), self.B, H, W, cin, self.store.p_ptr(layer.w_off),
+                 self.store.p_ptr(layer.b_off), layer.cout, KH, KW, stride, pad_t, pad_l, C.byref(dv), dst.H, dst.W, 1 if layer.relu else 0,
+                 self.dtype, kernel='conv_first_gen_kernel', flops=fl, bytes=by)
+
     def conv_fwd(self, plan, layer, srcs, Hi, Wi, dst, dst_off=(0, 0), out_f32=False, cfg=0, pool=None, ksplit=None, side=0):
         """srcs: list of (Act, oy, ox) (1 or 2 concat segments).  pool: Act of the 2x2 max-pool that consumes dst; when the
         layer's tile can carry it the pooled map is written by the same launch and `self.pool_fused` is set (else the
@@ -935,7 +947,7 @@ class Net(object):
         self._add_wgrad(plan, layer.name + '/dw', w, fl, sid='aux' if on_aux else (1 if (same_stream and col is not None) else None))
         plan.flops += fl
 
-    def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0, ksplit=0, dgrad_ksplit=None):
+    def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0, ksplit=0, dgrad_ksplit=None, wgrad_sid=None):
         """Filter + bias gradient, then one dgrad launch per entry of dsrcs.
         dsrcs: list aligned with srcs; each None (no input gradient wanted) or
         (dst_act, (oy,ox), mask_act_or_None, (moy,mox))."""
@@ -957,7 +969,7 @@ class Net(object):
         self._wgrad_ws(w, plan, ksplit)
         fl = 2 * self.B * Ho * Wo * k * k * layer.cin * layer.cout
         self._wg_bytes = self.B * (Hi * Wi * layer.cin + Ho * Wo * layer.cout) * self.es + k * k * layer.cin * layer.cout * 4
-        self._add_wgrad(plan, layer.name + '/dw', w, fl)
+        self._add_wgrad(plan, layer.name + '/dw', w, fl, sid=wgrad_sid)
         plan.flops += fl
         n_off = 0
         merged = (len(dsrcs) == 2 and dsrcs[0] is not None and dsrcs[1] is not None and not any(len(x) > 4 and x[4] for x in dsrcs)

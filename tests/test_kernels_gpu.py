@@ -510,6 +510,35 @@ def test_wgrad_every_instance_on_a_long_tile_walk(dtype, kind, wcfg):
     assert U.rel_err(g['biases'], db_ref) < U.tol(dtype, 5e-5, 1e-2), 'bias grad ' + name
 
 
+@pytest.mark.parametrize('relu', [True, False])
+@pytest.mark.parametrize('k,stride,padding,cin,cout,H', [(5, 2, 'SAME', 3, 64, 64), (5, 2, 'SAME', 3, 32, 37), (5, 2, 'SAME', 1, 40, 50), (3, 2, 'SAME', 3, 16, 33),
+                                                          (3, 1, 'VALID', 2, 64, 21), (7, 2, 'SAME', 3, 64, 70), (5, 2, 'VALID', 3, 64, 41)])
+def test_conv_first_gen(k, stride, padding, cin, cout, H, relu):
+    """seg_conv_first_gen (the DeconvModel's conv1_0, models/deconvolution.py:44-46: 5x5 / stride 2 SAME on the raw image) against the
+    oracle's convolution; the layer keeps the filter as the 1x1 layer over the im2col that the filter gradient uses."""
+    dtype = L.SEG_BF16
+    B, W = 2, H + 5
+    rng = np.random.default_rng(k * 100 + cout + H)
+    layer = E.Layer('f', 'conv', 1, [k * k * cin], cout, 'VALID', relu)
+    w = (rng.standard_normal((k, k, cin, cout)) * 0.2).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    p = {'f': {'weights': w.reshape(1, 1, k * k * cin, cout), 'biases': b}}
+    store = U.make_store([layer], dtype, p)
+    net = E.Net(store, B, dtype, U.dev())
+    x = rng.uniform(-1, 1, (B, H, W, cin)).astype(np.float32)
+    xt = torch.from_numpy(x).to(U.dev())
+    Ho, pt = ops.conv_out_size(H, k, stride, padding)
+    Wo, pl = ops.conv_out_size(W, k, stride, padding)
+    out = net.act(Ho, Wo, cout)
+    out.t.fill_(float('nan'))
+    plan = E.Plan('t'); net.first_gen_fwd(plan, layer, xt, H, W, cin, k, k, stride, pt, pl, out); plan.run(U.stream()); U.sync()
+    ref = ops.conv2d(U.round_dtype(x, dtype), U.round_dtype(w, dtype), b, padding, stride, relu)
+    got = U.read_act(out)
+    assert np.isfinite(got).all()
+    assert U.rel_err(got, ref) < 6e-3                  # bf16 operands, f32 accumulation, one rounding of the result
+    assert U.pad_channels_zero(out)
+
+
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('impl,relu', [('win', True), ('old', True), ('win', False), ('old', False)])
 @pytest.mark.parametrize('pad,cin,cout,H', [(0, 3, 32, 21), (1, 3, 16, 18), (0, 1, 40, 33), (1, 2, 64, 20), (0, 3, 32, 64)])
