@@ -183,6 +183,13 @@ int seg_conv_first_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t 
 int seg_conv_first_gen(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const float* w_hwio, const float* bias,
                        int32_t cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad_t, int32_t pad_l, const seg_view* dst,
                        int32_t Ho, int32_t Wo, int32_t relu, int32_t dtype, void* stream);
+/* The same launch also leaving the statistics rows of the batch norm that consumes the layer (5x5 / stride 2 only): bn_ws is that
+ * batch norm's workspace (seg_bn_ws_bytes(bn_C)); seg_bn_fwd_rows(..., rows = seg_conv_first_gen_rows(B, Ho, Wo, cout)) finishes it
+ * without reading the activation for its statistics (models/deconvolution.py:44-50 conv1_0 -> bn1). */
+int32_t seg_conv_first_gen_rows(int32_t B, int32_t Ho, int32_t Wo, int32_t cout);
+int seg_conv_first_gen_bn(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const float* w_hwio, const float* bias,
+                          int32_t cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad_t, int32_t pad_l, const seg_view* dst,
+                          int32_t Ho, int32_t Wo, int32_t relu, float* bn_ws, int32_t bn_C, int32_t dtype, void* stream);
 
 /* Same layer fused with the 2x2/s2 VALID max-pool that consumes it (models/unet.py pool1 over conv1_1, models/fcn.py:116
  * pool1 over conv1): one pass writes the activation and its pooled map [Hp = Ho/2, Wp = Wo/2].  bf16, cin <= 3, cout <= 64. */
@@ -278,6 +285,11 @@ int seg_thin_conv3x3(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, con
  * over `small`'s layout), filter in the TF layout [2,2,cout,cin] -- the DeconvModel's deconv3_0 on the vector ALU. */
 int seg_thin_up2x2(const seg_view* small, const seg_view* big, int32_t B, int32_t H, int32_t W, const float* w_tf, const float* bias,
                    int32_t cin, int32_t cout, int32_t relu, int32_t dgrad, const seg_view* mask, int32_t dtype, void* stream);
+/* Forward of seg_thin_up2x2 + the statistics rows ([rows][8][2] floats, rows = seg_thin_up2x2_rows(B, H, W)) of the batch norm that
+ * consumes `big` (models/deconvolution.py:166-168 deconv3_0 -> bn8), for seg_bn_fwd_rows. */
+int32_t seg_thin_up2x2_rows(int32_t B, int32_t H, int32_t W);
+int seg_thin_up2x2_bn(const seg_view* small, const seg_view* big, int32_t B, int32_t H, int32_t W, const float* w_tf, const float* bias,
+                      int32_t cin, int32_t cout, int32_t relu, float* bn_ws, int32_t dtype, void* stream);
 /* The same in two stages for big maps (512 workgroups of partial sums + a fixed-order final pass; bitwise reproducible):
  * ws of seg_bias_grad_ws_bytes(dz->c) bytes (0: this channel count is not supported, use seg_bias_grad). */
 int64_t seg_bias_grad_ws_bytes(int32_t C);
@@ -421,6 +433,10 @@ int seg_maxpool_k_bwd(const seg_view* src, const seg_view* dpool, const seg_view
 int64_t seg_bn_ws_bytes(int32_t C);
 int seg_bn_fwd(const seg_view* a, const seg_view* y, const float* beta, float* moving, float* stats, int32_t training, float decay,
                float eps, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype, void* stream);
+/* seg_bn_fwd (training statistics) whose statistics pass was done by the launch that produced `a`: ws holds `rows` (<= 1024) rows
+ * [C][2] of per-channel (sum, sum of squares) over disjoint pixel sets. */
+int seg_bn_fwd_rows(const seg_view* a, const seg_view* y, const float* beta, float* moving, float* stats, float decay, float eps,
+                    int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t rows, int32_t dtype, void* stream);
 int seg_bn_relu_bwd(const seg_view* a, const seg_view* dy, const seg_view* dz, const float* stats, float* dbeta, int32_t dbeta_add,
                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype, void* stream);
 

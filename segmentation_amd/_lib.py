@@ -76,6 +76,7 @@ SIGNATURES = {
     'seg_wgrad_reduce_batch': [vp, i32, i32, vp],
     'seg_conv_first_fwd': [vp, i32, i32, i32, i32, vp, vp, i32, i32, PV, i32, i32, i32, i32, vp],
     'seg_conv_first_gen': [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, PV, i32, i32, i32, i32, vp],
+    'seg_conv_first_gen_bn': [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, PV, i32, i32, i32, vp, i32, i32, vp],
     'seg_conv_first_pool_fwd': [vp, i32, i32, i32, i32, vp, vp, i32, i32, PV, i32, i32, i32, PV, i32, i32, i32, vp],
     'seg_im2col3x3': [vp, i32, i32, i32, i32, i32, PV, i32, i32, i32, vp],
     'seg_im2col': [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, PV, i32, i32, i32, vp],
@@ -91,6 +92,7 @@ SIGNATURES = {
     'seg_bias_grad': [PV, i32, i32, i32, i32, vp, i32, vp],
     'seg_bias_grad_ws': [PV, i32, i32, i32, i32, vp, vp, i64, i32, vp],
     'seg_thin_up2x2': [PV, PV, i32, i32, i32, vp, vp, i32, i32, i32, i32, PV, i32, vp],
+    'seg_thin_up2x2_bn': [PV, PV, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, vp],
     'seg_thin_conv3x3': [PV, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, PV, PV, i32, i32, i32, i32, vp],
     'seg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp],
     'seg_step_increment': [vp, vp],
@@ -112,6 +114,7 @@ SIGNATURES = {
     'seg_maxpool_k_fwd': [PV, PV, i32, i32, i32, i32, i32, i32, vp],
     'seg_maxpool_k_bwd': [PV, PV, PV, i32, i32, i32, i32, i32, i32, vp],
     'seg_bn_fwd': [PV, PV, vp, vp, vp, i32, f32, f32, i32, i32, i32, i32, i32, vp, i32, vp],
+    'seg_bn_fwd_rows': [PV, PV, vp, vp, vp, f32, f32, i32, i32, i32, i32, i32, vp, i32, i32, vp],
     'seg_bn_relu_bwd': [PV, PV, PV, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp],
     'seg_resize_bilinear_fwd': [PV, i32, i32, PV, i32, i32, i32, i32, i32, vp],
     'seg_resize_bilinear_bwd': [PV, i32, i32, PV, i32, i32, i32, i32, i32, vp],
@@ -159,6 +162,10 @@ def load():
     lib.seg_head_xent_ws_bytes.argtypes = [C.c_int32] * 5
     lib.seg_bias_grad_ws_bytes.restype = C.c_int64
     lib.seg_bias_grad_ws_bytes.argtypes = [C.c_int32]
+    lib.seg_conv_first_gen_rows.restype = C.c_int32
+    lib.seg_conv_first_gen_rows.argtypes = [C.c_int32] * 4
+    lib.seg_thin_up2x2_rows.restype = C.c_int32
+    lib.seg_thin_up2x2_rows.argtypes = [C.c_int32] * 3
     lib.seg_bilinear_up_bwd_ws_bytes.restype = C.c_int64
     lib.seg_bilinear_up_bwd_ws_bytes.argtypes = [C.c_int32] * 4
     _lib = lib

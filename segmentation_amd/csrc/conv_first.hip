@@ -449,9 +449,13 @@ struct GenK {
   int B, H, W, cin, cout, pad_t, pad_l, Ho, Wo;
   seg_view dst;
   int blocks_x, blocks_y;
+  float* bn_ws; int bn_C;             // STATS: one row [bn_C][2] of per-channel (sum, sum of squares) of the stored values per workgroup
 };
 
-template <int KH, int KW, int S, int NG, bool RELU>
+// STATS: the statistics pass of the batch norm that consumes this layer (seg_bn_fwd_rows) rides along -- every lane adds up the
+// rounded values it stores, the workgroup leaves one row of partial sums in the batch norm's workspace (fixed order: lanes by
+// butterfly, waves 0..3), and the 134 MB activation of the DeconvModel's conv1_0 is not read back for it.
+template <int KH, int KW, int S, int NG, bool RELU, bool STATS>
 __global__ __launch_bounds__(256) void conv_first_gen_kernel(const GenK P) {
   constexpr int PPR = (KW + 1) / 2, NP = KH * PPR, NS = (NP + 3) / 4;
   constexpr int PRL = (FTH - 1) * S + KH, PCL = (FTW - 1) * S + KW;               // patch rows / columns that are loaded
@@ -501,6 +505,11 @@ __global__ __launch_bounds__(256) void conv_first_gen_kernel(const GenK P) {
   }
   const int dlane = (r0 * P.dst.W + c0) * P.dst.cs + 8 * g;
 
+  float st1[STATS ? NG : 1][8], st2[STATS ? NG : 1][8];
+#pragma unroll
+  for (int q = 0; q < (STATS ? NG : 1); ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st1[q][e] = st2[q][e] = 0.f;
   float pre[NLD][3];
   auto patch_load = [&](int t) {
     const int b = t / per_img; const int r = t - b * per_img;
@@ -561,7 +570,32 @@ __global__ __launch_bounds__(256) void conv_first_gen_kernel(const GenK P) {
           for (int e = 0; e < 4; ++e) o[e] = pk_relu_bf16(o[e]);
         }
         if (ok) *reinterpret_cast<u32x4*>(dstp + dtile + dlane + (dy * P.dst.W + dx) * P.dst.cs + 32 * q) = o;
+        if (STATS && ok) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(o[e] << 16), hi = __uint_as_float(o[e] & 0xffff0000u);
+            st1[q][2 * e] += lo; st2[q][2 * e] = fmaf(lo, lo, st2[q][2 * e]);
+            st1[q][2 * e + 1] += hi; st2[q][2 * e + 1] = fmaf(hi, hi, st2[q][2 * e + 1]);
+          }
+        }
       }
+    }
+  }
+  if constexpr (STATS) {
+    __shared__ float red[4][NG * 32][2];
+#pragma unroll
+    for (int q = 0; q < NG; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = st1[q][e], b2 = st2[q][e];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b2 += __shfl_xor(b2, m); }      // the 16 pixel lanes of channel group g
+        if (p == 0) { red[wave][32 * q + 8 * g + e][0] = a; red[wave][32 * q + 8 * g + e][1] = b2; }
+      }
+    __syncthreads();
+    for (int i = tid; i < NG * 32 * 2; i += 256) {
+      const int c = i >> 1, j = i & 1;
+      if (c < P.bn_C) P.bn_ws[((int64_t)blockIdx.x * P.bn_C + c) * 2 + j] = ((red[0][c][j] + red[1][c][j]) + red[2][c][j]) + red[3][c][j];
     }
   }
 }
@@ -765,9 +799,22 @@ extern "C" int seg_conv_first_fwd(const float* x, int32_t B, int32_t H, int32_t 
 
 /* Small filter of any size / stride on the raw image as ONE pass (bf16, cin <= 3, cout <= 64): the DeconvModel's conv1_0
  * (/root/reference/models/deconvolution.py:44-46).  Instantiated: 5x5/s2, 3x3/s2, 3x3/s1, 7x7/s2. */
-extern "C" int seg_conv_first_gen(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const float* w_hwio, const float* bias,
-                                  int32_t cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad_t, int32_t pad_l, const seg_view* dst,
-                                  int32_t Ho, int32_t Wo, int32_t relu, int32_t dtype, void* stream) {
+static int first_gen_grid(int64_t total, int ng, bool stats) {
+  static const int per_cu_env = getenv("SEG_FIRST_WGS_PER_CU") ? atoi(getenv("SEG_FIRST_WGS_PER_CU")) : 0;
+  const int per_cu = (per_cu_env > 0 && !stats) ? per_cu_env : (ng == 1 ? 4 : 2);      // (what the filter fragments in registers leave resident)
+  int g = total > 256 * per_cu ? 256 * per_cu : (int)total;
+  return g < 1 ? 1 : g;
+}
+
+/* Workgroups = rows of batch-norm partial sums a seg_conv_first_gen_bn launch of this shape writes (<= 1024). */
+extern "C" int32_t seg_conv_first_gen_rows(int32_t B, int32_t Ho, int32_t Wo, int32_t cout) {
+  if (B < 1 || Ho < 1 || Wo < 1 || cout < 1 || cout > 64) return 0;
+  return first_gen_grid((int64_t)B * cdiv(Wo, FTW) * cdiv(Ho, FTH), cdiv(cout, 32), true);
+}
+
+static int first_gen_launch(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const float* w_hwio, const float* bias,
+                            int32_t cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad_t, int32_t pad_l, const seg_view* dst,
+                            int32_t Ho, int32_t Wo, int32_t relu, float* bn_ws, int32_t bn_C, int32_t dtype, void* stream) {
   if (!x || !w_hwio || !dst || !dst->ptr || cin < 1 || cin > 3 || cout < 1 || cout > 64 || B <= 0 || Ho <= 0 || Wo <= 0 || pad_t < 0 || pad_l < 0) {
     seg_set_error("conv_first_gen: bad args (cin 1..3, cout <= 64)"); return SEG_ERR_ARG; }
   if (dtype != SEG_BF16) { seg_set_error("conv_first_gen: bf16 only (f32: seg_im2col + the 1x1 convolution)"); return SEG_ERR_UNSUPPORTED; }
@@ -775,19 +822,25 @@ extern "C" int seg_conv_first_gen(const float* x, int32_t B, int32_t H, int32_t 
   if (dst->oy + Ho > dst->H || dst->ox + Wo > dst->W || dst->coff + cp > dst->cs || dst->cs % 8 || dst->coff % 8) { seg_set_error("conv_first_gen: destination window exceeds buffer"); return SEG_ERR_ARG; }
   if ((int64_t)(Ho - 1) * stride - pad_t >= H || (int64_t)(Wo - 1) * stride - pad_l >= W) { seg_set_error("conv_first_gen: output extent reaches past the input"); return SEG_ERR_ARG; }
   if ((int64_t)B * dst->H * dst->W * dst->cs >= ((int64_t)1 << 31) || (int64_t)B * H * W * cin >= ((int64_t)1 << 31)) { seg_set_error("conv_first_gen: tensor exceeds the 32-bit index range"); return SEG_ERR_UNSUPPORTED; }
+  if (bn_ws && (bn_C < cout || bn_C > cp || bn_C % 8 || KH != 5 || KW != 5 || stride != 2)) { seg_set_error("conv_first_gen_bn: 5x5/s2 only, cout <= bn_C <= %d", cp); return SEG_ERR_UNSUPPORTED; }
   GenK P = {};
   P.x = x; P.w = w_hwio; P.bias = bias; P.B = B; P.H = H; P.W = W; P.cin = cin; P.cout = cout; P.pad_t = pad_t; P.pad_l = pad_l; P.Ho = Ho; P.Wo = Wo;
-  P.dst = *dst; P.blocks_x = cdiv(Wo, FTW); P.blocks_y = cdiv(Ho, FTH);
+  P.dst = *dst; P.blocks_x = cdiv(Wo, FTW); P.blocks_y = cdiv(Ho, FTH); P.bn_ws = bn_ws; P.bn_C = bn_C;
   const int64_t total = (int64_t)B * P.blocks_x * P.blocks_y;
-  static const int per_cu_env = getenv("SEG_FIRST_WGS_PER_CU") ? atoi(getenv("SEG_FIRST_WGS_PER_CU")) : 0;
   const int ng = cdiv(cout, 32);
-  const int per_cu = per_cu_env > 0 ? per_cu_env : (ng == 1 ? 4 : 2);      // (what the filter fragments in registers leave resident)
-  int g = (int)total; if (g > 256 * per_cu) g = 256 * per_cu;
+  const int g = first_gen_grid(total, ng, bn_ws != nullptr);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int key = KH * 1000 + KW * 100 + stride * 10 + ng;
+  if (bn_ws) {
+#define FG_BN(NG_) do { if (relu) SEG_LAUNCH((conv_first_gen_kernel<5, 5, 2, NG_, true, true>), dim3(g), dim3(256), 0, st, P); \
+    else SEG_LAUNCH((conv_first_gen_kernel<5, 5, 2, NG_, false, true>), dim3(g), dim3(256), 0, st, P); } while (0)
+    if (ng == 1) FG_BN(1); else FG_BN(2);
+#undef FG_BN
+    return seg_check_launch("conv_first_gen_bn");
+  }
 #define FG_CASE(KH_, KW_, S_, NG_) case KH_ * 1000 + KW_ * 100 + S_ * 10 + NG_: \
-    if (relu) SEG_LAUNCH((conv_first_gen_kernel<KH_, KW_, S_, NG_, true>), dim3(g), dim3(256), 0, st, P); \
-    else SEG_LAUNCH((conv_first_gen_kernel<KH_, KW_, S_, NG_, false>), dim3(g), dim3(256), 0, st, P); break
+    if (relu) SEG_LAUNCH((conv_first_gen_kernel<KH_, KW_, S_, NG_, true, false>), dim3(g), dim3(256), 0, st, P); \
+    else SEG_LAUNCH((conv_first_gen_kernel<KH_, KW_, S_, NG_, false, false>), dim3(g), dim3(256), 0, st, P); break
   switch (key) {
     FG_CASE(5, 5, 2, 1); FG_CASE(5, 5, 2, 2); FG_CASE(3, 3, 2, 1); FG_CASE(3, 3, 2, 2); FG_CASE(3, 3, 1, 1); FG_CASE(3, 3, 1, 2);
     FG_CASE(7, 7, 2, 1); FG_CASE(7, 7, 2, 2);
@@ -795,6 +848,21 @@ extern "C" int seg_conv_first_gen(const float* x, int32_t B, int32_t H, int32_t 
   }
 #undef FG_CASE
   return seg_check_launch("conv_first_gen");
+}
+
+extern "C" int seg_conv_first_gen(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const float* w_hwio, const float* bias,
+                                  int32_t cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad_t, int32_t pad_l, const seg_view* dst,
+                                  int32_t Ho, int32_t Wo, int32_t relu, int32_t dtype, void* stream) {
+  return first_gen_launch(x, B, H, W, cin, w_hwio, bias, cout, KH, KW, stride, pad_t, pad_l, dst, Ho, Wo, relu, nullptr, 0, dtype, stream);
+}
+
+/* The same launch also leaving the statistics rows of the batch norm that consumes the layer (5x5 / stride 2): bn_ws is that batch
+ * norm's workspace (seg_bn_ws_bytes(bn_C)), which seg_bn_fwd_rows(..., seg_conv_first_gen_rows(...)) then finishes. */
+extern "C" int seg_conv_first_gen_bn(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const float* w_hwio, const float* bias,
+                                     int32_t cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad_t, int32_t pad_l, const seg_view* dst,
+                                     int32_t Ho, int32_t Wo, int32_t relu, float* bn_ws, int32_t bn_C, int32_t dtype, void* stream) {
+  if (!bn_ws) { seg_set_error("conv_first_gen_bn: no workspace"); return SEG_ERR_ARG; }
+  return first_gen_launch(x, B, H, W, cin, w_hwio, bias, cout, KH, KW, stride, pad_t, pad_l, dst, Ho, Wo, relu, bn_ws, bn_C, dtype, stream);
 }
 
 /* First layer + the 2x2/s2 max-pool (VALID) that consumes it, in one pass (bf16, cin <= 3, cout <= 64): writes both

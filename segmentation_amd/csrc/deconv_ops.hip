@@ -794,16 +794,31 @@ static int bn_nb(int64_t npix, int C8) {
   return (int)nb;
 }
 
+static int bn_fwd_launch(const seg_view* a, const seg_view* y, const float* beta, float* moving, float* stats, int32_t training,
+                         float decay, float eps, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t rows, int32_t dtype,
+                         void* stream);
 extern "C" int seg_bn_fwd(const seg_view* a, const seg_view* y, const float* beta, float* moving, float* stats, int32_t training,
                           float decay, float eps, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype,
                           void* stream) {
+  return bn_fwd_launch(a, y, beta, moving, stats, training, decay, eps, B, H, W, C, c_log, ws, 0, dtype, stream);
+}
+/* seg_bn_fwd whose statistics pass has been done by the launch that produced `a`: ws holds `rows` rows [C][2] of per-channel (sum,
+ * sum of squares) over disjoint pixel sets (seg_conv_first_gen_bn, seg_thin_up2x2_bn); training statistics only. */
+extern "C" int seg_bn_fwd_rows(const seg_view* a, const seg_view* y, const float* beta, float* moving, float* stats, float decay, float eps,
+                               int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t rows, int32_t dtype, void* stream) {
+  if (rows < 1 || rows > BN_NB) { seg_set_error("bn_fwd_rows: 1..%d rows", BN_NB); return SEG_ERR_ARG; }
+  return bn_fwd_launch(a, y, beta, moving, stats, 1, decay, eps, B, H, W, C, c_log, ws, rows, dtype, stream);
+}
+static int bn_fwd_launch(const seg_view* a, const seg_view* y, const float* beta, float* moving, float* stats, int32_t training,
+                         float decay, float eps, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t rows, int32_t dtype,
+                         void* stream) {
   if (!a || !y || !beta || !stats || !ws || C <= 0 || C % 8 || C > 2048 || c_log <= 0 || c_log > C || !view_ok(*a, H, W, C) || !view_ok(*y, H, W, C) ||
       (!training && !moving) || (dtype != SEG_F32 && dtype != SEG_BF16)) { seg_set_error("bn_fwd: bad arguments"); return SEG_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   const int64_t npix = (int64_t)B * H * W;
-  const int nb = bn_nb(npix, C / 8);
+  const int nb = rows > 0 ? rows : bn_nb(npix, C / 8);
   seg_view none = *a;
-  if (training) {
+  if (training && rows == 0) {
     if (dtype == SEG_F32) SEG_LAUNCH((bn_partial_kernel<float, 0>), dim3(nb), dim3(256), 0, st, *a, none, (const float*)nullptr, B, H, W, C, ws);
     else SEG_LAUNCH((bn_partial_kernel<bf16_t, 0>), dim3(nb), dim3(256), 0, st, *a, none, (const float*)nullptr, B, H, W, C, ws);
     if (int rc = seg_check_launch("bn_partial")) return rc;

@@ -1297,7 +1297,7 @@ extern "C" int seg_thin_conv3x3(const seg_view* src, int32_t B, int32_t Hi, int3
 //   dgrad   : dsmall[b,y,x,ci] = (mask > 0) * sum_{a,c,co} dbig[b, 2y+a, 2x+c, co] * w[a][c][co][ci]
 template <typename T, int NC, bool DGRAD>
 __global__ __launch_bounds__(256) void thin_up2x2_kernel(seg_view small, seg_view big, const float* w, const float* bias, int cin, int cout,
-                                                         int relu, seg_view mask, int B, int H, int W) {
+                                                         int relu, seg_view mask, int B, int H, int W, float* bn_ws) {
   extern __shared__ float sw_up[];            // [tap][co < NC][ci < cp]  (zero above the logical counts), then bias[NC]
   const int cp = small.c;                     // padded input channels of the layer (a multiple of 8)
   for (int i = threadIdx.x; i < 4 * NC * cp; i += 256) {
@@ -1310,6 +1310,9 @@ __global__ __launch_bounds__(256) void thin_up2x2_kernel(seg_view small, seg_vie
   __syncthreads();
   const int64_t total = (int64_t)B * H * W;
   const int G = cp / 8;
+  float st1[NC], st2[NC];                     // bn_ws (forward): per-channel sum / sum of squares of the values this thread stores
+#pragma unroll
+  for (int co = 0; co < NC; ++co) st1[co] = st2[co] = 0.f;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const Idx3 q_ = split3(i, W, H);
     const T* sp = reinterpret_cast<const T*>(small.ptr) + view_off(small, q_.b, q_.y, q_.x);
@@ -1337,6 +1340,10 @@ __global__ __launch_bounds__(256) void thin_up2x2_kernel(seg_view small, seg_vie
 #pragma unroll
         for (int co = 0; co < NC; ++co) o.set(co, relu ? fmaxf(acc[t][co], 0.f) : acc[t][co]);
         o.store(bp + view_off(big, q_.b, 2 * q_.y + (t >> 1), 2 * q_.x + (t & 1)));
+        if (bn_ws != nullptr) {
+#pragma unroll
+          for (int co = 0; co < NC; ++co) { const float v = o.get(co); st1[co] += v; st2[co] = fmaf(v, v, st2[co]); }
+        }
       }
     } else {
       float z[4][NC];
@@ -1371,20 +1378,49 @@ __global__ __launch_bounds__(256) void thin_up2x2_kernel(seg_view small, seg_vie
       }
     }
   }
+  if (!DGRAD && bn_ws != nullptr) {           // one row [8][2] of partial sums per workgroup (the statistics pass of seg_bn_fwd_rows)
+    __shared__ float red_up[4][NC][2];
+    __syncthreads();
+#pragma unroll
+    for (int co = 0; co < NC; ++co) {
+      const float a = wave_sum(st1[co]), b2 = wave_sum(st2[co]);
+      if ((threadIdx.x & 63) == 0) { red_up[threadIdx.x >> 6][co][0] = a; red_up[threadIdx.x >> 6][co][1] = b2; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      const int c = threadIdx.x >> 1, j = threadIdx.x & 1;
+      bn_ws[((int64_t)blockIdx.x * 8 + c) * 2 + j] = c < NC ? ((red_up[0][c < NC ? c : 0][j] + red_up[1][c < NC ? c : 0][j]) + red_up[2][c < NC ? c : 0][j]) + red_up[3][c < NC ? c : 0][j] : 0.f;
+    }
+  }
 }
 
+static int thin_up_launch(const seg_view* small, const seg_view* big, int32_t B, int32_t H, int32_t W, const float* w_tf, const float* bias,
+                          int32_t cin, int32_t cout, int32_t relu, int32_t dgrad, const seg_view* mask, float* bn_ws, int32_t dtype, void* stream);
 extern "C" int seg_thin_up2x2(const seg_view* small, const seg_view* big, int32_t B, int32_t H, int32_t W, const float* w_tf, const float* bias,
                               int32_t cin, int32_t cout, int32_t relu, int32_t dgrad, const seg_view* mask, int32_t dtype, void* stream) {
+  return thin_up_launch(small, big, B, H, W, w_tf, bias, cin, cout, relu, dgrad, mask, nullptr, dtype, stream);
+}
+/* Rows of batch-norm partial sums a seg_thin_up2x2_bn launch writes (= its workgroups, <= 1024). */
+extern "C" int32_t seg_thin_up2x2_rows(int32_t B, int32_t H, int32_t W) { return (B < 1 || H < 1 || W < 1) ? 0 : grid_for((int64_t)B * H * W, 256, 1024); }
+/* Forward of seg_thin_up2x2 that also leaves the statistics rows ([rows][8][2] floats) of the batch norm consuming `big` in bn_ws
+ * (that batch norm's workspace; seg_bn_fwd_rows finishes it): models/deconvolution.py:166-168 deconv3_0 -> bn8. */
+extern "C" int seg_thin_up2x2_bn(const seg_view* small, const seg_view* big, int32_t B, int32_t H, int32_t W, const float* w_tf, const float* bias,
+                                 int32_t cin, int32_t cout, int32_t relu, float* bn_ws, int32_t dtype, void* stream) {
+  if (!bn_ws) { seg_set_error("thin_up2x2_bn: no workspace"); return SEG_ERR_ARG; }
+  return thin_up_launch(small, big, B, H, W, w_tf, bias, cin, cout, relu, 0, nullptr, bn_ws, dtype, stream);
+}
+static int thin_up_launch(const seg_view* small, const seg_view* big, int32_t B, int32_t H, int32_t W, const float* w_tf, const float* bias,
+                          int32_t cin, int32_t cout, int32_t relu, int32_t dgrad, const seg_view* mask, float* bn_ws, int32_t dtype, void* stream) {
   if (!small || !small->ptr || !big || !big->ptr || !w_tf || cin < 1 || cout < 1 || cout > 8 || B <= 0 || small->c % 8 || cin > small->c || small->c > 512 ||
       !view_ok(small, H, W, small->c) || big->cs != 8 || big->coff != 0 || !view_ok(big, 2 * H, 2 * W, 8) ||
       (mask && mask->ptr && (!dgrad || !view_ok(mask, H, W, small->c)))) {
     seg_set_error("thin_up2x2: small [H,W,cin padded to 8..512], big thin [2H,2W,<= 8]; mask only with dgrad"); return SEG_ERR_ARG;
   }
   const seg_view mk = (mask && mask->ptr) ? *mask : seg_view{nullptr, 0, 0, 0, 0, 0, 0, 0};
-  const int g = grid_for((int64_t)B * H * W, 256, 16384);
+  const int g = bn_ws ? seg_thin_up2x2_rows(B, H, W) : grid_for((int64_t)B * H * W, 256, 16384);
   const int nc = cout <= 2 ? 2 : cout <= 4 ? 4 : 8;
   const size_t lds = (size_t)(4 * nc * small->c + nc) * sizeof(float);
-#define TU_ARGS dim3(g), dim3(256), lds, ST(stream), *small, *big, w_tf, dgrad ? (const float*)nullptr : bias, cin, cout, relu, mk, B, H, W
+#define TU_ARGS dim3(g), dim3(256), lds, ST(stream), *small, *big, w_tf, dgrad ? (const float*)nullptr : bias, cin, cout, relu, mk, B, H, W, bn_ws
 #define TU_NC(TT, DG) do { if (nc == 2) SEG_LAUNCH((thin_up2x2_kernel<TT, 2, DG>), TU_ARGS); else if (nc == 4) SEG_LAUNCH((thin_up2x2_kernel<TT, 4, DG>), TU_ARGS); \
     else SEG_LAUNCH((thin_up2x2_kernel<TT, 8, DG>), TU_ARGS); } while (0)
   if (dgrad) { DISPATCH(dtype, TU_NC(float, true), TU_NC(bf16_t, true)); }

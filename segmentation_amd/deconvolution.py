@@ -207,12 +207,12 @@ class DeconvModel(BaseModel):
                 plan.add(*col_args, kernel='im2col_kernel')
         net.join_aux(plan)                     # packed weights (re-packed on the aux stream in training) are needed from here on
 
-        def act_bn(name, a):
-            """ReLU output of `name` -> batch norm (-> dropout)"""
+        def act_bn(name, a, rows=0):
+            """ReLU output of `name` -> batch norm (-> dropout); rows: statistics rows the producer of `a` left for it"""
             b = 'bn' + str(GRAPH.index(name) // 2 + 1)
             A[name] = a
             Y[b] = net.act(a.H, a.W, a.C, name=b, thin=a.thin)
-            net.bn_fwd(plan, Ly[b], bn[b], a, Y[b], training=bn_training, update_moving=update_moving)
+            net.bn_fwd(plan, Ly[b], bn[b], a, Y[b], training=bn_training, update_moving=update_moving, rows=rows)
             out = Y[b]
             if self.bayesian and b in DROP_SITES:
                 Y[b + '/drop'] = net.act(a.H, a.W, a.C, name=b + '/drop', thin=a.thin)
@@ -228,10 +228,11 @@ class DeconvModel(BaseModel):
 
         a = net.act(sz['conv1_0'], sz['conv1_0'], nk, name='conv1_0')
         if direct:
-            net.first_gen_fwd(plan, Ly['conv1_0'], x_in, H, W, self.input_channel, 5, 5, 2, pad, pad, a)
+            rows = net.first_gen_fwd(plan, Ly['conv1_0'], x_in, H, W, self.input_channel, 5, 5, 2, pad, pad, a, bn_st=bn['bn1'] if bn_training else None)
         else:
+            rows = 0
             net.conv_fwd(plan, Ly['conv1_0'], [(xin, 0, 0)], xin.H, xin.W, a)
-        t = act_bn('conv1_0', a)
+        t = act_bn('conv1_0', a, rows)
         P = {}
         P[1] = net.act(sz['pool1'], sz['pool1'], nk, name='pool1'); net.pool_k_fwd(plan, t, P[1], 2)
         for i, (cn, k) in enumerate((('conv2_0', 3), ('conv3_0', 3)), 2):
@@ -254,8 +255,8 @@ class DeconvModel(BaseModel):
         net.resize_fwd(plan, t, R)
         thin = thin_tail(self.n_classes)
         a = net.act(sz['deconv3_0'], sz['deconv3_0'], self.n_classes, name='deconv3_0', thin=thin)
-        net.up_fwd(plan, Ly['deconv3_0'], R, R.H, R.W, a)
-        t = act_bn('deconv3_0', a)             # (resize_image_with_crop_or_pad to (H, W) is the identity for even H)
+        rows = net.up_fwd(plan, Ly['deconv3_0'], R, R.H, R.W, a, bn_st=bn['bn8'] if bn_training else None)
+        t = act_bn('deconv3_0', a, rows)             # (resize_image_with_crop_or_pad to (H, W) is the identity for even H)
         A['logits'] = net.act(H, W, self.n_classes, f32=True, name='logits', thin=thin)
         net.conv_fwd(plan, Ly['conv_out'], [(t, 0, 0)], H, W, A['logits'], out_f32=True)
         A['x'], A['resize'] = xin, R

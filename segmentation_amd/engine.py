@@ -685,17 +685,27 @@ class Net(object):
                  1 if layer.relu else 0, self.dtype, kernel=kern, flops=fl, bytes=by)
         return False
 
-    def first_gen_fwd(self, plan, layer, x_f32, H, W, cin, KH, KW, stride, pad_t, pad_l, dst):
+    def first_gen_fwd(self, plan, layer, x_f32, H, W, cin, KH, KW, stride, pad_t, pad_l, dst, bn_st=None):
         """A KH x KW / stride filter on the raw float image in one pass (seg_conv_first_gen: bf16, cin <= 3, cout <= 64).  `layer`
-        holds the filter as [KH*KW*cin][cout] = HWIO (the DeconvModel keeps conv1_0 as a 1x1 layer over its im2col)."""
+        holds the filter as [KH*KW*cin][cout] = HWIO (the DeconvModel keeps conv1_0 as a 1x1 layer over its im2col).
+        bn_st (the state of the batch norm that consumes dst; 5x5/s2): the launch leaves that batch norm's statistics rows in its
+        workspace and the row count is returned -- pass it to bn_fwd(rows=...); else returns 0."""
         dv = dst.view()
         plan.keep.append(dv)
         fl = 2 * self.B * dst.H * dst.W * KH * KW * cin * layer.cout
         plan.flops += fl
         by = self.B * (H * W * cin * 4 + dst.H * dst.W * layer.cout * self.es)
+        if bn_st is not None and (KH, KW, stride) == (5, 5, 2) and os.environ.get('SEG_BN_FUSE_STATS', '1') != '0':
+            rows = int(self.lib.seg_conv_first_gen_rows(self.B, dst.H, dst.W, layer.cout))
+            plan.keep.append(bn_st)
+            plan.add(layer.name, self.lib.seg_conv_first_gen_bn, x_f32.data_ptr(), self.B, H, W, cin, self.store.p_ptr(layer.w_off),
+                     self.store.p_ptr(layer.b_off), layer.cout, KH, KW, stride, pad_t, pad_l, C.byref(dv), dst.H, dst.W, 1 if layer.relu else 0,
+                     bn_st['ws'].data_ptr(), dst.Cp, self.dtype, kernel='conv_first_gen_kernel', flops=fl, bytes=by)
+            return rows
         plan.add(layer.name, self.lib.seg_conv_first_gen, x_f32.data_ptr(), self.B, H, W, cin, self.store.p_ptr(layer.w_off),
                  self.store.p_ptr(layer.b_off), layer.cout, KH, KW, stride, pad_t, pad_l, C.byref(dv), dst.H, dst.W, 1 if layer.relu else 0,
                  self.dtype, kernel='conv_first_gen_kernel', flops=fl, bytes=by)
+        return 0
 
     def conv_fwd(self, plan, layer, srcs, Hi, Wi, dst, dst_off=(0, 0), out_f32=False, cfg=0, pool=None, ksplit=None, side=0):
         """srcs: list of (Act, oy, ox) (1 or 2 concat segments).  pool: Act of the 2x2 max-pool that consumes dst; when the
@@ -757,17 +767,27 @@ class Net(object):
         plan.flops += fl
         return Ho, Wo
 
-    def up_fwd(self, plan, layer, src, Hi, Wi, dst, cfg=0):
+    def up_fwd(self, plan, layer, src, Hi, Wi, dst, cfg=0, bn_st=None):
+        """bn_st (state of the batch norm consuming dst): where the launch can leave that batch norm's statistics rows (the thin
+        vector-ALU kernel) it does and their count is returned for bn_fwd(rows=...); else 0."""
         if dst.thin and not src.thin and layer.cout <= 8 and os.environ.get('SEG_THIN_VALU', '1') != '0':
             # into a thin tensor: the vector-ALU kernel (a thread per input pixel writes its 2x2 block of <= 8-channel records)
             sv, dv = src.view(), dst.view()
             plan.keep += [sv, dv]
             fl = 2 * self.B * Hi * Wi * 4 * layer.cin * layer.cout
+            if bn_st is not None and os.environ.get('SEG_BN_FUSE_STATS', '1') != '0':
+                rows = int(self.lib.seg_thin_up2x2_rows(self.B, Hi, Wi))
+                plan.keep.append(bn_st)
+                plan.add(layer.name, self.lib.seg_thin_up2x2_bn, C.byref(sv), C.byref(dv), self.B, Hi, Wi, self.store.p_ptr(layer.w_off),
+                         self.store.p_ptr(layer.b_off), layer.cin, layer.cout, 1 if layer.relu else 0, bn_st['ws'].data_ptr(), self.dtype,
+                         kernel='thin_up2x2_kernel', flops=fl, bytes=self.B * Hi * Wi * (src.Cp + 4 * 8) * self.es)
+                plan.flops += fl
+                return rows
             plan.add(layer.name, self.lib.seg_thin_up2x2, C.byref(sv), C.byref(dv), self.B, Hi, Wi, self.store.p_ptr(layer.w_off), self.store.p_ptr(layer.b_off),
                      layer.cin, layer.cout, 1 if layer.relu else 0, 0, None, self.dtype, kernel='thin_up2x2_kernel', flops=fl,
                      bytes=self.B * Hi * Wi * (src.Cp + 4 * 8) * self.es)
             plan.flops += fl
-            return
+            return 0
         d = L.ConvDesc()
         d.src0 = src.view(); d.src1 = L.null_view()
         d.B, d.Hi, d.Wi = self.B, Hi, Wi
@@ -785,6 +805,7 @@ class Net(object):
         by = self.B * Hi * Wi * (layer.cin + 4 * layer.cout) * self.es + 4 * layer.cin * layer.cout * self.es
         plan.add(layer.name, self.lib.seg_conv2d, C.byref(d), desc=d, flops=fl, bytes=by)
         plan.flops += fl
+        return 0
 
     def pool_fwd(self, plan, src, dst, Ho, Wo):
         sv, dv = src.view(), dst.view()
@@ -1369,10 +1390,16 @@ class Net(object):
         ws = torch.zeros(self.lib.seg_bn_ws_bytes(Cp) // 4, dtype=torch.float32, device=self.device)
         return {'moving': mov, 'stats': stats, 'ws': ws}
 
-    def bn_fwd(self, plan, layer, st, a, y, training=True, update_moving=True, decay=0.999, eps=1e-3):
+    def bn_fwd(self, plan, layer, st, a, y, training=True, update_moving=True, decay=0.999, eps=1e-3, rows=0):
+        """rows > 0: the launch that produced `a` has left that many statistics rows in st['ws'] (first_gen_fwd / up_fwd with
+        bn_st): the statistics pass over `a` is skipped (training statistics only)."""
         av, yv = a.view(), y.view()
         plan.keep += [av, yv, st]
         mov = st['moving'].data_ptr() if (update_moving or not training) else None
+        if rows > 0 and training:
+            plan.add(layer.name, self.lib.seg_bn_fwd_rows, C.byref(av), C.byref(yv), self.store.p_ptr(layer.w_off), mov, st['stats'].data_ptr(),
+                     decay, eps, self.B, a.H, a.W, a.Cp, layer.cout, st['ws'].data_ptr(), rows, self.dtype, kernel='bn_apply_kernel')
+            return
         plan.add(layer.name, self.lib.seg_bn_fwd, C.byref(av), C.byref(yv), self.store.p_ptr(layer.w_off), mov, st['stats'].data_ptr(),
                  1 if training else 0, decay, eps, self.B, a.H, a.W, a.Cp, layer.cout, st['ws'].data_ptr(), self.dtype, kernel='bn_apply_kernel')
 

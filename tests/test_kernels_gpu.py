@@ -539,6 +539,59 @@ def test_conv_first_gen(k, stride, padding, cin, cout, H, relu):
     assert U.pad_channels_zero(out)
 
 
+@pytest.mark.parametrize('which,cout,H,B', [('first', 32, 64, 3), ('first', 64, 37, 2), ('first', 20, 130, 4), ('up', 2, 40, 3), ('up', 5, 23, 2), ('up', 8, 150, 2)])
+def test_batch_norm_statistics_from_the_producing_launch(which, cout, H, B):
+    """seg_conv_first_gen_bn / seg_thin_up2x2_bn + seg_bn_fwd_rows (the DeconvModel's conv1_0 -> bn1 and deconv3_0 -> bn8,
+    models/deconvolution.py:44-50,166-168): the same activation bits, the same statistics (another summation order) and the same
+    normalised output as the producer followed by the three-stage seg_bn_fwd."""
+    dtype = L.SEG_BF16
+    rng = np.random.default_rng(cout * 7 + H)
+    W = H + 6
+    thin = which == 'up'
+    if which == 'first':
+        prod = E.Layer('f', 'conv', 1, [75], cout, 'VALID', True)
+        w = (rng.standard_normal((1, 1, 75, cout)) * 0.2).astype(np.float32)
+        Ho, pt = ops.conv_out_size(H, 5, 2, 'SAME'); Wo, pl = ops.conv_out_size(W, 5, 2, 'SAME')
+    else:
+        prod = E.Layer('f', 'up', 2, [32], cout, 'VALID', True)
+        w = (rng.standard_normal((2, 2, cout, 32)) * 0.2).astype(np.float32)
+        Ho, Wo = 2 * H, 2 * W
+    bnl = E.Layer('bn', 'bn', 1, [cout], cout)
+    if thin:
+        bnl.cout_p = 8
+    p = {'f': {'weights': w, 'biases': (rng.standard_normal(cout) * 0.1).astype(np.float32)}, 'bn': {'beta': (rng.standard_normal(cout) * 0.1).astype(np.float32)}}
+    store = U.make_store([prod, bnl], dtype, p)
+    net = E.Net(store, B, dtype, U.dev())
+    if which == 'first':
+        xt = torch.from_numpy(rng.uniform(-1, 1, (B, H, W, 3)).astype(np.float32)).to(U.dev())
+    else:
+        xs = net.act(H, W, 32); U.fill_act(xs, U.round_dtype(rng.standard_normal((B, H, W, 32)), dtype))
+    outs = []
+    for fused in (True, False):
+        a = net.act(Ho, Wo, cout, thin=thin); a.t.fill_(float('nan'))
+        y = net.act(Ho, Wo, cout, thin=thin)
+        st = net.bn_state(bnl)
+        st['ws'].fill_(float('nan'))
+        plan = E.Plan('t')
+        if which == 'first':
+            rows = net.first_gen_fwd(plan, prod, xt, H, W, 3, 5, 5, 2, pt, pl, a, bn_st=st if fused else None)
+        else:
+            rows = net.up_fwd(plan, prod, xs, H, W, a, bn_st=st if fused else None)
+        assert (rows > 0) == fused
+        net.bn_fwd(plan, bnl, st, a, y, training=True, update_moving=True, rows=rows)
+        assert [o[0] for o in plan.ops] == ['f', 'bn']
+        plan.run(U.stream()); U.sync()
+        outs.append((a.t.clone(), y.t.float().cpu().numpy(), st['stats'].cpu().numpy().copy(), st['moving'].cpu().numpy().copy()))
+    (a1, y1, s1, m1), (a0, y0, s0, m0) = outs
+    assert torch.equal(a1, a0)
+    assert np.isfinite(s1).all() and np.isfinite(y1).all()
+    Cp = s0.size // 2
+    assert np.abs(s1[:Cp] - s0[:Cp]).max() < 1e-5 * max(1.0, np.abs(s0[:Cp]).max())          # means
+    assert np.abs(s1[Cp:] / s0[Cp:] - 1).max() < 1e-4                                        # 1 / sqrt(var + eps)
+    assert np.abs(m1 - m0).max() < 1e-6
+    assert np.abs(y1 - y0).max() < 2e-2 * max(1.0, np.abs(y0).max())
+
+
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('impl,relu', [('win', True), ('old', True), ('win', False), ('old', False)])
 @pytest.mark.parametrize('pad,cin,cout,H', [(0, 3, 32, 21), (1, 3, 16, 18), (0, 1, 40, 33), (1, 2, 64, 20), (0, 3, 32, 64)])
