@@ -94,6 +94,7 @@ SIGNATURES = {
     'seg_thin_up2x2': [PV, PV, i32, i32, i32, vp, vp, i32, i32, i32, i32, PV, i32, vp],
     'seg_thin_up2x2_bn': [PV, PV, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, vp],
     'seg_thin_conv3x3': [PV, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, PV, PV, i32, i32, i32, i32, vp],
+    'seg_thin_wgrad3x3': [PV, i32, i32, i32, PV, i32, i32, i32, i32, i32, vp, vp, vp, i64, i32, vp],
     'seg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp],
     'seg_step_increment': [vp, vp],
     'seg_step_begin': [vp, vp, vp],
@@ -162,6 +163,8 @@ def load():
     lib.seg_head_xent_ws_bytes.argtypes = [C.c_int32] * 5
     lib.seg_bias_grad_ws_bytes.restype = C.c_int64
     lib.seg_bias_grad_ws_bytes.argtypes = [C.c_int32]
+    lib.seg_thin_wgrad3x3_ws_bytes.restype = C.c_int64
+    lib.seg_thin_wgrad3x3_ws_bytes.argtypes = [C.c_int32] * 2
     lib.seg_conv_first_gen_rows.restype = C.c_int32
     lib.seg_conv_first_gen_rows.argtypes = [C.c_int32] * 4
     lib.seg_thin_up2x2_rows.restype = C.c_int32

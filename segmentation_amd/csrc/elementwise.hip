@@ -29,6 +29,13 @@ SEG_DEV float wave_sum(float v) {
   return v;
 }
 
+// XCD-aware workgroup order for stencil-like walks: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2), so
+// with the identity mapping the rows above and below a workgroup's pixels are fetched by OTHER XCDs and every L2 pulls three rows
+// per row of output.  This gives XCD x the x-th contiguous eighth of the virtual ids: vertical neighbours meet in one L2.
+SEG_DEV unsigned xcd_block(unsigned b, unsigned n, int on = 1) {
+  return (on && n % 8u == 0u) ? (b % 8u) * (n / 8u) + b / 8u : b;
+}
+
 // (b, y, x[, c8]) of a flat element index.  The element counts of this path fit 32 bits; 64-bit divisions by run-time extents
 // are ~100 instructions each and were a third of the byte-moving kernels' issue time.
 struct Idx3 { int x, y, b; };
@@ -1204,7 +1211,7 @@ extern "C" int seg_sigmoid_argmax(const seg_view* logits, int32_t B, int32_t H, 
 // ------------------------------------------------------------------------------------------
 template <typename T, int NC, bool OUT_F32>
 __global__ __launch_bounds__(256) void thin_conv3x3_kernel(seg_view src, const float* w, const float* bias, int cin, int cout, int pad, int relu,
-                                                           int dgrad, seg_view mask, seg_view dst, int B, int Ho, int Wo, int Hi, int Wi) {
+                                                           int dgrad, seg_view mask, seg_view dst, int B, int Ho, int Wo, int Hi, int Wi, int remap) {
   __shared__ float sw[9 * NC * NC];          // [tap][ci][co] as THIS launch consumes it (zero above the logical counts)
   __shared__ float sb[NC];
   for (int i = threadIdx.x; i < 9 * NC * NC; i += 256) {
@@ -1218,7 +1225,8 @@ __global__ __launch_bounds__(256) void thin_conv3x3_kernel(seg_view src, const f
   __syncthreads();
   const int64_t total = (int64_t)B * Ho * Wo;
   const T* sp = reinterpret_cast<const T*>(src.ptr);
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  const unsigned vb = xcd_block(blockIdx.x, gridDim.x, remap);
+  for (int64_t i = vb * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const Idx3 q_ = split3(i, Wo, Ho);
     float acc[NC];
 #pragma unroll
@@ -1281,7 +1289,8 @@ extern "C" int seg_thin_conv3x3(const seg_view* src, int32_t B, int32_t Hi, int3
   const seg_view mk = (mask && mask->ptr) ? *mask : seg_view{nullptr, 0, 0, 0, 0, 0, 0, 0};
   const int m = cin > cout ? cin : cout;
   const int g = grid_for((int64_t)B * Ho * Wo, 256, 16384);
-#define TC_ARGS dim3(g), dim3(256), 0, ST(stream), *src, w_hwio, bias, cin, cout, pad, relu, dgrad, mk, *dst, B, Ho, Wo, Hi, Wi
+  const int remap = getenv("SEG_XCD_REMAP") ? atoi(getenv("SEG_XCD_REMAP")) : 1;
+#define TC_ARGS dim3(g), dim3(256), 0, ST(stream), *src, w_hwio, bias, cin, cout, pad, relu, dgrad, mk, *dst, B, Ho, Wo, Hi, Wi, remap
 #define TC_NC(TT, F32) do { if (m <= 2) SEG_LAUNCH((thin_conv3x3_kernel<TT, 2, F32>), TC_ARGS); \
     else if (m <= 4) SEG_LAUNCH((thin_conv3x3_kernel<TT, 4, F32>), TC_ARGS); else SEG_LAUNCH((thin_conv3x3_kernel<TT, 8, F32>), TC_ARGS); } while (0)
   if (out_f32) { DISPATCH(dtype, TC_NC(float, true), TC_NC(bf16_t, true)); }
@@ -1289,6 +1298,122 @@ extern "C" int seg_thin_conv3x3(const seg_view* src, int32_t B, int32_t Hi, int3
 #undef TC_NC
 #undef TC_ARGS
   return seg_check_launch("thin_conv3x3");
+}
+
+// ------------------------------------------------------------------------------------------
+// Filter + bias gradient of that layer (thin source, thin dZ) on the vector ALU, two stages in a fixed order:
+//   dW[u][v][ci][co] = sum_{b,y,x} src[b, y - pad + u, x - pad + v, ci] * dz[b, y, x, co],   db[co] = sum dz[b, y, x, co]
+// A thread walks output pixels and keeps TAPS x NC x NC (+ NC) sums; a workgroup leaves one row of partial sums, the second launch
+// adds the rows.  NC = 8 splits the nine taps over blockIdx.y (64 sums per thread instead of 576).  On the MFMA walk the layer is
+// 32 x 32 padded channels against 2 x 2 real ones: 317 us at 16 x 512^2 (the longest launch of the DeconvModel step) for two 67 MB
+// tensors.
+// ------------------------------------------------------------------------------------------
+constexpr int TW_ROWS = 1024;                // partial-sum rows = workgroups per tap group
+template <typename T, int NC, int TAPS>
+__global__ __launch_bounds__(256) void thin_wgrad3x3_partial_kernel(seg_view src, seg_view dz, int pad, int B, int Ho, int Wo, int Hi, int Wi, float* ws, int remap) {
+  constexpr int NA = TAPS * NC * NC;
+  const int tap0 = blockIdx.y * TAPS;
+  float acc[NA], bsum[NC];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) bsum[i] = 0.f;
+  const int64_t total = (int64_t)B * Ho * Wo;
+  const T* sp = reinterpret_cast<const T*>(src.ptr);
+  const T* zp = reinterpret_cast<const T*>(dz.ptr);
+  // a workgroup owns a CONTIGUOUS run of pixels (a few image rows) and an XCD a contiguous band of runs: the rows above and below
+  // are this workgroup's own previous / next iterations (a grid-stride walk fetched every row three times: 187 us)
+  const int64_t chunk = (total + gridDim.x - 1) / gridDim.x;
+  const int64_t p0 = (int64_t)xcd_block(blockIdx.x, gridDim.x, remap) * chunk, p1 = p0 + chunk < total ? p0 + chunk : total;
+  for (int64_t i = p0 + threadIdx.x; i < p1; i += blockDim.x) {
+    const Idx3 q_ = split3(i, Wo, Ho);
+    Vec8<T> zv; zv.load(zp + view_off(dz, q_.b, q_.y, q_.x));
+    float z[NC];
+#pragma unroll
+    for (int co = 0; co < NC; ++co) { z[co] = zv.get(co); bsum[co] += z[co]; }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int tap = tap0 + t, u = tap / 3, v = tap - 3 * u;
+      const int iy = q_.y - pad + u, ix = q_.x - pad + v;
+      if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
+      Vec8<T> xv; xv.load(sp + view_off(src, q_.b, iy, ix));
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) {
+        const float xf = xv.get(ci);
+#pragma unroll
+        for (int co = 0; co < NC; ++co) acc[(t * NC + ci) * NC + co] = fmaf(xf, z[co], acc[(t * NC + ci) * NC + co]);
+      }
+    }
+  }
+  __shared__ float red[4][NA + NC];
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) { const float a = wave_sum(acc[i]); if ((threadIdx.x & 63) == 0) red[wave][i] = a; }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) { const float a = wave_sum(bsum[i]); if ((threadIdx.x & 63) == 0) red[wave][NA + i] = a; }
+  __syncthreads();
+  // row layout: [9 * NC * NC] filter sums (tap-major) then [NC] bias sums (written by tap group 0)
+  float* row = ws + (int64_t)blockIdx.x * (9 * NC * NC + NC);
+  for (int i = threadIdx.x; i < NA + NC; i += 256) {
+    const float a = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+    if (i < NA) row[tap0 * NC * NC + i] = a;
+    else if (blockIdx.y == 0) row[9 * NC * NC + (i - NA)] = a;
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void thin_wgrad3x3_final_kernel(const float* ws, int rows, int cin, int cout, float* dw, float* db) {
+  // 8 sums x 32 row slices per workgroup, the slices meet in LDS in a fixed order (a thread walking all rows alone is 512 dependent
+  // load latencies)
+  constexpr int RL = 9 * NC * NC + NC;
+  __shared__ double part[32][8];
+  const int el = threadIdx.x & 7, sl = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + el;
+  double a = 0.0;
+  if (i < RL)
+    for (int r = sl; r < rows; r += 32) a += (double)ws[(int64_t)r * RL + i];
+  part[sl][el] = a;
+  __syncthreads();
+  if (sl != 0 || i >= RL) return;
+  a = 0.0;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) a += part[q][el];
+  if (i < 9 * NC * NC) {
+    const int tap = i / (NC * NC), ci = (i / NC) % NC, co = i % NC;
+    if (ci < cin && co < cout) dw[((int64_t)tap * cin + ci) * cout + co] = (float)a;
+  } else if (db != nullptr && i - 9 * NC * NC < cout) db[i - 9 * NC * NC] = (float)a;
+}
+
+static int thin_wgrad_nc(int cin, int cout) { const int m = cin > cout ? cin : cout; return m <= 2 ? 2 : m <= 4 ? 4 : 8; }
+extern "C" int64_t seg_thin_wgrad3x3_ws_bytes(int32_t cin, int32_t cout) {
+  if (cin < 1 || cin > 8 || cout < 1 || cout > 8) return 0;
+  const int nc = thin_wgrad_nc(cin, cout);
+  return (int64_t)TW_ROWS * (9 * nc * nc + nc) * (int64_t)sizeof(float);
+}
+
+extern "C" int seg_thin_wgrad3x3(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, const seg_view* dz, int32_t Ho, int32_t Wo, int32_t cin,
+                                 int32_t cout, int32_t pad, float* dw_hwio, float* db, void* ws, int64_t ws_bytes, int32_t dtype, void* stream) {
+  if (!src || !src->ptr || !dz || !dz->ptr || !dw_hwio || !ws || cin < 1 || cin > 8 || cout < 1 || cout > 8 || pad < 0 || pad > 2 || B <= 0 ||
+      src->cs != 8 || src->coff != 0 || dz->cs != 8 || dz->coff != 0 || !view_ok(dz, Ho, Wo, 8) || src->oy + Hi > src->H || src->ox + Wi > src->W ||
+      Ho != Hi + 2 * pad - 2 || Wo != Wi + 2 * pad - 2 || Ho < 1 || Wo < 1 || ws_bytes < seg_thin_wgrad3x3_ws_bytes(cin, cout)) {
+    seg_set_error("thin_wgrad3x3: thin views (cs 8, coff 0), 1..8 channels, Ho = Hi + 2 pad - 2, workspace of seg_thin_wgrad3x3_ws_bytes"); return SEG_ERR_ARG;
+  }
+  const int nc = thin_wgrad_nc(cin, cout);
+  const int g = grid_for((int64_t)B * Ho * Wo, 256, TW_ROWS);
+  float* wsf = reinterpret_cast<float*>(ws);
+  const int remap = getenv("SEG_XCD_REMAP") ? atoi(getenv("SEG_XCD_REMAP")) : 1;
+#define TWG_ARGS(GY) dim3(g, GY), dim3(256), 0, ST(stream), *src, *dz, pad, B, Ho, Wo, Hi, Wi, wsf, remap
+#define TWG_NC(TT) do { if (nc == 2) SEG_LAUNCH((thin_wgrad3x3_partial_kernel<TT, 2, 9>), TWG_ARGS(1)); \
+    else if (nc == 4) SEG_LAUNCH((thin_wgrad3x3_partial_kernel<TT, 4, 3>), TWG_ARGS(3)); else SEG_LAUNCH((thin_wgrad3x3_partial_kernel<TT, 8, 1>), TWG_ARGS(9)); } while (0)
+  DISPATCH(dtype, TWG_NC(float), TWG_NC(bf16_t));
+#undef TWG_NC
+#undef TWG_ARGS
+  if (int rc = seg_check_launch("thin_wgrad3x3_partial")) return rc;
+  const int rl = 9 * nc * nc + nc;
+  if (nc == 2) SEG_LAUNCH(thin_wgrad3x3_final_kernel<2>, dim3(cdiv(rl, 8)), dim3(256), 0, ST(stream), (const float*)wsf, g, cin, cout, dw_hwio, db);
+  else if (nc == 4) SEG_LAUNCH(thin_wgrad3x3_final_kernel<4>, dim3(cdiv(rl, 8)), dim3(256), 0, ST(stream), (const float*)wsf, g, cin, cout, dw_hwio, db);
+  else SEG_LAUNCH(thin_wgrad3x3_final_kernel<8>, dim3(cdiv(rl, 8)), dim3(256), 0, ST(stream), (const float*)wsf, g, cin, cout, dw_hwio, db);
+  return seg_check_launch("thin_wgrad3x3_final");
 }
 
 // 2x2 / stride-2 transposed convolution INTO a thin tensor and its data gradient, on the vector ALU (the DeconvModel's deconv3_0:

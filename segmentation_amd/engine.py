@@ -974,6 +974,10 @@ class Net(object):
         (dst_act, (oy,ox), mask_act_or_None, (moy,mox))."""
         k, pad = layer.k, layer.pad
         Ho, Wo = Hi + 2 * pad - k + 1, Wi + 2 * pad - k + 1
+        if (k == 3 and len(srcs) == 1 and srcs[0][0].thin and dz.thin and srcs[0][1:] == (0, 0) and dz_off == (0, 0) and layer.cin <= 8 and layer.cout <= 8
+                and os.environ.get('SEG_THIN_VALU', '1') != '0' and os.environ.get('SEG_THIN_WGRAD', '1') != '0'):
+            self._thin_wgrad(plan, layer, srcs[0][0], Hi, Wi, dz, Ho, Wo, wgrad_sid)
+            return self._conv_bwd_data(plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off, cfg, dgrad_ksplit, Ho, Wo)
         w = L.WgradDesc()
         w.src0 = srcs[0][0].view_wide(srcs[0][1], srcs[0][2])
         w.src1 = srcs[1][0].view_wide(srcs[1][1], srcs[1][2]) if len(srcs) > 1 else L.null_view()
@@ -992,6 +996,26 @@ class Net(object):
         self._wg_bytes = self.B * (Hi * Wi * layer.cin + Ho * Wo * layer.cout) * self.es + k * k * layer.cin * layer.cout * 4
         self._add_wgrad(plan, layer.name + '/dw', w, fl, sid=wgrad_sid)
         plan.flops += fl
+        return self._conv_bwd_data(plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off, cfg, dgrad_ksplit, Ho, Wo)
+
+    def _thin_wgrad(self, plan, layer, src, Hi, Wi, dz, Ho, Wo, sid=None):
+        """3x3 filter + bias gradient between thin tensors on the vector ALU (seg_thin_wgrad3x3), on a filter-gradient stream"""
+        sv, zv = src.view(), dz.view()
+        nbytes = int(self.lib.seg_thin_wgrad3x3_ws_bytes(layer.cin, layer.cout))
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+        plan.keep += [sv, zv, ws]
+        fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
+        if sid is None:
+            sid = self._pick_wgrad_stream(15.0 + self.B * Ho * Wo * 32 * self.es / 3e6)
+        if not self.side_enabled:
+            sid = 0
+        plan.add(layer.name + '/dw', self.lib.seg_thin_wgrad3x3, C.byref(sv), self.B, Hi, Wi, C.byref(zv), Ho, Wo, layer.cin, layer.cout, layer.pad,
+                 self.store.g_ptr(layer.w_off), self.store.g_ptr(layer.b_off) if layer.nbias else None, ws.data_ptr(), nbytes, self.dtype,
+                 kernel='thin_wgrad3x3_partial_kernel', flops=fl, bytes=self.B * (Hi * Wi + Ho * Wo) * 8 * self.es, side=sid)
+        plan.flops += fl
+
+    def _conv_bwd_data(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off, cfg, dgrad_ksplit, Ho, Wo):
+        k, pad = layer.k, layer.pad
         n_off = 0
         merged = (len(dsrcs) == 2 and dsrcs[0] is not None and dsrcs[1] is not None and not any(len(x) > 4 and x[4] for x in dsrcs)
                   and os.environ.get('SEG_MERGE_DGRAD', '1') != '0')
