@@ -443,6 +443,13 @@ int seg_bn_fwd(const seg_view* a, const seg_view* y, const float* beta, float* m
  * [C][2] of per-channel (sum, sum of squares) over disjoint pixel sets. */
 int seg_bn_fwd_rows(const seg_view* a, const seg_view* y, const float* beta, float* moving, float* stats, float decay, float eps,
                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t rows, int32_t dtype, void* stream);
+/* slim.batch_norm + the k x k / stride-k slim.max_pool2d behind it (models/deconvolution.py:50-75: bn1 -> pool 2x2, bn2 / bn3 -> pool
+ * 3x3) in one pass over `a`: pooled [H/k, W/k] is bit for bit what seg_bn_fwd + seg_maxpool_k_fwd write (normalisation and rounding
+ * are increasing maps, so they commute with the maximum) and the normalised full-resolution tensor does not exist;
+ * seg_maxpool_k_bwd then takes `a` as its source (the same first maximum).  rows: 0, or the statistics rows already in ws. */
+int seg_bn_pool_fwd(const seg_view* a, const seg_view* pooled, const float* beta, float* moving, float* stats, int32_t training,
+                    float decay, float eps, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t rows,
+                    int32_t k, int32_t dtype, void* stream);
 int seg_bn_relu_bwd(const seg_view* a, const seg_view* dy, const seg_view* dz, const float* stats, float* dbeta, int32_t dbeta_add,
                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype, void* stream);
 

@@ -478,6 +478,47 @@ SEG_DEV void lerp_coord(int o, float scale, int n_in, int& i0, int& i1, float& l
   l = f - floorf(f);
 }
 
+// Batch norm + the k x k / stride-k max-pool behind it in one pass (DeconvModel bn1 -> pool 2x2, bn2 / bn3 -> pool 3x3,
+// models/deconvolution.py:50-75): the normalisation is an increasing map per channel (rstd > 0) and so is the rounding to T, hence
+// max over the window of round(bn(a)) == round(bn(max a)) bit for bit -- the normalised full-resolution tensor is never written or
+// read (it had no other reader: the pool's backward finds the same first maximum in `a`).
+template <typename T>
+__global__ void bn_pool_apply_kernel(seg_view a, seg_view out, const float* stats_g, const float* beta_g, int k, int B, int Ho, int Wo, int C8, int C, int c_log) {
+  extern __shared__ float sst[];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) { sst[c] = stats_g[c]; sst[C + c] = stats_g[C + c]; sst[2 * C + c] = c < c_log ? beta_g[c] : 0.f; }
+  __syncthreads();
+  const float* stats = sst;
+  const float* aux = sst + 2 * C;
+  const int64_t total = (int64_t)B * Ho * Wo * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c8, x, y, b;
+    if (i <= 0x7fffffff) {
+      unsigned t = (unsigned)i;
+      c8 = t % (unsigned)C8; t /= (unsigned)C8;
+      x = t % (unsigned)Wo; t /= (unsigned)Wo;
+      y = t % (unsigned)Ho; b = t / (unsigned)Ho;
+    } else {
+      int64_t t = i;
+      c8 = t % C8; t /= C8;
+      x = t % Wo; t /= Wo;
+      y = t % Ho; b = (int)(t / Ho);
+    }
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+    for (int u = 0; u < k; ++u)
+      for (int v = 0; v < k; ++v) {
+        Vec8<T> av; av.load(reinterpret_cast<const T*>(a.ptr) + view_off(a, b, y * k + u, x * k + v) + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], av.get(e));
+      }
+    Vec8<T> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int c = c8 * 8 + e; o.set(e, c < c_log ? (m[e] - stats[c]) * stats[C + c] + aux[c] : 0.f); }
+    o.store(reinterpret_cast<T*>(out.ptr) + view_off(out, b, y, x) + c8 * 8);
+  }
+}
+
 template <typename T>
 __global__ void resize_fwd_kernel(seg_view src, int Hs, int Ws, seg_view dst, int Hd, int Wd, int B, int C8) {
   const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
@@ -796,7 +837,7 @@ static int bn_nb(int64_t npix, int C8) {
 
 static int bn_fwd_launch(const seg_view* a, const seg_view* y, const float* beta, float* moving, float* stats, int32_t training,
                          float decay, float eps, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t rows, int32_t dtype,
-                         void* stream);
+                         void* stream, int32_t pool_k = 0);
 extern "C" int seg_bn_fwd(const seg_view* a, const seg_view* y, const float* beta, float* moving, float* stats, int32_t training,
                           float decay, float eps, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype,
                           void* stream) {
@@ -809,10 +850,20 @@ extern "C" int seg_bn_fwd_rows(const seg_view* a, const seg_view* y, const float
   if (rows < 1 || rows > BN_NB) { seg_set_error("bn_fwd_rows: 1..%d rows", BN_NB); return SEG_ERR_ARG; }
   return bn_fwd_launch(a, y, beta, moving, stats, 1, decay, eps, B, H, W, C, c_log, ws, rows, dtype, stream);
 }
+/* seg_bn_fwd with the k x k / stride-k max-pool (VALID) that consumes it: `pooled` [H/k, W/k] = max_pool(batch_norm(a)), bit for
+ * bit what seg_bn_fwd + seg_maxpool_k_fwd write, without the normalised full-resolution tensor (seg_maxpool_k_bwd then takes `a` as
+ * its source: the same first maximum).  rows: as seg_bn_fwd_rows (0: statistics pass over `a` here). */
+extern "C" int seg_bn_pool_fwd(const seg_view* a, const seg_view* pooled, const float* beta, float* moving, float* stats, int32_t training,
+                               float decay, float eps, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t rows,
+                               int32_t k, int32_t dtype, void* stream) {
+  if (k < 1 || k > 8 || H < k || W < k || rows < 0 || rows > BN_NB || (rows > 0 && !training)) { seg_set_error("bn_pool_fwd: pool 1..8, rows 0..%d (training only)", BN_NB); return SEG_ERR_ARG; }
+  return bn_fwd_launch(a, pooled, beta, moving, stats, training, decay, eps, B, H, W, C, c_log, ws, rows, dtype, stream, k);
+}
 static int bn_fwd_launch(const seg_view* a, const seg_view* y, const float* beta, float* moving, float* stats, int32_t training,
                          float decay, float eps, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t rows, int32_t dtype,
-                         void* stream) {
-  if (!a || !y || !beta || !stats || !ws || C <= 0 || C % 8 || C > 2048 || c_log <= 0 || c_log > C || !view_ok(*a, H, W, C) || !view_ok(*y, H, W, C) ||
+                         void* stream, int32_t pool_k) {
+  const int yH = pool_k ? H / pool_k : H, yW = pool_k ? W / pool_k : W;
+  if (!a || !y || !beta || !stats || !ws || C <= 0 || C % 8 || C > 2048 || c_log <= 0 || c_log > C || !view_ok(*a, H, W, C) || !view_ok(*y, yH, yW, C) ||
       (!training && !moving) || (dtype != SEG_F32 && dtype != SEG_BF16)) { seg_set_error("bn_fwd: bad arguments"); return SEG_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   const int64_t npix = (int64_t)B * H * W;
@@ -826,6 +877,12 @@ static int bn_fwd_launch(const seg_view* a, const seg_view* y, const float* beta
   SEG_LAUNCH(bn_final_kernel<0>, dim3((C + 7) / 8), dim3(256), 0, st, (const float*)ws, training ? nb : 0, C, c_log, 1.0 / (double)npix, eps, decay,
              training, moving, stats, (float*)nullptr, (float*)nullptr, 0);
   if (int rc = seg_check_launch("bn_final")) return rc;
+  if (pool_k) {
+    const int gp = grid_for((int64_t)B * yH * yW * (C / 8));
+    if (dtype == SEG_F32) SEG_LAUNCH(bn_pool_apply_kernel<float>, dim3(gp), dim3(256), (size_t)C * 12, st, *a, *y, (const float*)stats, beta, pool_k, B, yH, yW, C / 8, C, c_log);
+    else SEG_LAUNCH(bn_pool_apply_kernel<bf16_t>, dim3(gp), dim3(256), (size_t)C * 12, st, *a, *y, (const float*)stats, beta, pool_k, B, yH, yW, C / 8, C, c_log);
+    return seg_check_launch("bn_pool_apply");
+  }
   const int g = grid_for(npix * (C / 8));
   if (dtype == SEG_F32) SEG_LAUNCH((bn_apply_kernel<float, 0>), dim3(g), dim3(256), (size_t)C * 16, st, *a, none, *y, (const float*)stats, beta, B, H, W, C / 8, C, c_log);
   else SEG_LAUNCH((bn_apply_kernel<bf16_t, 0>), dim3(g), dim3(256), (size_t)C * 16, st, *a, none, *y, (const float*)stats, beta, B, H, W, C / 8, C, c_log);

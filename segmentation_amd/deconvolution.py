@@ -227,19 +227,34 @@ class DeconvModel(BaseModel):
             return out
 
         a = net.act(sz['conv1_0'], sz['conv1_0'], nk, name='conv1_0')
+        P = {}
+
+        def bn_pool(name, a, pooled, k, rows=0):
+            """ReLU output of `name` -> batch norm -> k x k max-pool.  bf16 without a dropout in between: one pass, the normalised
+            tensor is never stored and Y[bn + '/poolsrc'] = a tells the backward plan where the pool finds its maxima."""
+            b = 'bn' + str(GRAPH.index(name) // 2 + 1)
+            if net.dtype == L.SEG_BF16 and not (self.bayesian and b in DROP_SITES) and os.environ.get('SEG_BN_POOL', '1') != '0':
+                A[name] = a
+                Y[b] = None
+                Y[b + '/poolsrc'] = a
+                net.bn_pool_fwd(plan, Ly[b], bn[b], a, pooled, k, training=bn_training, update_moving=update_moving, rows=rows)
+                return
+            t_ = act_bn(name, a, rows)
+            Y[b + '/poolsrc'] = t_
+            net.pool_k_fwd(plan, t_, pooled, k)
+
         if direct:
             rows = net.first_gen_fwd(plan, Ly['conv1_0'], x_in, H, W, self.input_channel, 5, 5, 2, pad, pad, a, bn_st=bn['bn1'] if bn_training else None)
         else:
             rows = 0
             net.conv_fwd(plan, Ly['conv1_0'], [(xin, 0, 0)], xin.H, xin.W, a)
-        t = act_bn('conv1_0', a, rows)
-        P = {}
-        P[1] = net.act(sz['pool1'], sz['pool1'], nk, name='pool1'); net.pool_k_fwd(plan, t, P[1], 2)
+        P[1] = net.act(sz['pool1'], sz['pool1'], nk, name='pool1')
+        bn_pool('conv1_0', a, P[1], 2, rows)
         for i, (cn, k) in enumerate((('conv2_0', 3), ('conv3_0', 3)), 2):
             a = net.act(sz[cn], sz[cn], Ly[cn].cout, name=cn)
             net.conv_fwd(plan, Ly[cn], [(P[i - 1], 0, 0)], P[i - 1].H, P[i - 1].W, a)
-            t = act_bn(cn, a)
-            P[i] = net.act(sz['pool%d' % i], sz['pool%d' % i], Ly[cn].cout, name='pool%d' % i); net.pool_k_fwd(plan, t, P[i], k)
+            P[i] = net.act(sz['pool%d' % i], sz['pool%d' % i], Ly[cn].cout, name='pool%d' % i)
+            bn_pool(cn, a, P[i], k)
         a = net.act(sz['conv4_0'], sz['conv4_0'], Ly['conv4_0'].cout, name='conv4_0')
         net.conv_fwd(plan, Ly['conv4_0'], [(P[3], 0, 0)], P[3].H, P[3].W, a)
         t = act_bn('conv4_0', a)
@@ -330,14 +345,14 @@ class DeconvModel(BaseModel):
         dP = {3: like(P[3], 'dpool3')}
         net.conv_bwd(seg, Ly['conv4_0'], [(P[3], 0, 0)], P[3].H, P[3].W, dz, [(dP[3], (0, 0), None, (0, 0))])
         for i, (cn, b, k) in ((3, ('conv3_0', 'bn3', 3)), (2, ('conv2_0', 'bn2', 3))):
-            src = last(b)
+            src = Y[b + '/poolsrc']                  # (the normalised tensor, its dropout, or -- fused forward -- the pre-BN activation)
             d = like(src, 'd_' + b + '_out')
             net.pool_k_bwd(seg, src, dP[i], d, k)
             dz = bn_bwd(b, cn, d)
             dP[i - 1] = like(P[i - 1], 'dpool%d' % (i - 1))
             net.conv_bwd(seg, Ly[cn], [(P[i - 1], 0, 0)], P[i - 1].H, P[i - 1].W, dz, [(dP[i - 1], (0, 0), None, (0, 0))])
-        d = like(Y['bn1'], 'd_bn1')
-        net.pool_k_bwd(seg, Y['bn1'], dP[1], d, 2)
+        d = like(Y['bn1/poolsrc'], 'd_bn1')
+        net.pool_k_bwd(seg, Y['bn1/poolsrc'], dP[1], d, 2)
         dz = bn_bwd('bn1', 'conv1_0', d)
         net.conv_bwd(seg, Ly['conv1_0'], [(A['x'], 0, 0)], A['x'].H, A['x'].W, dz, [None], wgrad_sid=col_sid)
         self.grads_act = G

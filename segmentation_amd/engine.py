@@ -1427,6 +1427,16 @@ class Net(object):
         plan.add(layer.name, self.lib.seg_bn_fwd, C.byref(av), C.byref(yv), self.store.p_ptr(layer.w_off), mov, st['stats'].data_ptr(),
                  1 if training else 0, decay, eps, self.B, a.H, a.W, a.Cp, layer.cout, st['ws'].data_ptr(), self.dtype, kernel='bn_apply_kernel')
 
+    def bn_pool_fwd(self, plan, layer, st, a, pooled, k, training=True, update_moving=True, decay=0.999, eps=1e-3, rows=0):
+        """batch norm + the k x k / stride-k max-pool that consumes it in one pass (seg_bn_pool_fwd): `pooled` is bit for bit
+        max_pool(batch_norm(a)); the normalised tensor is not produced -- pool_k_bwd takes `a` as its source."""
+        av, pv = a.view(), pooled.view()
+        plan.keep += [av, pv, st]
+        mov = st['moving'].data_ptr() if (update_moving or not training) else None
+        plan.add(layer.name + '+pool%d' % k, self.lib.seg_bn_pool_fwd, C.byref(av), C.byref(pv), self.store.p_ptr(layer.w_off), mov, st['stats'].data_ptr(),
+                 1 if training else 0, decay, eps, self.B, a.H, a.W, a.Cp, layer.cout, st['ws'].data_ptr(), rows if training else 0, k, self.dtype,
+                 kernel='bn_pool_apply_kernel')
+
     def bn_relu_bwd(self, plan, layer, st, a, dy, dz, dbeta_ptr=None, dbeta_add=False):
         """dbeta goes to the layer's slot of the gradient arena (dbeta_add: added to it -- a second batch through the same
         layer) or to dbeta_ptr (a scratch buffer: data-gradient-only passes)"""

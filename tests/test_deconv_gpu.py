@@ -142,6 +142,52 @@ def test_batch_norm_fwd_bwd(dtype, B, H, W, Cc):
 
 
 @pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('training', [True, False])
+@pytest.mark.parametrize('B,H,W,Cc,k', [(2, 13, 11, 8, 2), (3, 40, 37, 40, 3), (1, 9, 9, 256, 3), (4, 64, 64, 32, 2), (2, 31, 50, 64, 3)])
+def test_batch_norm_and_pool_in_one_pass(dtype, B, H, W, Cc, k, training):
+    """seg_bn_pool_fwd == seg_bn_fwd followed by seg_maxpool_k_fwd, bit for bit (pooled map, batch statistics, moving averages), and
+    the pool's backward routes to the same positions whether it looks for the maxima in the normalised tensor or in `a`
+    (models/deconvolution.py:50-75: bn1 -> pool 2x2, bn2 / bn3 -> pool 3x3)."""
+    rng = np.random.default_rng(H * 3 + Cc + k)
+    layer = E.Layer('bn', 'bn', 1, [Cc], Cc)
+    store, p = _store([layer], dtype, rng)
+    net = E.Net(store, B, dtype, U.dev())
+    av = np.maximum(U.round_dtype(rng.standard_normal((B, H, W, Cc)) + 0.3, dtype), 0)      # a ReLU output (zeros tie)
+    a = net.act(H, W, Cc); U.fill_act(a, av)
+    Hp, Wp = H // k, W // k
+    res = []
+    for fused in (False, True):
+        st = net.bn_state(layer)
+        mov = st['moving'].cpu().numpy(); mov[:Cc] = 0.05; mov[layer.cout_p:layer.cout_p + Cc] = 0.8; st['moving'].copy_(torch.from_numpy(mov))
+        pooled = net.act(Hp, Wp, Cc); pooled.t.fill_(7.0)
+        plan = E.Plan('f')
+        if fused:
+            net.bn_pool_fwd(plan, layer, st, a, pooled, k, training=training, update_moving=training)
+            src = a
+        else:
+            y = net.act(H, W, Cc)
+            net.bn_fwd(plan, layer, st, a, y, training=training, update_moving=training)
+            net.pool_k_fwd(plan, y, pooled, k)
+            src = y
+        dpv = U.round_dtype(np.random.default_rng(5).standard_normal((B, Hp, Wp, Cc)), dtype)
+        dp = net.act(Hp, Wp, Cc); U.fill_act(dp, dpv)
+        dsrc = net.act(H, W, Cc); dsrc.t.fill_(3.0)
+        net.pool_k_bwd(plan, src, dp, dsrc, k)
+        plan.run(U.stream()); U.sync()
+        res.append((pooled.t.clone(), st['stats'].clone(), st['moving'].clone(), dsrc.t.clone()))
+    for x0, x1 in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(x0, x1)
+    assert U.pad_channels_zero(pooled)
+    # the routing: the first maximum of `a` in each window -- what the float32 reference graph routes to (its normalised values are
+    # distinct wherever a's are); the rounded normalised tensor of the two-pass form can hold ties that `a` does not
+    _, idx = ops.max_pool_k(av, k)
+    want = ops.max_pool_k_bwd(dpv, idx, (H, W), k)
+    assert np.array_equal(res[1][3][..., :Cc].float().cpu().numpy().astype(np.float64), want)
+    diff = (res[0][3] != res[1][3]).float().mean().item()
+    assert diff < (1e-6 if dtype == L.SEG_F32 else 0.02)          # (bf16: a few windows per thousand tie after rounding)
+
+
+@pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('Hs,Ws,Hd,Wd,Cc', [(13, 13, 32, 32, 8), (29, 29, 80, 80, 16), (9, 12, 9, 12, 8), (20, 16, 7, 5, 40), (5, 7, 11, 9, 8)])
 def test_resize_bilinear(dtype, Hs, Ws, Hd, Wd, Cc):
     B = 2
