@@ -450,6 +450,10 @@ int seg_bn_fwd_rows(const seg_view* a, const seg_view* y, const float* beta, flo
 int seg_bn_pool_fwd(const seg_view* a, const seg_view* pooled, const float* beta, float* moving, float* stats, int32_t training,
                     float decay, float eps, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t rows,
                     int32_t k, int32_t dtype, void* stream);
+/* Backward of that pair: seg_maxpool_k_bwd (its source = `a`) + seg_bn_relu_bwd in two passes over `a`, the pool's full-resolution
+ * gradient never written.  dz = masked pre-activation gradient in front of the batch norm, dbeta as seg_bn_relu_bwd. */
+int seg_bn_pool_relu_bwd(const seg_view* a, const seg_view* dpool, const seg_view* dz, const float* stats, float* dbeta, int32_t dbeta_add,
+                         int32_t k, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype, void* stream);
 int seg_bn_relu_bwd(const seg_view* a, const seg_view* dy, const seg_view* dz, const float* stats, float* dbeta, int32_t dbeta_add,
                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype, void* stream);
 

@@ -117,6 +117,7 @@ SIGNATURES = {
     'seg_bn_fwd': [PV, PV, vp, vp, vp, i32, f32, f32, i32, i32, i32, i32, i32, vp, i32, vp],
     'seg_bn_fwd_rows': [PV, PV, vp, vp, vp, f32, f32, i32, i32, i32, i32, i32, vp, i32, i32, vp],
     'seg_bn_pool_fwd': [PV, PV, vp, vp, vp, i32, f32, f32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp],
+    'seg_bn_pool_relu_bwd': [PV, PV, PV, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp],
     'seg_bn_relu_bwd': [PV, PV, PV, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp],
     'seg_resize_bilinear_fwd': [PV, i32, i32, PV, i32, i32, i32, i32, i32, vp],
     'seg_resize_bilinear_bwd': [PV, i32, i32, PV, i32, i32, i32, i32, i32, vp],

@@ -519,6 +519,111 @@ __global__ void bn_pool_apply_kernel(seg_view a, seg_view out, const float* stat
   }
 }
 
+// Backward of that pair in two passes over `a` instead of three over `a` and two over the pool's full-resolution gradient: the
+// gradient behind the batch norm is dpool at the first maximum of each window and zero elsewhere, so
+//   sum dy = sum dpool,   sum dy * xhat = sum_windows dpool * xhat(max a)          (statistics: windows only)
+//   dz = [a > 0] * rstd * (dy - mean(dy) - xhat * mean(dy * xhat))                  (every pixel, dy rebuilt per window)
+// and that gradient tensor is never written (seg_maxpool_k_bwd + seg_bn_relu_bwd: 486 MB for the DeconvModel's bn1 at 16 x 512^2,
+// here 235 MB).  The means are over ALL B*H*W pixels, as in seg_bn_relu_bwd.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_pool_partial_bwd_kernel(seg_view a, seg_view dpool, const float* stats, int k, int B, int Hp, int Wp, int C, float* ws) {
+  __shared__ float red[256][17];
+  const int C8 = C / 8, PL = 256 / C8;
+  const int tid = threadIdx.x, c8 = tid % C8, pl = tid / C8;
+  const int64_t nwin = (int64_t)B * Hp * Wp;
+  const int64_t chunk = (nwin + gridDim.x - 1) / gridDim.x;
+  const int64_t p0 = (int64_t)blockIdx.x * chunk, p1 = p0 + chunk < nwin ? p0 + chunk : nwin;
+  float s1[8], s2[8], mean[8], rstd[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = s2[e] = 0.f; mean[e] = 0.f; rstd[e] = 1.f; }
+  if (pl < PL) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { mean[e] = stats[c8 * 8 + e]; rstd[e] = stats[C + c8 * 8 + e]; }
+    for (int64_t p = p0 + pl; p < p1; p += PL) {
+      int64_t t = p;
+      const int wx = t % Wp; t /= Wp;
+      const int wy = t % Hp; const int b = t / Hp;
+      float m[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+      for (int u = 0; u < k; ++u)
+        for (int v = 0; v < k; ++v) {
+          Vec8<T> av; av.load(reinterpret_cast<const T*>(a.ptr) + view_off(a, b, wy * k + u, wx * k + v) + c8 * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], av.get(e));
+        }
+      Vec8<T> gv; gv.load(reinterpret_cast<const T*>(dpool.ptr) + view_off(dpool, b, wy, wx) + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float g = gv.get(e); s1[e] += g; s2[e] = fmaf(g, (m[e] - mean[e]) * rstd[e], s2[e]); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[tid][e] = s1[e]; red[tid][8 + e] = s2[e]; }
+  __syncthreads();
+  for (int idx = tid; idx < C8 * 16; idx += 256) {
+    const int cc = idx / 16, j = idx % 16;
+    float s = 0.f;
+    for (int q = 0; q < PL; ++q) s += red[q * C8 + cc][j];
+    ws[((int64_t)blockIdx.x * C + cc * 8 + (j & 7)) * 2 + (j >> 3)] = s;
+  }
+}
+
+template <typename T>
+__global__ void bn_pool_apply_bwd_kernel(seg_view a, seg_view dpool, seg_view dz, const float* stats_g, const float* means_g, int k, int B, int H, int W,
+                                         int C8, int C) {
+  extern __shared__ float sst[];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) { sst[c] = stats_g[c]; sst[C + c] = stats_g[C + c]; sst[2 * C + c] = means_g[c]; sst[3 * C + c] = means_g[C + c]; }
+  __syncthreads();
+  const float* stats = sst;
+  const float* aux = sst + 2 * C;
+  const int Ho = H / k, Wo = W / k, Hw = (H + k - 1) / k, Ww = (W + k - 1) / k;
+  const int64_t total = (int64_t)B * Hw * Ww * C8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c8, wx, wy, b;
+    if (i <= 0x7fffffff) {
+      unsigned t = (unsigned)i;
+      c8 = t % (unsigned)C8; t /= (unsigned)C8;
+      wx = t % (unsigned)Ww; t /= (unsigned)Ww;
+      wy = t % (unsigned)Hw; b = t / (unsigned)Hw;
+    } else {
+      int64_t t = i;
+      c8 = t % C8; t /= C8;
+      wx = t % Ww; t /= Ww;
+      wy = t % Hw; b = (int)(t / Hw);
+    }
+    const bool full = wy < Ho && wx < Wo;
+    float m[8]; int mi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; mi[e] = -1; }
+    Vec8<T> dp; dp.zero();
+    if (full) {
+      dp.load(reinterpret_cast<const T*>(dpool.ptr) + view_off(dpool, b, wy, wx) + c8 * 8);
+      for (int u = 0; u < k; ++u)
+        for (int v = 0; v < k; ++v) {
+          Vec8<T> x; x.load(reinterpret_cast<const T*>(a.ptr) + view_off(a, b, wy * k + u, wx * k + v) + c8 * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float xv = x.get(e); if (xv > m[e] || mi[e] < 0) { m[e] = xv; mi[e] = u * k + v; } }
+        }
+    }
+    for (int u = 0; u < k; ++u)
+      for (int v = 0; v < k; ++v) {
+        const int yy = wy * k + u, xx = wx * k + v;
+        if (yy >= H || xx >= W) continue;
+        Vec8<T> av; av.load(reinterpret_cast<const T*>(a.ptr) + view_off(a, b, yy, xx) + c8 * 8);      // (second touch: L1 / L2)
+        Vec8<T> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = c8 * 8 + e;
+          const float dy = (full && mi[e] == u * k + v) ? dp.get(e) : 0.f;
+          const float xh = (av.get(e) - stats[c]) * stats[C + c];
+          const float da = stats[C + c] * (dy - aux[c] - xh * aux[C + c]);
+          o.set(e, av.get(e) > 0.f ? da : 0.f);
+        }
+        o.store(reinterpret_cast<T*>(dz.ptr) + view_off(dz, b, yy, xx) + c8 * 8);
+      }
+  }
+}
+
 template <typename T>
 __global__ void resize_fwd_kernel(seg_view src, int Hs, int Ws, seg_view dst, int Hd, int Wd, int B, int C8) {
   const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
@@ -907,6 +1012,30 @@ extern "C" int seg_bn_relu_bwd(const seg_view* a, const seg_view* dy, const seg_
   if (dtype == SEG_F32) SEG_LAUNCH((bn_apply_kernel<float, 1>), dim3(g), dim3(256), (size_t)C * 16, st, *a, *dy, *dz, stats, (const float*)means, B, H, W, C / 8, C, c_log);
   else SEG_LAUNCH((bn_apply_kernel<bf16_t, 1>), dim3(g), dim3(256), (size_t)C * 16, st, *a, *dy, *dz, stats, (const float*)means, B, H, W, C / 8, C, c_log);
   return seg_check_launch("bn_apply_bwd");
+}
+
+/* seg_maxpool_k_bwd (source `a`) + seg_bn_relu_bwd in two passes, without the pool's full-resolution gradient tensor: dz = masked
+ * pre-activation gradient of the layer in front of the batch norm, dbeta as seg_bn_relu_bwd; dpool [H/k, W/k]. */
+extern "C" int seg_bn_pool_relu_bwd(const seg_view* a, const seg_view* dpool, const seg_view* dz, const float* stats, float* dbeta, int32_t dbeta_add,
+                                    int32_t k, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t dtype, void* stream) {
+  if (!a || !dpool || !dz || !stats || !dbeta || !ws || k < 1 || k > 8 || H < k || W < k || C <= 0 || C % 8 || C > 2048 || c_log <= 0 || c_log > C ||
+      !view_ok(*a, H, W, C) || !view_ok(*dz, H, W, C) || !view_ok(*dpool, H / k, W / k, C) || (dtype != SEG_F32 && dtype != SEG_BF16)) {
+    seg_set_error("bn_pool_relu_bwd: bad arguments"); return SEG_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  const int Hp = H / k, Wp = W / k;
+  const int64_t npix = (int64_t)B * H * W, nwin = (int64_t)B * Hp * Wp;
+  const int nb = bn_nb(nwin * 4, C / 8);                     // (a window is k*k loads: workgroups pay earlier than per pixel)
+  float* means = ws + (int64_t)BN_NB * C * 2;
+  if (dtype == SEG_F32) SEG_LAUNCH(bn_pool_partial_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, *a, *dpool, stats, k, B, Hp, Wp, C, ws);
+  else SEG_LAUNCH(bn_pool_partial_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, *a, *dpool, stats, k, B, Hp, Wp, C, ws);
+  if (int rc = seg_check_launch("bn_pool_partial_bwd")) return rc;
+  SEG_LAUNCH(bn_final_kernel<1>, dim3((C + 7) / 8), dim3(256), 0, st, (const float*)ws, nb, C, c_log, 1.0 / (double)npix, 0.f, 0.f, 1,
+             (float*)nullptr, (float*)nullptr, means, dbeta, dbeta_add);
+  if (int rc = seg_check_launch("bn_final_bwd")) return rc;
+  const int g = grid_for((int64_t)B * ((H + k - 1) / k) * ((W + k - 1) / k) * (C / 8));
+  if (dtype == SEG_F32) SEG_LAUNCH(bn_pool_apply_bwd_kernel<float>, dim3(g), dim3(256), (size_t)C * 16, st, *a, *dpool, *dz, stats, (const float*)means, k, B, H, W, C / 8, C);
+  else SEG_LAUNCH(bn_pool_apply_bwd_kernel<bf16_t>, dim3(g), dim3(256), (size_t)C * 16, st, *a, *dpool, *dz, stats, (const float*)means, k, B, H, W, C / 8, C);
+  return seg_check_launch("bn_pool_apply_bwd");
 }
 
 extern "C" int seg_resize_bilinear_fwd(const seg_view* src, int32_t Hs, int32_t Ws, const seg_view* dst, int32_t Hd, int32_t Wd, int32_t B,

@@ -320,6 +320,17 @@ class DeconvModel(BaseModel):
             return G[name]
 
         last = lambda b: Y[b + '/drop'] if (self.bayesian and b in DROP_SITES) else Y[b]
+
+        def pool_bn_bwd(b, cn, dpool, k):
+            """pooled gradient -> masked pre-activation gradient of layer `cn` through the max-pool and batch norm `b`"""
+            src = Y[b + '/poolsrc']                  # (the normalised tensor, its dropout, or -- fused forward -- the pre-BN activation)
+            if Y[b] is None and os.environ.get('SEG_BN_POOL_BWD', '1') != '0':
+                G[cn] = like(A[cn], 'dz_' + cn)
+                net.bn_pool_relu_bwd(seg, Ly[b], self.bn[b], A[cn], dpool, G[cn], k)
+                return G[cn]
+            d_ = like(src, 'd_' + b + '_out')
+            net.pool_k_bwd(seg, src, dpool, d_, k)
+            return bn_bwd(b, cn, d_)
         # conv_out
         dY8 = like(Y['bn8'], 'd_bn8')
         net.conv_bwd(seg, Ly['conv_out'], [(Y['bn8'], 0, 0)], H, W, dlog, [(dY8, (0, 0), None, (0, 0))])
@@ -345,15 +356,10 @@ class DeconvModel(BaseModel):
         dP = {3: like(P[3], 'dpool3')}
         net.conv_bwd(seg, Ly['conv4_0'], [(P[3], 0, 0)], P[3].H, P[3].W, dz, [(dP[3], (0, 0), None, (0, 0))])
         for i, (cn, b, k) in ((3, ('conv3_0', 'bn3', 3)), (2, ('conv2_0', 'bn2', 3))):
-            src = Y[b + '/poolsrc']                  # (the normalised tensor, its dropout, or -- fused forward -- the pre-BN activation)
-            d = like(src, 'd_' + b + '_out')
-            net.pool_k_bwd(seg, src, dP[i], d, k)
-            dz = bn_bwd(b, cn, d)
+            dz = pool_bn_bwd(b, cn, dP[i], k)
             dP[i - 1] = like(P[i - 1], 'dpool%d' % (i - 1))
             net.conv_bwd(seg, Ly[cn], [(P[i - 1], 0, 0)], P[i - 1].H, P[i - 1].W, dz, [(dP[i - 1], (0, 0), None, (0, 0))])
-        d = like(Y['bn1/poolsrc'], 'd_bn1')
-        net.pool_k_bwd(seg, Y['bn1/poolsrc'], dP[1], d, 2)
-        dz = bn_bwd('bn1', 'conv1_0', d)
+        dz = pool_bn_bwd('bn1', 'conv1_0', dP[1], 2)
         net.conv_bwd(seg, Ly['conv1_0'], [(A['x'], 0, 0)], A['x'].H, A['x'].W, dz, [None], wgrad_sid=col_sid)
         self.grads_act = G
         net.flush_reduce(seg)

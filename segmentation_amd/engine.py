@@ -1437,6 +1437,13 @@ class Net(object):
                  1 if training else 0, decay, eps, self.B, a.H, a.W, a.Cp, layer.cout, st['ws'].data_ptr(), rows if training else 0, k, self.dtype,
                  kernel='bn_pool_apply_kernel')
 
+    def bn_pool_relu_bwd(self, plan, layer, st, a, dpool, dz, k):
+        """backward of bn_pool_fwd: pool_k_bwd (source `a`) + bn_relu_bwd without the pool's full-resolution gradient tensor"""
+        av, pv, zv = a.view(), dpool.view(), dz.view()
+        plan.keep += [av, pv, zv, st]
+        plan.add(layer.name + '+pool%d/bwd' % k, self.lib.seg_bn_pool_relu_bwd, C.byref(av), C.byref(pv), C.byref(zv), st['stats'].data_ptr(),
+                 self.store.g_ptr(layer.w_off), 0, k, self.B, a.H, a.W, a.Cp, layer.cout, st['ws'].data_ptr(), self.dtype, kernel='bn_pool_apply_bwd_kernel')
+
     def bn_relu_bwd(self, plan, layer, st, a, dy, dz, dbeta_ptr=None, dbeta_add=False):
         """dbeta goes to the layer's slot of the gradient arena (dbeta_add: added to it -- a second batch through the same
         layer) or to dbeta_ptr (a scratch buffer: data-gradient-only passes)"""

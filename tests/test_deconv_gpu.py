@@ -185,6 +185,33 @@ def test_batch_norm_and_pool_in_one_pass(dtype, B, H, W, Cc, k, training):
     assert np.array_equal(res[1][3][..., :Cc].float().cpu().numpy().astype(np.float64), want)
     diff = (res[0][3] != res[1][3]).float().mean().item()
     assert diff < (1e-6 if dtype == L.SEG_F32 else 0.02)          # (bf16: a few windows per thousand tie after rounding)
+    if not training:
+        return
+    # backward in two passes (seg_bn_pool_relu_bwd) against seg_maxpool_k_bwd on `a` + seg_bn_relu_bwd: the same sums in another order
+    st = net.bn_state(layer)
+    y = net.act(H, W, Cc)
+    fp = E.Plan('f2'); net.bn_fwd(fp, layer, st, a, y, training=True, update_moving=False); fp.run(U.stream()); U.sync()
+    dp = net.act(Hp, Wp, Cc); U.fill_act(dp, dpv)
+    out = []
+    for fused in (False, True):
+        dz = net.act(H, W, Cc); dz.t.fill_(9.0)
+        store.g.fill_(float('nan'))
+        bp = E.Plan('b')
+        if fused:
+            net.bn_pool_relu_bwd(bp, layer, st, a, dp, dz, k)
+        else:
+            d = net.act(H, W, Cc)
+            net.pool_k_bwd(bp, a, dp, d, k)
+            net.bn_relu_bwd(bp, layer, st, a, d, dz)
+        bp.run(U.stream()); U.sync()
+        out.append((U.read_act(dz), store.get_grads()['bn']['beta'].copy(), U.pad_channels_zero(dz)))
+    (z0, b0, p0), (z1, b1, p1) = out
+    assert p0 and p1
+    assert U.rel_err(b1, b0) < (1e-5 if dtype == L.SEG_F32 else 1e-4)
+    assert np.abs(z1 - z0).max() < (1e-5 if dtype == L.SEG_F32 else 1e-2) * max(1.0, np.abs(z0).max())
+    dref, dbeta = ops.batch_norm_bwd(want, ops.batch_norm(av, p['bn']['beta'].astype(np.float64), np.zeros(Cc), np.ones(Cc), True)[1])
+    assert np.abs(z1 - dref * (av > 0)).max() < (3e-5 if dtype == L.SEG_F32 else 3e-2) * max(1.0, np.abs(dref).max())
+    assert U.rel_err(b1, dbeta) < (1e-5 if dtype == L.SEG_F32 else 1e-2)
 
 
 @pytest.mark.parametrize('dtype', DT)
