@@ -191,7 +191,8 @@ class DeconvModel(BaseModel):
         mode = os.environ.get('SEG_FIRST_GEN', '1')
         direct = net.dtype == L.SEG_BF16 and self.input_channel <= 3 and nk <= 64 and mode != '0'
         xin = None
-        self._col_late = None
+        if want_col:
+            self._col_late = None
         if want_col or not direct:
             xin = net.act(sz['conv1_0'], sz['conv1_0'], 25 * self.input_channel, name='x_im2col')
             cv = xin.view()
@@ -199,9 +200,10 @@ class DeconvModel(BaseModel):
             col_args = ('conv1_0/im2col', net.lib.seg_im2col, x_in.data_ptr(), net.B, H, W, self.input_channel, 5, 5, 2, pad, pad, E.C.byref(cv),
                         sz['conv1_0'], sz['conv1_0'], net.dtype)
             if direct and mode != 'fwd' and net.side_enabled:
-                # emitted by the backward plan on the filter gradient's stream, half a backward pass ahead of it: 16 x 512^2 step
-                # 1.76 (im2col + 1x1 convolution) -> 1.65 ms; written during the forward pass -- whose kernels are all HBM-bound --
-                # it gave the direct kernel's gain back (1.76 on the main stream, 1.78 on a side stream: SEG_FIRST_GEN=fwd)
+                # emitted by the backward plan on the filter gradient's stream, half a backward pass ahead of it, off the critical
+                # stream (16 x 512^2 step: 1.631 against 1.643 ms with the im2col in the forward pass -- SEG_FIRST_GEN=fwd -- or with
+                # im2col + 1x1 convolution -- SEG_FIRST_GEN=0; the plans without a backward pass simply have no im2col: inference
+                # 0.73 -> 0.60 ms)
                 self._col_late = col_args
             else:
                 plan.add(*col_args, kernel='im2col_kernel')
