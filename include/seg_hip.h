@@ -190,6 +190,14 @@ int32_t seg_conv_first_gen_rows(int32_t B, int32_t Ho, int32_t Wo, int32_t cout)
 int seg_conv_first_gen_bn(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const float* w_hwio, const float* bias,
                           int32_t cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad_t, int32_t pad_l, const seg_view* dst,
                           int32_t Ho, int32_t Wo, int32_t relu, float* bn_ws, int32_t bn_C, int32_t dtype, void* stream);
+/* Filter + bias gradient of that layer (tf.gradients through slim.convolution2d(images, n_kernels, 5, 2), models/deconvolution.py:44-46)
+ * straight from the image -- no im2col tensor: MFMAs over the pixel dimension with the patch read transposed out of LDS.  bf16, 5x5 /
+ * stride 2, cin <= 3, cout <= 64.  dw_hwio float32 [5][5][cin][cout], db [cout] or NULL; ws: seg_conv_first_gen_wgrad_ws_bytes
+ * (cout) bytes of partial rows, summed in a fixed order by a second launch (deterministic). */
+int64_t seg_conv_first_gen_wgrad_ws_bytes(int32_t cout);
+int seg_conv_first_gen_wgrad(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const seg_view* dz, int32_t Ho, int32_t Wo,
+                             int32_t cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad_t, int32_t pad_l, float* dw_hwio, float* db,
+                             void* ws, int64_t ws_bytes, int32_t dtype, void* stream);
 
 /* Same layer fused with the 2x2/s2 VALID max-pool that consumes it (models/unet.py pool1 over conv1_1, models/fcn.py:116
  * pool1 over conv1): one pass writes the activation and its pooled map [Hp = Ho/2, Wp = Wo/2].  bf16, cin <= 3, cout <= 64. */

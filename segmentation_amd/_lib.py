@@ -76,6 +76,7 @@ SIGNATURES = {
     'seg_wgrad_reduce_batch': [vp, i32, i32, vp],
     'seg_conv_first_fwd': [vp, i32, i32, i32, i32, vp, vp, i32, i32, PV, i32, i32, i32, i32, vp],
     'seg_conv_first_gen': [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, PV, i32, i32, i32, i32, vp],
+    'seg_conv_first_gen_wgrad': [vp, i32, i32, i32, i32, PV, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, i32, vp],
     'seg_conv_first_gen_bn': [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, PV, i32, i32, i32, vp, i32, i32, vp],
     'seg_conv_first_pool_fwd': [vp, i32, i32, i32, i32, vp, vp, i32, i32, PV, i32, i32, i32, PV, i32, i32, i32, vp],
     'seg_im2col3x3': [vp, i32, i32, i32, i32, i32, PV, i32, i32, i32, vp],
@@ -167,6 +168,8 @@ def load():
     lib.seg_bias_grad_ws_bytes.argtypes = [C.c_int32]
     lib.seg_thin_wgrad3x3_ws_bytes.restype = C.c_int64
     lib.seg_thin_wgrad3x3_ws_bytes.argtypes = [C.c_int32] * 2
+    lib.seg_conv_first_gen_wgrad_ws_bytes.restype = C.c_int64
+    lib.seg_conv_first_gen_wgrad_ws_bytes.argtypes = [C.c_int32]
     lib.seg_conv_first_gen_rows.restype = C.c_int32
     lib.seg_conv_first_gen_rows.argtypes = [C.c_int32] * 4
     lib.seg_thin_up2x2_rows.restype = C.c_int32

@@ -600,6 +600,160 @@ __global__ __launch_bounds__(256) void conv_first_gen_kernel(const GenK P) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Filter + bias gradient of that layer from the image itself (no im2col tensor): dW[kslot][o] = sum_px col[px][kslot] * dZ[px][o] as
+// MFMAs whose reduction dimension is the PIXEL -- A = the tile's patch read "transposed" out of LDS (lane (kslot i, group g) picks
+// its k-slot's value at 8 consecutive pixels of a tile row: eight 2-byte reads 16 bytes apart), B = the tile's dZ, transposed once
+// into LDS as [o][pixel] so that a fragment is one 16-byte read.  The k-slot layout is the forward kernel's (pairs of taps, RGB0
+// pixels); the spare channel of the pixel holds 1.0 inside the image, so the k-slot of tap (pad_t, pad_l) -- under it lies input pixel (S y, S x), always inside --
+// accumulates the bias gradient.  Persistent workgroups keep the [NS*32][32 NG] sums in MFMA accumulators (wave w: k-slot groups
+// 2w, 2w+1 of the eight), leave one row each in ws, and conv_first_gen_wgrad_final_kernel adds the rows in a fixed order.
+// The DeconvModel's conv1_0 at 16 x 512^2: im2col (250 MB) + the 1x1 filter gradient over it (225 MB) = 112 + 97 us on a side
+// stream; this reads 50 + 67 MB.
+// ---------------------------------------------------------------------------------------------------------
+template <int KH, int KW, int S, int NG>
+__global__ __launch_bounds__(256) void conv_first_gen_wgrad_kernel(const GenK P, seg_view dzv, float* ws) {
+  constexpr int PPR = (KW + 1) / 2, NP = KH * PPR, NS = (NP + 3) / 4;
+  static_assert(NS == 4, "eight k-slot groups of 16 (two per wave)");
+  constexpr int PRL = (FTH - 1) * S + KH, PCL = (FTW - 1) * S + KW;
+  constexpr int PR = (FTH - 1) * S + (4 * NS - 1) / PPR + 1, PC = (FTW - 1) * S + 2 * PPR;
+  constexpr int RS = PC | 1;
+  constexpr int NPX = PRL * PCL, NLD = (NPX + 255) / 256;
+  constexpr int NO = 32 * NG, ZRS = FTH * FTW + 8;              // dZ^T row stride in elements (16-byte aligned rows)
+  constexpr int NZ = NO / 8;                                     // 16-byte dZ pieces per thread and tile
+  __shared__ __attribute__((aligned(16))) uint32_t sp[PR * RS * 2];
+  __shared__ __attribute__((aligned(16))) uint16_t zt[NO * ZRS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, g = lane >> 4;
+  for (int i = tid; i < PR * RS * 2; i += 256) sp[i] = 0u;
+
+  f32x4 acc[2][2 * NG];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int o = 0; o < 2 * NG; ++o) acc[a][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // byte address (within sp) of this lane's k-slot at pixel (row 0, column 8 g) of the tile, for its two k-slot groups
+  int abase[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int kslot = 16 * (2 * wave + a) + i16;
+    const int pi = kslot >> 3, j = kslot & 7;
+    const int ty = pi / PPR, tx = 2 * (pi - ty * PPR) + (j >> 2), ch = j & 3;
+    abase[a] = ((ty * RS + (8 * g) * S + tx) * 4 + ch) * 2;
+  }
+  const int tiles_x = P.blocks_x, tiles_y = P.blocks_y;
+  const int per_img = tiles_x * tiles_y, total = P.B * per_img;
+  const bf16_t* dzp = reinterpret_cast<const bf16_t*>(dzv.ptr);
+
+  float pre[NLD][3]; bool pin[NLD];
+  u32x4 zpre[NZ];
+  auto tile_load = [&](int t) {
+    const int b = t / per_img; const int r = t - b * per_img;
+    const int ty = r / tiles_x, tx = r - ty * tiles_x;
+    const float* xb = P.x + (int64_t)b * P.H * P.W * P.cin;
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) {
+      const int i = tid + n * 256;
+      const int py = i / PCL, px = i - py * PCL;
+      const int iy = ty * FTH * S - P.pad_t + py, ix = tx * FTW * S - P.pad_l + px;
+      const bool in = i < NPX && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+      const float* q = xb + ((int64_t)iy * P.W + ix) * P.cin;
+      pin[n] = in;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pre[n][c] = (in && c < P.cin) ? q[c] : 0.f;
+    }
+#pragma unroll
+    for (int n = 0; n < NZ; ++n) {
+      const int pc = tid + n * 256;                              // piece: pixel pc / NZ of the tile, channels 8 (pc % NZ) ..
+      const int px = pc / NZ, c8 = pc - px * NZ;
+      const int oy = ty * FTH + (px >> 5), ox = tx * FTW + (px & 31);
+      const bool ok = oy < P.Ho && ox < P.Wo;
+      zpre[n] = ok ? *reinterpret_cast<const u32x4*>(dzp + view_off(dzv, b, oy, ox) + c8 * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  if ((int)blockIdx.x < total) tile_load(blockIdx.x);
+  __syncthreads();
+  for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    lds_barrier();                                                 // previous tile's reads are done
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) {
+      const int i = tid + n * 256;
+      if (i < NPX) {
+        const int py = i / PCL, px = i - py * PCL;
+        const bf16x4 v = bf16x4{(bf16_t)pre[n][0], (bf16_t)pre[n][1], (bf16_t)pre[n][2], (bf16_t)(pin[n] ? 1.f : 0.f)};
+        *reinterpret_cast<u32x2*>(&sp[(py * RS + px) * 2]) = __builtin_bit_cast(u32x2, v);
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NZ; ++n) {
+      const int pc = tid + n * 256;
+      const int px = pc / NZ, c8 = pc - px * NZ;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        zt[(c8 * 8 + 2 * e) * ZRS + px] = (uint16_t)(zpre[n][e] & 0xffffu);
+        zt[(c8 * 8 + 2 * e + 1) * ZRS + px] = (uint16_t)(zpre[n][e] >> 16);
+      }
+    }
+    lds_barrier();
+    if (t + (int)gridDim.x < total) tile_load(t + gridDim.x);      // in flight behind this tile's arithmetic
+    const char* spb = reinterpret_cast<const char*>(sp);
+#pragma unroll
+    for (int r = 0; r < FTH; ++r) {                                // reduction step = one tile row of 32 pixels
+      Frag<bf16_t> fb[2 * NG];
+#pragma unroll
+      for (int o = 0; o < 2 * NG; ++o)
+        fb[o].v = *reinterpret_cast<const bf16x8*>(&zt[(16 * o + i16) * ZRS + 32 * r + 8 * g]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const char* ap = spb + abase[a] + r * (S * RS * 8);
+        uint32_t w4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t lo = *reinterpret_cast<const uint16_t*>(ap + (2 * e) * (S * 8));
+          const uint32_t hi = *reinterpret_cast<const uint16_t*>(ap + (2 * e + 1) * (S * 8));
+          w4[e] = lo | (hi << 16);
+        }
+        Frag<bf16_t> fa;
+        fa.v = __builtin_bit_cast(bf16x8, u32x4{w4[0], w4[1], w4[2], w4[3]});
+#pragma unroll
+        for (int o = 0; o < 2 * NG; ++o) mma32(acc[a][o], fa, fb[o]);
+      }
+    }
+  }
+  // one row [NS * 32][NO] of partial sums per workgroup: D row 4 g + r of k-slot group (2 wave + a), column i16 of output group o
+  float* row = ws + (int64_t)blockIdx.x * (NS * 32 * NO);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int o = 0; o < 2 * NG; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) row[(16 * (2 * wave + a) + 4 * g + r) * NO + 16 * o + i16] = acc[a][o][r];
+}
+
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void conv_first_gen_wgrad_final_kernel(const float* ws, int rows, int NO, int cin, int cout, int pad_t, int pad_l, float* dw, float* db) {
+  constexpr int PPR = (KW + 1) / 2;
+  __shared__ double part[32][8];
+  const int el = threadIdx.x & 7, sl = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + el, RL = 128 * NO;
+  double a = 0.0;
+  if (i < RL)
+    for (int r = sl; r < rows; r += 32) a += (double)ws[(int64_t)r * RL + i];
+  part[sl][el] = a;
+  __syncthreads();
+  if (sl != 0 || i >= RL) return;
+  a = 0.0;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) a += part[q][el];
+  const int kslot = i / NO, o = i - kslot * NO;
+  const int pi = kslot >> 3, j = kslot & 7;
+  const int ty = pi / PPR, tx = 2 * (pi - ty * PPR) + (j >> 2), ch = j & 3;
+  if (o >= cout || ty >= KH || tx >= KW) return;
+  if (ch < cin) dw[((int64_t)(ty * KW + tx) * cin + ch) * cout + o] = (float)a;
+  else if (ch == 3 && ty == pad_t && tx == pad_l && db != nullptr) db[o] = (float)a;
+}
+
 }  // namespace
 
 static int launch_first_mfma(const FirstK& P0, hipStream_t st) {
@@ -863,6 +1017,40 @@ extern "C" int seg_conv_first_gen_bn(const float* x, int32_t B, int32_t H, int32
                                      int32_t Ho, int32_t Wo, int32_t relu, float* bn_ws, int32_t bn_C, int32_t dtype, void* stream) {
   if (!bn_ws) { seg_set_error("conv_first_gen_bn: no workspace"); return SEG_ERR_ARG; }
   return first_gen_launch(x, B, H, W, cin, w_hwio, bias, cout, KH, KW, stride, pad_t, pad_l, dst, Ho, Wo, relu, bn_ws, bn_C, dtype, stream);
+}
+
+/* Rows of partial sums (= persistent workgroups) and workspace bytes of seg_conv_first_gen_wgrad. */
+static int first_gen_wgrad_rows(int64_t total) { return total > 512 ? 512 : (total < 1 ? 1 : (int)total); }
+extern "C" int64_t seg_conv_first_gen_wgrad_ws_bytes(int32_t cout) {
+  if (cout < 1 || cout > 64) return 0;
+  return (int64_t)512 * 128 * (cdiv(cout, 32) * 32) * (int64_t)sizeof(float);
+}
+
+/* Filter + bias gradient of seg_conv_first_gen's layer straight from the image (5x5 / stride 2, pad <= 1, cin <= 3, cout <= 64, bf16):
+ * dw_hwio float32 [KH][KW][cin][cout], db [cout] or NULL; two launches (partial rows in ws, then a fixed-order sum), deterministic. */
+extern "C" int seg_conv_first_gen_wgrad(const float* x, int32_t B, int32_t H, int32_t W, int32_t cin, const seg_view* dz, int32_t Ho, int32_t Wo,
+                                        int32_t cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad_t, int32_t pad_l, float* dw_hwio, float* db,
+                                        void* ws, int64_t ws_bytes, int32_t dtype, void* stream) {
+  if (!x || !dz || !dz->ptr || !dw_hwio || !ws || cin < 1 || cin > 3 || cout < 1 || cout > 64 || B <= 0 || Ho <= 0 || Wo <= 0 || pad_t < 0 || pad_l < 0) {
+    seg_set_error("conv_first_gen_wgrad: bad args (cin 1..3, cout <= 64)"); return SEG_ERR_ARG; }
+  if (dtype != SEG_BF16 || KH != 5 || KW != 5 || stride != 2 || pad_t >= KH || pad_l >= KW) { seg_set_error("conv_first_gen_wgrad: bf16, 5x5 / stride 2, pad < 5"); return SEG_ERR_UNSUPPORTED; }
+  const int cp = cdiv(cout, 32) * 32;
+  if (dz->oy + Ho > dz->H || dz->ox + Wo > dz->W || dz->coff + cp > dz->cs || dz->cs % 8 || dz->coff % 8 || dz->c < cp) { seg_set_error("conv_first_gen_wgrad: dZ window exceeds buffer"); return SEG_ERR_ARG; }
+  if ((int64_t)(Ho - 1) * stride >= H || (int64_t)(Wo - 1) * stride >= W) { seg_set_error("conv_first_gen_wgrad: output extent reaches past the input"); return SEG_ERR_ARG; }
+  if ((int64_t)B * dz->H * dz->W * dz->cs >= ((int64_t)1 << 31) || (int64_t)B * H * W * cin >= ((int64_t)1 << 31)) { seg_set_error("conv_first_gen_wgrad: tensor exceeds the 32-bit index range"); return SEG_ERR_UNSUPPORTED; }
+  if (ws_bytes < seg_conv_first_gen_wgrad_ws_bytes(cout)) { seg_set_error("conv_first_gen_wgrad: workspace too small"); return SEG_ERR_ARG; }
+  GenK P = {};
+  P.x = x; P.B = B; P.H = H; P.W = W; P.cin = cin; P.cout = cout; P.pad_t = pad_t; P.pad_l = pad_l; P.Ho = Ho; P.Wo = Wo;
+  P.blocks_x = cdiv(Wo, FTW); P.blocks_y = cdiv(Ho, FTH);
+  const int64_t total = (int64_t)B * P.blocks_x * P.blocks_y;
+  const int g = first_gen_wgrad_rows(total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* wsf = reinterpret_cast<float*>(ws);
+  if (cp == 32) SEG_LAUNCH((conv_first_gen_wgrad_kernel<5, 5, 2, 1>), dim3(g), dim3(256), 0, st, P, *dz, wsf);
+  else SEG_LAUNCH((conv_first_gen_wgrad_kernel<5, 5, 2, 2>), dim3(g), dim3(256), 0, st, P, *dz, wsf);
+  if (int rc = seg_check_launch("conv_first_gen_wgrad")) return rc;
+  SEG_LAUNCH((conv_first_gen_wgrad_final_kernel<5, 5>), dim3(128 * cp / 8), dim3(256), 0, st, (const float*)wsf, g, cp, cin, cout, pad_t, pad_l, dw_hwio, db);
+  return seg_check_launch("conv_first_gen_wgrad_final");
 }
 
 /* First layer + the 2x2/s2 max-pool (VALID) that consumes it, in one pass (bf16, cin <= 3, cout <= 64): writes both

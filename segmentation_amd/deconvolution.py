@@ -191,9 +191,12 @@ class DeconvModel(BaseModel):
         mode = os.environ.get('SEG_FIRST_GEN', '1')
         direct = net.dtype == L.SEG_BF16 and self.input_channel <= 3 and nk <= 64 and mode != '0'
         xin = None
+        # ... and with the filter gradient taken from the image as well (seg_conv_first_gen_wgrad) there is no im2col at all
+        direct_bwd = direct and os.environ.get('SEG_FIRST_GEN_WGRAD', '1') != '0'
         if want_col:
             self._col_late = None
-        if want_col or not direct:
+            self._first_direct_bwd = (direct_bwd, pad)
+        if (want_col and not direct_bwd) or not direct:
             xin = net.act(sz['conv1_0'], sz['conv1_0'], 25 * self.input_channel, name='x_im2col')
             cv = xin.view()
             plan.keep.append(cv)
@@ -362,7 +365,10 @@ class DeconvModel(BaseModel):
             dP[i - 1] = like(P[i - 1], 'dpool%d' % (i - 1))
             net.conv_bwd(seg, Ly[cn], [(P[i - 1], 0, 0)], P[i - 1].H, P[i - 1].W, dz, [(dP[i - 1], (0, 0), None, (0, 0))])
         dz = pool_bn_bwd('bn1', 'conv1_0', dP[1], 2)
-        net.conv_bwd(seg, Ly['conv1_0'], [(A['x'], 0, 0)], A['x'].H, A['x'].W, dz, [None], wgrad_sid=col_sid)
+        if self._first_direct_bwd[0]:
+            net.first_gen_bwd(seg, Ly['conv1_0'], self.input_x, H, W, self.input_channel, 5, 5, 2, self._first_direct_bwd[1], self._first_direct_bwd[1], dz)
+        else:
+            net.conv_bwd(seg, Ly['conv1_0'], [(A['x'], 0, 0)], A['x'].H, A['x'].W, dz, [None], wgrad_sid=col_sid)
         self.grads_act = G
         net.flush_reduce(seg)
         l = Ly['conv1_0']

@@ -707,6 +707,24 @@ class Net(object):
                  self.dtype, kernel='conv_first_gen_kernel', flops=fl, bytes=by)
         return 0
 
+    def first_gen_bwd(self, plan, layer, x_f32, H, W, cin, KH, KW, stride, pad_t, pad_l, dz, sid=None):
+        """Filter + bias gradient of first_gen_fwd's layer straight from the image (seg_conv_first_gen_wgrad: 5x5 / stride 2, bf16), on a
+        filter-gradient stream; no im2col tensor."""
+        zv = dz.view()
+        nbytes = int(self.lib.seg_conv_first_gen_wgrad_ws_bytes(layer.cout))
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+        plan.keep += [zv, ws]
+        fl = 2 * self.B * dz.H * dz.W * KH * KW * cin * layer.cout
+        if sid is None:
+            sid = self._pick_wgrad_stream(15.0 + fl / 2e8 + 10.0)
+        if not self.side_enabled:
+            sid = 0
+        plan.add(layer.name + '/dw', self.lib.seg_conv_first_gen_wgrad, x_f32.data_ptr(), self.B, H, W, cin, C.byref(zv), dz.H, dz.W, layer.cout,
+                 KH, KW, stride, pad_t, pad_l, self.store.g_ptr(layer.w_off), self.store.g_ptr(layer.b_off) if layer.nbias else None,
+                 ws.data_ptr(), nbytes, self.dtype, kernel='conv_first_gen_wgrad_kernel', flops=fl,
+                 bytes=self.B * (H * W * cin * 4 + dz.H * dz.W * layer.cout * self.es), side=sid)
+        plan.flops += fl
+
     def conv_fwd(self, plan, layer, srcs, Hi, Wi, dst, dst_off=(0, 0), out_f32=False, cfg=0, pool=None, ksplit=None, side=0):
         """srcs: list of (Act, oy, ox) (1 or 2 concat segments).  pool: Act of the 2x2 max-pool that consumes dst; when the
         layer's tile can carry it the pooled map is written by the same launch and `self.pool_fused` is set (else the

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     bound = set(_lib.SIGNATURES) | {'seg_last_error', 'seg_version', 'seg_bn_ws_bytes', 'seg_dconv_wgrad_ws_bytes', 'seg_bilinear_up_bwd_ws_bytes',
-             'seg_head_xent_ws_bytes', 'seg_bias_grad_ws_bytes', 'seg_conv_first_gen_rows', 'seg_thin_up2x2_rows', 'seg_thin_wgrad3x3_ws_bytes'}
+             'seg_head_xent_ws_bytes', 'seg_bias_grad_ws_bytes', 'seg_conv_first_gen_rows', 'seg_thin_up2x2_rows', 'seg_thin_wgrad3x3_ws_bytes', 'seg_conv_first_gen_wgrad_ws_bytes'}
     assert bound == set(names)
     assert _lib.load().seg_version() == 100
 

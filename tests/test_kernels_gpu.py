@@ -539,6 +539,32 @@ def test_conv_first_gen(k, stride, padding, cin, cout, H, relu):
     assert U.pad_channels_zero(out)
 
 
+@pytest.mark.parametrize('padding,cin,cout,H,B', [('SAME', 3, 32, 64, 3), ('SAME', 3, 64, 37, 2), ('SAME', 1, 20, 50, 4), ('VALID', 3, 32, 41, 2), ('SAME', 2, 40, 130, 1)])
+def test_conv_first_gen_wgrad(padding, cin, cout, H, B):
+    """seg_conv_first_gen_wgrad (filter + bias gradient of the DeconvModel's conv1_0 straight from the image, models/deconvolution.py:
+    44-46) against the oracle's Conv2DBackpropFilter on the same bf16-rounded operands."""
+    dtype = L.SEG_BF16
+    W = H + 7
+    rng = np.random.default_rng(cout + H)
+    layer = E.Layer('f', 'conv', 1, [25 * cin], cout, 'VALID', True)
+    p = {'f': {'weights': np.zeros((1, 1, 25 * cin, cout), np.float32), 'biases': np.zeros(cout, np.float32)}}
+    store = U.make_store([layer], dtype, p)
+    net = E.Net(store, B, dtype, U.dev())
+    x = rng.uniform(-1, 1, (B, H, W, cin)).astype(np.float32)
+    xt = torch.from_numpy(x).to(U.dev())
+    Ho, pt = ops.conv_out_size(H, 5, 2, padding); Wo, pl = ops.conv_out_size(W, 5, 2, padding)
+    dzv = U.round_dtype(rng.standard_normal((B, Ho, Wo, cout)), dtype)
+    dz = net.act(Ho, Wo, cout); U.fill_act(dz, dzv)
+    store.g.fill_(float('nan'))
+    plan = E.Plan('b'); net.first_gen_bwd(plan, layer, xt, H, W, cin, 5, 5, 2, pt, pl, dz); plan.run(U.stream()); U.sync()
+    dw_ref, db_ref = ops.conv2d_wgrad(U.round_dtype(x, dtype), dzv, (5, 5), padding, 2)
+    g = store.get_grads()['f']
+    got = g['weights'].reshape(5, 5, cin, cout)
+    assert np.isfinite(got).all() and np.isfinite(g['biases']).all()
+    assert U.rel_err(got, dw_ref) < 1e-4                     # exact products of bf16 operands, f32 accumulation: only the summation order differs
+    assert U.rel_err(g["biases"], db_ref) < 1e-4
+
+
 @pytest.mark.parametrize('which,cout,H,B', [('first', 32, 64, 3), ('first', 64, 37, 2), ('first', 20, 130, 4), ('up', 2, 40, 3), ('up', 5, 23, 2), ('up', 8, 150, 2)])
 def test_batch_norm_statistics_from_the_producing_launch(which, cout, H, B):
     """seg_conv_first_gen_bn / seg_thin_up2x2_bn + seg_bn_fwd_rows (the DeconvModel's conv1_0 -> bn1 and deconv3_0 -> bn8,
