@@ -216,8 +216,17 @@ def roofline_report(agg, ops, reps, dtype, total_steps_ms, pmc_tag=None):
                        'flop_per_byte': round(fl / by, 1) if by else None, 'bound': bound,
                        'achieved': round(fl / sec / 1e12, 1) if bound == 'mfma' else round(by / sec / 1e9, 1),
                        'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s', 'frac': round(max(t_mfma, t_hbm) / sec, 4)})
+    # the dominant kernel's own bound: MFMA unless its algorithmic bytes at the HBM peak take longer than its FLOPs at the MFMA peak
+    # (the vector-ALU kernels of the <= 8-channel tensors, the first layer): then achieved / peak are bytes per second
+    own = [(fl, by) for _, kern, _, fl, by in ops if kern == name and fl]
+    head = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4)}
+    if own:
+        fl1 = sum(o_[0] for o_ in own) / len(own); by1 = sum(o_[1] for o_ in own) / len(own)
+        if by1 / (HBM_PEAK_GBS * 1e9) > fl1 / (peak * 1e12):
+            gbs = by1 / (avg_ms * 1e-3) / 1e9
+            head = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4)}
     return {
-        'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+        **head,
         'traffic': traffic, 'traffic_source': tsrc, 'kernel': name, 'avg_launch_us': round(avg_ms * 1e3, 2),
         'launches_per_step': a['launches'] // reps, 'share_of_step_kernel_time': round(a['ms'] / total_ms, 3),
         'algorithmic_gflop_per_launch': round(a['flops'] / a['launches'] / 1e9, 3),
