@@ -223,7 +223,7 @@ def test_bias_grad_two_stage(dtype, C_, nlog, H, W, B):
 
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('valu', ['1', '0'])
-@pytest.mark.parametrize('nc,H,W,B', [(2, 19, 23, 2), (5, 12, 40, 3), (8, 33, 9, 1)])
+@pytest.mark.parametrize('nc,H,W,B', [(2, 19, 23, 2), (5, 12, 40, 3), (8, 33, 9, 1), (4, 10, 14, 2)])
 def test_thin_tensors_through_the_mfma_kernels(dtype, nc, H, W, B, valu, monkeypatch):
     """<= 8-channel tensors at a channel stride of 8 (engine.Act(thin=True)): a 2x2/s2 transposed conv INTO a thin tensor, a 3x3
     SAME conv FROM a thin tensor into a thin float tensor, and every gradient of both (thin dZ, thin sources, thin data-gradient
