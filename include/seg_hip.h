@@ -288,12 +288,23 @@ int seg_bias_grad(const seg_view* dz, int32_t B, int32_t H, int32_t W, int32_t n
 int seg_thin_conv3x3(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, const float* w_hwio, const float* bias, int32_t cin,
                      int32_t cout, int32_t pad, int32_t relu, int32_t dgrad, const seg_view* mask, const seg_view* dst, int32_t Ho,
                      int32_t Wo, int32_t out_f32, int32_t dtype, void* stream);
+/* Forward of seg_thin_conv3x3 on slim.batch_norm(src) without that tensor (models/deconvolution.py:168-170: bn8 -> conv_out): src is
+ * the PRE-batch-norm activation, bn_stats the 8-channel batch norm's [mean[8] | rstd[8]] (the `stats` of seg_bn_fwd; pass y = NULL
+ * there for the statistics alone) and bn_beta its beta[cin]; every value read is normalised and rounded exactly as seg_bn_fwd would
+ * have stored it, so the output is bit-identical. */
+int seg_thin_conv3x3_bn(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, const float* w_hwio, const float* bias, int32_t cin,
+                        int32_t cout, int32_t pad, int32_t relu, const seg_view* dst, int32_t Ho, int32_t Wo, int32_t out_f32,
+                        const float* bn_stats, const float* bn_beta, int32_t dtype, void* stream);
 /* Filter and bias gradient of that layer (tf.gradients through slim.convolution2d(net, n_classes, 3, 1), models/deconvolution.py:170)
  * from a thin source and a thin dZ on the vector ALU: dw_hwio float32 [3][3][cin][cout], db [cout] (NULL: none); two launches
  * (partial rows in ws, seg_thin_wgrad3x3_ws_bytes(cin, cout) bytes; a fixed-order sum of the rows), deterministic. */
 int64_t seg_thin_wgrad3x3_ws_bytes(int32_t cin, int32_t cout);
 int seg_thin_wgrad3x3(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, const seg_view* dz, int32_t Ho, int32_t Wo, int32_t cin,
                       int32_t cout, int32_t pad, float* dw_hwio, float* db, void* ws, int64_t ws_bytes, int32_t dtype, void* stream);
+/* seg_thin_wgrad3x3 with the batch norm of `src` applied on load (src = the pre-batch-norm activation; see seg_thin_conv3x3_bn). */
+int seg_thin_wgrad3x3_bn(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, const seg_view* dz, int32_t Ho, int32_t Wo, int32_t cin,
+                         int32_t cout, int32_t pad, float* dw_hwio, float* db, void* ws, int64_t ws_bytes, const float* bn_stats,
+                         const float* bn_beta, int32_t dtype, void* stream);
 /* 2x2 / stride-2 transposed convolution from a [H,W,cin] tensor INTO a thin [2H,2W,cout <= 8] tensor (dgrad == 0: `big` written,
  * bias + optional ReLU) and its data gradient (dgrad != 0: `small` written from the thin gradient `big`, optional ReLU-grad mask
  * over `small`'s layout), filter in the TF layout [2,2,cout,cin] -- the DeconvModel's deconv3_0 on the vector ALU. */

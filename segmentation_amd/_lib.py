@@ -96,6 +96,8 @@ SIGNATURES = {
     'seg_thin_up2x2_bn': [PV, PV, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, vp],
     'seg_thin_conv3x3': [PV, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, PV, PV, i32, i32, i32, i32, vp],
     'seg_thin_wgrad3x3': [PV, i32, i32, i32, PV, i32, i32, i32, i32, i32, vp, vp, vp, i64, i32, vp],
+    'seg_thin_wgrad3x3_bn': [PV, i32, i32, i32, PV, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp, vp, i32, vp],
+    'seg_thin_conv3x3_bn': [PV, i32, i32, i32, vp, vp, i32, i32, i32, i32, PV, i32, i32, i32, vp, vp, i32, vp],
     'seg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp],
     'seg_step_increment': [vp, vp],
     'seg_step_begin': [vp, vp, vp],

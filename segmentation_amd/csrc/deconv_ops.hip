@@ -968,7 +968,8 @@ static int bn_fwd_launch(const seg_view* a, const seg_view* y, const float* beta
                          float decay, float eps, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t rows, int32_t dtype,
                          void* stream, int32_t pool_k) {
   const int yH = pool_k ? H / pool_k : H, yW = pool_k ? W / pool_k : W;
-  if (!a || !y || !beta || !stats || !ws || C <= 0 || C % 8 || C > 2048 || c_log <= 0 || c_log > C || !view_ok(*a, H, W, C) || !view_ok(*y, yH, yW, C) ||
+  const bool stats_only = y == nullptr || y->ptr == nullptr;       // (the consumer normalises on load: seg_thin_conv3x3_bn)
+  if (!a || !beta || !stats || !ws || C <= 0 || C % 8 || C > 2048 || c_log <= 0 || c_log > C || !view_ok(*a, H, W, C) || (!stats_only && !view_ok(*y, yH, yW, C)) ||
       (!training && !moving) || (dtype != SEG_F32 && dtype != SEG_BF16)) { seg_set_error("bn_fwd: bad arguments"); return SEG_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   const int64_t npix = (int64_t)B * H * W;
@@ -982,6 +983,7 @@ static int bn_fwd_launch(const seg_view* a, const seg_view* y, const float* beta
   SEG_LAUNCH(bn_final_kernel<0>, dim3((C + 7) / 8), dim3(256), 0, st, (const float*)ws, training ? nb : 0, C, c_log, 1.0 / (double)npix, eps, decay,
              training, moving, stats, (float*)nullptr, (float*)nullptr, 0);
   if (int rc = seg_check_launch("bn_final")) return rc;
+  if (stats_only) return 0;
   if (pool_k) {
     const int gp = grid_for((int64_t)B * yH * yW * (C / 8));
     if (dtype == SEG_F32) SEG_LAUNCH(bn_pool_apply_kernel<float>, dim3(gp), dim3(256), (size_t)C * 12, st, *a, *y, (const float*)stats, beta, pool_k, B, yH, yW, C / 8, C, c_log);

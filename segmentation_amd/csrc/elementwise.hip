@@ -1211,9 +1211,18 @@ extern "C" int seg_sigmoid_argmax(const seg_view* logits, int32_t B, int32_t H, 
 // ------------------------------------------------------------------------------------------
 template <typename T, int NC, bool OUT_F32>
 __global__ __launch_bounds__(256) void thin_conv3x3_kernel(seg_view src, const float* w, const float* bias, int cin, int cout, int pad, int relu,
-                                                           int dgrad, seg_view mask, seg_view dst, int B, int Ho, int Wo, int Hi, int Wi, int remap) {
+                                                           int dgrad, seg_view mask, seg_view dst, int B, int Ho, int Wo, int Hi, int Wi, int remap,
+                                                           const float* bn_stats, const float* bn_beta, int bn_clog) {
   __shared__ float sw[9 * NC * NC];          // [tap][ci][co] as THIS launch consumes it (zero above the logical counts)
   __shared__ float sb[NC];
+  // bn_stats != NULL: the source is the PRE-batch-norm activation and every value read is normalised on the fly, rounded as the
+  // stored normalised tensor would have been (so the results are bit-identical to reading that tensor, which then need not exist)
+  float bm[NC], br[NC], bb[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const bool on = bn_stats != nullptr && c < bn_clog;
+    bm[c] = on ? bn_stats[c] : 0.f; br[c] = on ? bn_stats[8 + c] : (bn_stats != nullptr ? 0.f : 1.f); bb[c] = on ? bn_beta[c] : 0.f;
+  }
   for (int i = threadIdx.x; i < 9 * NC * NC; i += 256) {
     const int tap = i / (NC * NC), ci = (i / NC) % NC, co = i % NC;
     float v = 0.f;
@@ -1244,7 +1253,8 @@ __global__ __launch_bounds__(256) void thin_conv3x3_kernel(seg_view src, const f
         const float* wt = sw + (u * 3 + v) * NC * NC;
 #pragma unroll
         for (int ci = 0; ci < NC; ++ci) {
-          const float xf = xv.get(ci);
+          float xf = xv.get(ci);
+          if (bn_stats != nullptr) xf = to_f32(from_f32<T>((xf - bm[ci]) * br[ci] + bb[ci]));
 #pragma unroll
           for (int co = 0; co < NC; ++co) acc[co] = fmaf(xf, wt[ci * NC + co], acc[co]);
         }
@@ -1275,9 +1285,26 @@ __global__ __launch_bounds__(256) void thin_conv3x3_kernel(seg_view src, const f
   }
 }
 
+static int thin_conv_launch(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, const float* w_hwio, const float* bias, int32_t cin,
+                            int32_t cout, int32_t pad, int32_t relu, int32_t dgrad, const seg_view* mask, const seg_view* dst, int32_t Ho,
+                            int32_t Wo, int32_t out_f32, const float* bn_stats, const float* bn_beta, int32_t dtype, void* stream);
 extern "C" int seg_thin_conv3x3(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, const float* w_hwio, const float* bias, int32_t cin,
                                 int32_t cout, int32_t pad, int32_t relu, int32_t dgrad, const seg_view* mask, const seg_view* dst, int32_t Ho,
                                 int32_t Wo, int32_t out_f32, int32_t dtype, void* stream) {
+  return thin_conv_launch(src, B, Hi, Wi, w_hwio, bias, cin, cout, pad, relu, dgrad, mask, dst, Ho, Wo, out_f32, nullptr, nullptr, dtype, stream);
+}
+/* Forward of seg_thin_conv3x3 on the batch norm of `src` without that tensor: src is the PRE-batch-norm activation, bn_stats the batch
+ * norm's [mean[8] | rstd[8]] (seg_bn_fwd's `stats` of an 8-channel layer) and bn_beta its beta[cin]; every value is normalised and
+ * rounded on load exactly as seg_bn_fwd would have stored it (models/deconvolution.py:168-170: bn8 -> conv_out). */
+extern "C" int seg_thin_conv3x3_bn(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, const float* w_hwio, const float* bias, int32_t cin,
+                                   int32_t cout, int32_t pad, int32_t relu, const seg_view* dst, int32_t Ho, int32_t Wo, int32_t out_f32,
+                                   const float* bn_stats, const float* bn_beta, int32_t dtype, void* stream) {
+  if (!bn_stats || !bn_beta) { seg_set_error("thin_conv3x3_bn: statistics and beta are required"); return SEG_ERR_ARG; }
+  return thin_conv_launch(src, B, Hi, Wi, w_hwio, bias, cin, cout, pad, relu, 0, nullptr, dst, Ho, Wo, out_f32, bn_stats, bn_beta, dtype, stream);
+}
+static int thin_conv_launch(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, const float* w_hwio, const float* bias, int32_t cin,
+                            int32_t cout, int32_t pad, int32_t relu, int32_t dgrad, const seg_view* mask, const seg_view* dst, int32_t Ho,
+                            int32_t Wo, int32_t out_f32, const float* bn_stats, const float* bn_beta, int32_t dtype, void* stream) {
   const int ci_w = dgrad ? cout : cin, co_w = dgrad ? cin : cout;             // channels this walk reads / writes
   if (!src || !src->ptr || !dst || !dst->ptr || !w_hwio || cin < 1 || cin > 8 || cout < 1 || cout > 8 || pad < 0 || pad > 2 || B <= 0 ||
       src->cs != 8 || src->coff != 0 || dst->cs != 8 || dst->coff != 0 || !view_ok(dst, Ho, Wo, 8) ||
@@ -1290,7 +1317,7 @@ extern "C" int seg_thin_conv3x3(const seg_view* src, int32_t B, int32_t Hi, int3
   const int m = cin > cout ? cin : cout;
   const int g = grid_for((int64_t)B * Ho * Wo, 256, 16384);
   const int remap = getenv("SEG_XCD_REMAP") ? atoi(getenv("SEG_XCD_REMAP")) : 1;
-#define TC_ARGS dim3(g), dim3(256), 0, ST(stream), *src, w_hwio, bias, cin, cout, pad, relu, dgrad, mk, *dst, B, Ho, Wo, Hi, Wi, remap
+#define TC_ARGS dim3(g), dim3(256), 0, ST(stream), *src, w_hwio, bias, cin, cout, pad, relu, dgrad, mk, *dst, B, Ho, Wo, Hi, Wi, remap, bn_stats, bn_beta, cin
 #define TC_NC(TT, F32) do { if (m <= 2) SEG_LAUNCH((thin_conv3x3_kernel<TT, 2, F32>), TC_ARGS); \
     else if (m <= 4) SEG_LAUNCH((thin_conv3x3_kernel<TT, 4, F32>), TC_ARGS); else SEG_LAUNCH((thin_conv3x3_kernel<TT, 8, F32>), TC_ARGS); } while (0)
   if (out_f32) { DISPATCH(dtype, TC_NC(float, true), TC_NC(bf16_t, true)); }
@@ -1310,8 +1337,15 @@ extern "C" int seg_thin_conv3x3(const seg_view* src, int32_t B, int32_t Hi, int3
 // ------------------------------------------------------------------------------------------
 constexpr int TW_ROWS = 1024;                // partial-sum rows = workgroups per tap group
 template <typename T, int NC, int TAPS>
-__global__ __launch_bounds__(256) void thin_wgrad3x3_partial_kernel(seg_view src, seg_view dz, int pad, int B, int Ho, int Wo, int Hi, int Wi, float* ws, int remap) {
+__global__ __launch_bounds__(256) void thin_wgrad3x3_partial_kernel(seg_view src, seg_view dz, int pad, int B, int Ho, int Wo, int Hi, int Wi, float* ws, int remap,
+                                  const float* bn_stats, const float* bn_beta, int bn_clog) {
   constexpr int NA = TAPS * NC * NC;
+  float bm[NC], br[NC], bb[NC];                // (bn_stats != NULL: src is the pre-batch-norm activation, normalised on load as above)
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const bool on = bn_stats != nullptr && c < bn_clog;
+    bm[c] = on ? bn_stats[c] : 0.f; br[c] = on ? bn_stats[8 + c] : (bn_stats != nullptr ? 0.f : 1.f); bb[c] = on ? bn_beta[c] : 0.f;
+  }
   const int tap0 = blockIdx.y * TAPS;
   float acc[NA], bsum[NC];
 #pragma unroll
@@ -1339,7 +1373,8 @@ __global__ __launch_bounds__(256) void thin_wgrad3x3_partial_kernel(seg_view src
       Vec8<T> xv; xv.load(sp + view_off(src, q_.b, iy, ix));
 #pragma unroll
       for (int ci = 0; ci < NC; ++ci) {
-        const float xf = xv.get(ci);
+        float xf = xv.get(ci);
+        if (bn_stats != nullptr) xf = to_f32(from_f32<T>((xf - bm[ci]) * br[ci] + bb[ci]));
 #pragma unroll
         for (int co = 0; co < NC; ++co) acc[(t * NC + ci) * NC + co] = fmaf(xf, z[co], acc[(t * NC + ci) * NC + co]);
       }
@@ -1391,8 +1426,23 @@ extern "C" int64_t seg_thin_wgrad3x3_ws_bytes(int32_t cin, int32_t cout) {
   return (int64_t)TW_ROWS * (9 * nc * nc + nc) * (int64_t)sizeof(float);
 }
 
+static int thin_wgrad_launch(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, const seg_view* dz, int32_t Ho, int32_t Wo, int32_t cin,
+                             int32_t cout, int32_t pad, float* dw_hwio, float* db, void* ws, int64_t ws_bytes, const float* bn_stats,
+                             const float* bn_beta, int32_t dtype, void* stream);
 extern "C" int seg_thin_wgrad3x3(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, const seg_view* dz, int32_t Ho, int32_t Wo, int32_t cin,
                                  int32_t cout, int32_t pad, float* dw_hwio, float* db, void* ws, int64_t ws_bytes, int32_t dtype, void* stream) {
+  return thin_wgrad_launch(src, B, Hi, Wi, dz, Ho, Wo, cin, cout, pad, dw_hwio, db, ws, ws_bytes, nullptr, nullptr, dtype, stream);
+}
+/* seg_thin_wgrad3x3 with the batch norm of `src` applied on load (src = the pre-batch-norm activation; see seg_thin_conv3x3_bn). */
+extern "C" int seg_thin_wgrad3x3_bn(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, const seg_view* dz, int32_t Ho, int32_t Wo, int32_t cin,
+                                    int32_t cout, int32_t pad, float* dw_hwio, float* db, void* ws, int64_t ws_bytes, const float* bn_stats,
+                                    const float* bn_beta, int32_t dtype, void* stream) {
+  if (!bn_stats || !bn_beta) { seg_set_error("thin_wgrad3x3_bn: statistics and beta are required"); return SEG_ERR_ARG; }
+  return thin_wgrad_launch(src, B, Hi, Wi, dz, Ho, Wo, cin, cout, pad, dw_hwio, db, ws, ws_bytes, bn_stats, bn_beta, dtype, stream);
+}
+static int thin_wgrad_launch(const seg_view* src, int32_t B, int32_t Hi, int32_t Wi, const seg_view* dz, int32_t Ho, int32_t Wo, int32_t cin,
+                             int32_t cout, int32_t pad, float* dw_hwio, float* db, void* ws, int64_t ws_bytes, const float* bn_stats,
+                             const float* bn_beta, int32_t dtype, void* stream) {
   if (!src || !src->ptr || !dz || !dz->ptr || !dw_hwio || !ws || cin < 1 || cin > 8 || cout < 1 || cout > 8 || pad < 0 || pad > 2 || B <= 0 ||
       src->cs != 8 || src->coff != 0 || dz->cs != 8 || dz->coff != 0 || !view_ok(dz, Ho, Wo, 8) || src->oy + Hi > src->H || src->ox + Wi > src->W ||
       Ho != Hi + 2 * pad - 2 || Wo != Wi + 2 * pad - 2 || Ho < 1 || Wo < 1 || ws_bytes < seg_thin_wgrad3x3_ws_bytes(cin, cout)) {
@@ -1402,7 +1452,7 @@ extern "C" int seg_thin_wgrad3x3(const seg_view* src, int32_t B, int32_t Hi, int
   const int g = grid_for((int64_t)B * Ho * Wo, 256, TW_ROWS);
   float* wsf = reinterpret_cast<float*>(ws);
   const int remap = getenv("SEG_XCD_REMAP") ? atoi(getenv("SEG_XCD_REMAP")) : 1;
-#define TWG_ARGS(GY) dim3(g, GY), dim3(256), 0, ST(stream), *src, *dz, pad, B, Ho, Wo, Hi, Wi, wsf, remap
+#define TWG_ARGS(GY) dim3(g, GY), dim3(256), 0, ST(stream), *src, *dz, pad, B, Ho, Wo, Hi, Wi, wsf, remap, bn_stats, bn_beta, cin
 #define TWG_NC(TT) do { if (nc == 2) SEG_LAUNCH((thin_wgrad3x3_partial_kernel<TT, 2, 9>), TWG_ARGS(1)); \
     else if (nc == 4) SEG_LAUNCH((thin_wgrad3x3_partial_kernel<TT, 4, 3>), TWG_ARGS(3)); else SEG_LAUNCH((thin_wgrad3x3_partial_kernel<TT, 8, 1>), TWG_ARGS(9)); } while (0)
   DISPATCH(dtype, TWG_NC(float), TWG_NC(bf16_t));

@@ -276,9 +276,16 @@ class DeconvModel(BaseModel):
         thin = thin_tail(self.n_classes)
         a = net.act(sz['deconv3_0'], sz['deconv3_0'], self.n_classes, name='deconv3_0', thin=thin)
         rows = net.up_fwd(plan, Ly['deconv3_0'], R, R.H, R.W, a, bn_st=bn['bn8'] if bn_training else None)
-        t = act_bn('deconv3_0', a, rows)             # (resize_image_with_crop_or_pad to (H, W) is the identity for even H)
         A['logits'] = net.act(H, W, self.n_classes, f32=True, name='logits', thin=thin)
-        net.conv_fwd(plan, Ly['conv_out'], [(t, 0, 0)], H, W, A['logits'], out_f32=True)
+        if thin and net.dtype == L.SEG_BF16 and os.environ.get('SEG_THIN_VALU', '1') != '0' and os.environ.get('SEG_BN_ON_LOAD', '1') != '0':
+            # bn8 is never materialised: its statistics alone, conv_out (and its filter gradient) normalise deconv3_0's output on load
+            A['deconv3_0'] = a
+            Y['bn8'] = None
+            net.bn_stats(plan, Ly['bn8'], bn['bn8'], a, training=bn_training, update_moving=update_moving, rows=rows)
+            net.conv_fwd(plan, Ly['conv_out'], [(a, 0, 0)], H, W, A['logits'], out_f32=True, src_bn=(bn['bn8'], Ly['bn8']))
+        else:
+            t = act_bn('deconv3_0', a, rows)             # (resize_image_with_crop_or_pad to (H, W) is the identity for even H)
+            net.conv_fwd(plan, Ly['conv_out'], [(t, 0, 0)], H, W, A['logits'], out_f32=True)
         A['x'], A['resize'] = xin, R
         return A, Y, P, sz
 
@@ -337,8 +344,12 @@ class DeconvModel(BaseModel):
             net.pool_k_bwd(seg, src, dpool, d_, k)
             return bn_bwd(b, cn, d_)
         # conv_out
-        dY8 = like(Y['bn8'], 'd_bn8')
-        net.conv_bwd(seg, Ly['conv_out'], [(Y['bn8'], 0, 0)], H, W, dlog, [(dY8, (0, 0), None, (0, 0))])
+        if Y['bn8'] is None:                      # (conv_out read deconv3_0's output through bn8 on load: so does its filter gradient)
+            dY8 = like(A['deconv3_0'], 'd_bn8')
+            net.conv_bwd(seg, Ly['conv_out'], [(A['deconv3_0'], 0, 0)], H, W, dlog, [(dY8, (0, 0), None, (0, 0))], src_bn=(self.bn['bn8'], Ly['bn8']))
+        else:
+            dY8 = like(Y['bn8'], 'd_bn8')
+            net.conv_bwd(seg, Ly['conv_out'], [(Y['bn8'], 0, 0)], H, W, dlog, [(dY8, (0, 0), None, (0, 0))])
         dz = bn_bwd('bn8', 'deconv3_0', dY8)
         dR = like(A['resize'], 'd_resize')
         net.up_bwd(seg, Ly['deconv3_0'], A['resize'], A['resize'].H, A['resize'].W, dz, dR, None)

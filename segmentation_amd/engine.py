@@ -725,7 +725,7 @@ class Net(object):
                  bytes=self.B * (H * W * cin * 4 + dz.H * dz.W * layer.cout * self.es), side=sid)
         plan.flops += fl
 
-    def conv_fwd(self, plan, layer, srcs, Hi, Wi, dst, dst_off=(0, 0), out_f32=False, cfg=0, pool=None, ksplit=None, side=0):
+    def conv_fwd(self, plan, layer, srcs, Hi, Wi, dst, dst_off=(0, 0), out_f32=False, cfg=0, pool=None, ksplit=None, side=0, src_bn=None):
         """srcs: list of (Act, oy, ox) (1 or 2 concat segments).  pool: Act of the 2x2 max-pool that consumes dst; when the
         layer's tile can carry it the pooled map is written by the same launch and `self.pool_fused` is set (else the
         caller emits pool_fwd)."""
@@ -738,11 +738,24 @@ class Net(object):
             sv, dv = srcs[0][0].view(), dst.view()
             plan.keep += [sv, dv]
             fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
+            by = self.B * (Hi * Wi + Ho * Wo) * 8 * (self.es if not out_f32 else (self.es + 4) // 2)
+            if src_bn is not None:
+                # the source is the pre-batch-norm activation, normalised on load (src_bn = (state, layer) of that batch norm, whose
+                # statistics bn_stats() has put into state['stats']): bit-identical to reading the normalised tensor
+                st_, bl_ = src_bn
+                plan.keep.append(st_)
+                plan.add(layer.name, self.lib.seg_thin_conv3x3_bn, C.byref(sv), self.B, Hi, Wi, self.store.p_ptr(layer.w_off), self.store.p_ptr(layer.b_off),
+                         layer.cin, layer.cout, pad, 1 if layer.relu else 0, C.byref(dv), Ho, Wo, 1 if out_f32 else 0, st_['stats'].data_ptr(),
+                         self.store.p_ptr(bl_.w_off), self.dtype, kernel='thin_conv3x3_kernel', flops=fl, bytes=by)
+                plan.flops += fl
+                return Ho, Wo
             plan.add(layer.name, self.lib.seg_thin_conv3x3, C.byref(sv), self.B, Hi, Wi, self.store.p_ptr(layer.w_off), self.store.p_ptr(layer.b_off),
                      layer.cin, layer.cout, pad, 1 if layer.relu else 0, 0, None, C.byref(dv), Ho, Wo, 1 if out_f32 else 0, self.dtype,
-                     kernel='thin_conv3x3_kernel', flops=fl, bytes=self.B * (Hi * Wi + Ho * Wo) * 8 * (self.es if not out_f32 else (self.es + 4) // 2))
+                     kernel='thin_conv3x3_kernel', flops=fl, bytes=by)
             plan.flops += fl
             return Ho, Wo
+        if src_bn is not None:
+            raise L.SegError('conv_fwd(src_bn=...): only the thin 3x3 vector-ALU route normalises on load')
         d = L.ConvDesc()
         d.src0 = srcs[0][0].view_wide(srcs[0][1], srcs[0][2])
         d.src1 = srcs[1][0].view_wide(srcs[1][1], srcs[1][2]) if len(srcs) > 1 else L.null_view()
@@ -986,7 +999,7 @@ class Net(object):
         self._add_wgrad(plan, layer.name + '/dw', w, fl, sid='aux' if on_aux else (1 if (same_stream and col is not None) else None))
         plan.flops += fl
 
-    def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0, ksplit=0, dgrad_ksplit=None, wgrad_sid=None):
+    def conv_bwd(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off=(0, 0), cfg=0, wcfg=0, ksplit=0, dgrad_ksplit=None, wgrad_sid=None, src_bn=None):
         """Filter + bias gradient, then one dgrad launch per entry of dsrcs.
         dsrcs: list aligned with srcs; each None (no input gradient wanted) or
         (dst_act, (oy,ox), mask_act_or_None, (moy,mox))."""
@@ -994,8 +1007,10 @@ class Net(object):
         Ho, Wo = Hi + 2 * pad - k + 1, Wi + 2 * pad - k + 1
         if (k == 3 and len(srcs) == 1 and srcs[0][0].thin and dz.thin and srcs[0][1:] == (0, 0) and dz_off == (0, 0) and layer.cin <= 8 and layer.cout <= 8
                 and os.environ.get('SEG_THIN_VALU', '1') != '0' and os.environ.get('SEG_THIN_WGRAD', '1') != '0'):
-            self._thin_wgrad(plan, layer, srcs[0][0], Hi, Wi, dz, Ho, Wo, wgrad_sid)
+            self._thin_wgrad(plan, layer, srcs[0][0], Hi, Wi, dz, Ho, Wo, wgrad_sid, src_bn)
             return self._conv_bwd_data(plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off, cfg, dgrad_ksplit, Ho, Wo)
+        if src_bn is not None:
+            raise L.SegError('conv_bwd(src_bn=...): only the thin 3x3 vector-ALU route normalises on load')
         w = L.WgradDesc()
         w.src0 = srcs[0][0].view_wide(srcs[0][1], srcs[0][2])
         w.src1 = srcs[1][0].view_wide(srcs[1][1], srcs[1][2]) if len(srcs) > 1 else L.null_view()
@@ -1016,7 +1031,7 @@ class Net(object):
         plan.flops += fl
         return self._conv_bwd_data(plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off, cfg, dgrad_ksplit, Ho, Wo)
 
-    def _thin_wgrad(self, plan, layer, src, Hi, Wi, dz, Ho, Wo, sid=None):
+    def _thin_wgrad(self, plan, layer, src, Hi, Wi, dz, Ho, Wo, sid=None, src_bn=None):
         """3x3 filter + bias gradient between thin tensors on the vector ALU (seg_thin_wgrad3x3), on a filter-gradient stream"""
         sv, zv = src.view(), dz.view()
         nbytes = int(self.lib.seg_thin_wgrad3x3_ws_bytes(layer.cin, layer.cout))
@@ -1027,6 +1042,15 @@ class Net(object):
             sid = self._pick_wgrad_stream(15.0 + self.B * Ho * Wo * 32 * self.es / 3e6)
         if not self.side_enabled:
             sid = 0
+        if src_bn is not None:
+            st_, bl_ = src_bn
+            plan.keep.append(st_)
+            plan.add(layer.name + '/dw', self.lib.seg_thin_wgrad3x3_bn, C.byref(sv), self.B, Hi, Wi, C.byref(zv), Ho, Wo, layer.cin, layer.cout, layer.pad,
+                     self.store.g_ptr(layer.w_off), self.store.g_ptr(layer.b_off) if layer.nbias else None, ws.data_ptr(), nbytes,
+                     st_['stats'].data_ptr(), self.store.p_ptr(bl_.w_off), self.dtype,
+                     kernel='thin_wgrad3x3_partial_kernel', flops=fl, bytes=self.B * (Hi * Wi + Ho * Wo) * 8 * self.es, side=sid)
+            plan.flops += fl
+            return
         plan.add(layer.name + '/dw', self.lib.seg_thin_wgrad3x3, C.byref(sv), self.B, Hi, Wi, C.byref(zv), Ho, Wo, layer.cin, layer.cout, layer.pad,
                  self.store.g_ptr(layer.w_off), self.store.g_ptr(layer.b_off) if layer.nbias else None, ws.data_ptr(), nbytes, self.dtype,
                  kernel='thin_wgrad3x3_partial_kernel', flops=fl, bytes=self.B * (Hi * Wi + Ho * Wo) * 8 * self.es, side=sid)
@@ -1444,6 +1468,19 @@ class Net(object):
             return
         plan.add(layer.name, self.lib.seg_bn_fwd, C.byref(av), C.byref(yv), self.store.p_ptr(layer.w_off), mov, st['stats'].data_ptr(),
                  1 if training else 0, decay, eps, self.B, a.H, a.W, a.Cp, layer.cout, st['ws'].data_ptr(), self.dtype, kernel='bn_apply_kernel')
+
+    def bn_stats(self, plan, layer, st, a, training=True, update_moving=True, decay=0.999, eps=1e-3, rows=0):
+        """the statistics of bn_fwd alone (batch or moving -> st['stats'], moving averages updated): for a consumer that normalises on
+        load (conv_fwd / conv_bwd with src_bn=(st, layer))"""
+        av = a.view()
+        plan.keep += [av, st]
+        mov = st['moving'].data_ptr() if (update_moving or not training) else None
+        if rows > 0 and training:
+            plan.add(layer.name + '/stats', self.lib.seg_bn_fwd_rows, C.byref(av), None, self.store.p_ptr(layer.w_off), mov, st['stats'].data_ptr(),
+                     decay, eps, self.B, a.H, a.W, a.Cp, layer.cout, st['ws'].data_ptr(), rows, self.dtype, kernel='bn_final_kernel')
+            return
+        plan.add(layer.name + '/stats', self.lib.seg_bn_fwd, C.byref(av), None, self.store.p_ptr(layer.w_off), mov, st['stats'].data_ptr(),
+                 1 if training else 0, decay, eps, self.B, a.H, a.W, a.Cp, layer.cout, st['ws'].data_ptr(), self.dtype, kernel='bn_final_kernel')
 
     def bn_pool_fwd(self, plan, layer, st, a, pooled, k, training=True, update_moving=True, decay=0.999, eps=1e-3, rows=0):
         """batch norm + the k x k / stride-k max-pool that consumes it in one pass (seg_bn_pool_fwd): `pooled` is bit for bit

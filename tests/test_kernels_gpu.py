@@ -539,6 +539,47 @@ def test_conv_first_gen(k, stride, padding, cin, cout, H, relu):
     assert U.pad_channels_zero(out)
 
 
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('nc,H,W,B', [(2, 21, 30, 2), (4, 16, 9, 3), (7, 12, 25, 1)])
+def test_thin_conv_normalises_its_source_on_load(dtype, nc, H, W, B):
+    """seg_thin_conv3x3_bn / seg_thin_wgrad3x3_bn (DeconvModel bn8 -> conv_out, models/deconvolution.py:168-170): the convolution and its
+    filter gradient read the pre-batch-norm activation and normalise on load -- bit-identical logits and filter gradient to running
+    seg_bn_fwd first and reading its output, which therefore need not exist."""
+    rng = np.random.default_rng(nc * 31 + H)
+    cv = E.Layer('c', 'conv', 3, [nc], nc, 'SAME', False)
+    bnl = E.Layer('bn', 'bn', 1, [nc], nc); bnl.cout_p = 8
+    p = {'c': _rand_params(cv, rng, dtype), 'bn': {'beta': (rng.standard_normal(nc) * 0.2).astype(np.float32)}}
+    store = U.make_store([cv, bnl], dtype, p)
+    net = E.Net(store, B, dtype, U.dev())
+    av = np.maximum(U.round_dtype(rng.standard_normal((B, H, W, nc)) + 0.2, dtype), 0)
+    a = net.act(H, W, nc, thin=True); U.fill_act(a, av)
+    dzv = U.round_dtype(rng.standard_normal((B, H, W, nc)), dtype)
+    dz = net.act(H, W, nc, thin=True); U.fill_act(dz, dzv)
+    res = []
+    for fused in (False, True):
+        st = net.bn_state(bnl)
+        lg = net.act(H, W, nc, f32=True, thin=True); lg.t.fill_(float('nan'))
+        da = net.act(H, W, nc, thin=True)
+        plan = E.Plan('t')
+        store.g.fill_(float('nan'))
+        if fused:
+            net.bn_stats(plan, bnl, st, a, training=True, update_moving=True)
+            net.conv_fwd(plan, cv, [(a, 0, 0)], H, W, lg, out_f32=True, src_bn=(st, bnl))
+            net.conv_bwd(plan, cv, [(a, 0, 0)], H, W, dz, [(da, (0, 0), None, (0, 0))], src_bn=(st, bnl))
+        else:
+            y = net.act(H, W, nc, thin=True)
+            net.bn_fwd(plan, bnl, st, a, y, training=True, update_moving=True)
+            net.conv_fwd(plan, cv, [(y, 0, 0)], H, W, lg, out_f32=True)
+            net.conv_bwd(plan, cv, [(y, 0, 0)], H, W, dz, [(da, (0, 0), None, (0, 0))])
+        net.flush_reduce(plan)
+        plan.run(U.stream()); U.sync()
+        g = store.get_grads()['c']
+        res.append((lg.t.clone(), st['stats'].clone(), st['moving'].clone(), da.t.clone(), g['weights'].copy(), g['biases'].copy()))
+    for x0, x1 in zip(res[0][:4], res[1][:4]):
+        assert torch.equal(x0, x1)
+    assert np.isfinite(res[1][4]).all() and np.array_equal(res[0][4], res[1][4]) and np.array_equal(res[0][5], res[1][5])
+
+
 @pytest.mark.parametrize('padding,cin,cout,H,B', [('SAME', 3, 32, 64, 3), ('SAME', 3, 64, 37, 2), ('SAME', 1, 20, 50, 4), ('VALID', 3, 32, 41, 2), ('SAME', 2, 40, 130, 1)])
 def test_conv_first_gen_wgrad(padding, cin, cout, H, B):
     """seg_conv_first_gen_wgrad (filter + bias gradient of the DeconvModel's conv1_0 straight from the image, models/deconvolution.py:
