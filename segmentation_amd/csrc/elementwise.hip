@@ -1240,17 +1240,37 @@ __global__ __launch_bounds__(256) void thin_conv3x3_kernel(seg_view src, const f
     float acc[NC];
 #pragma unroll
     for (int co = 0; co < NC; ++co) acc[co] = sb[co];
+    // all nine loads first, at clamped addresses, the out-of-image taps zeroed by a select: with a branch per tap the loads could
+    // not be issued together and a pixel cost nine load latencies in a row
+    if constexpr (NC <= 4) {
+    Vec8<T> xv[9]; bool ok[9];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int iy = q_.y - pad + u;
-      if (iy < 0 || iy >= Hi) continue;
+    for (int t = 0; t < 9; ++t) {
+      const int iy = q_.y - pad + t / 3, ix = q_.x - pad + t % 3;
+      ok[t] = iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+      const int cy = iy < 0 ? 0 : (iy >= Hi ? Hi - 1 : iy), cx = ix < 0 ? 0 : (ix >= Wi ? Wi - 1 : ix);
+      xv[t].load(sp + view_off(src, q_.b, cy, cx));
+    }
 #pragma unroll
-      for (int v = 0; v < 3; ++v) {
-        const int ix = q_.x - pad + v;
-        if (ix < 0 || ix >= Wi) continue;
+    for (int t = 0; t < 9; ++t) {
+      const float* wt = sw + t * NC * NC;
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) {
+        float xf = xv[t].get(ci);
+        if (bn_stats != nullptr) xf = to_f32(from_f32<T>((xf - bm[ci]) * br[ci] + bb[ci]));
+        xf = ok[t] ? xf : 0.f;
+#pragma unroll
+        for (int co = 0; co < NC; ++co) acc[co] = fmaf(xf, wt[ci * NC + co], acc[co]);
+      }
+    }
+    } else {                                   // (8 x 8 channels: the hoisted form spills; one tap at a time)
+#pragma unroll 1
+      for (int t = 0; t < 9; ++t) {
+        const int iy = q_.y - pad + t / 3, ix = q_.x - pad + t % 3;
+        if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
         Vec8<T> xv;
         xv.load(sp + view_off(src, q_.b, iy, ix));
-        const float* wt = sw + (u * 3 + v) * NC * NC;
+        const float* wt = sw + t * NC * NC;
 #pragma unroll
         for (int ci = 0; ci < NC; ++ci) {
           float xf = xv.get(ci);
@@ -1365,16 +1385,22 @@ __global__ __launch_bounds__(256) void thin_wgrad3x3_partial_kernel(seg_view src
     float z[NC];
 #pragma unroll
     for (int co = 0; co < NC; ++co) { z[co] = zv.get(co); bsum[co] += z[co]; }
+    Vec8<T> xv[TAPS]; bool ok[TAPS];             // (all loads first, clamped addresses: see thin_conv3x3_kernel)
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
       const int tap = tap0 + t, u = tap / 3, v = tap - 3 * u;
       const int iy = q_.y - pad + u, ix = q_.x - pad + v;
-      if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
-      Vec8<T> xv; xv.load(sp + view_off(src, q_.b, iy, ix));
+      ok[t] = iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+      const int cy = iy < 0 ? 0 : (iy >= Hi ? Hi - 1 : iy), cx = ix < 0 ? 0 : (ix >= Wi ? Wi - 1 : ix);
+      xv[t].load(sp + view_off(src, q_.b, cy, cx));
+    }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
 #pragma unroll
       for (int ci = 0; ci < NC; ++ci) {
-        float xf = xv.get(ci);
+        float xf = xv[t].get(ci);
         if (bn_stats != nullptr) xf = to_f32(from_f32<T>((xf - bm[ci]) * br[ci] + bb[ci]));
+        xf = ok[t] ? xf : 0.f;
 #pragma unroll
         for (int co = 0; co < NC; ++co) acc[(t * NC + ci) * NC + co] = fmaf(xf, z[co], acc[(t * NC + ci) * NC + co]);
       }
