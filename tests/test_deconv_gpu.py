@@ -428,6 +428,26 @@ def test_deconv_bf16_gradients_follow_f32_layer_by_layer():
     assert worst[('conv1_0', 'weights')][0] > 0.85
 
 
+def test_deconv_bf16_bayesian_graph_equals_eager():
+    """bf16 with the `bayesian` dropouts: bn2 (a dropout sits between it and its pool) keeps the two-pass form while bn1 / bn3 run fused
+    with their pools and bn8 is applied on load -- the mixed plan trains, and its captured graph replays the eager launches bit for bit."""
+    B, S, nc = 4, 256, 2
+    x, y = _data(B, S, nc, seed=5)
+    kw = dict(sess=None, n_classes=nc, input_dims=S, n_kernels=32, log_dir=None, save_dir=None, load_snapshot=False, dtype='bf16',
+              bayesian=True, learning_rate=1e-3)
+    m1 = DeconvModel(dataset=ArrayDataSet(x, y), use_graph=False, **kw)
+    m2 = DeconvModel(dataset=ArrayDataSet(x, y), use_graph=True, **kw)
+    l1 = []
+    for _ in range(10):
+        m1.train_step(); m2.train_step(); l1.append(m1.last_loss())
+    torch.cuda.synchronize()
+    assert np.isfinite(l1).all() and l1[-1] < l1[0]
+    assert torch.equal(m1.store.p, m2.store.p)
+    assert all(torch.equal(m1.bn[b]['moving'], m2.bn[b]['moving']) for b in m1.bn)
+    m1.test()
+    assert np.isfinite(m1.last_test_loss)
+
+
 def test_deconv_rejects_infeasible_and_odd_sizes():
     x, y = _data(1, 128, 2)
     with pytest.raises(Exception):
