@@ -380,24 +380,33 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(seg_view a, seg_view dy
   }
 }
 
+constexpr int BNF_SL = 128;            // row slices per workgroup of bn_final_kernel (x 8 channels = 1024 threads)
 template <int MODE>
-__global__ void bn_final_kernel(const float* ws, int nb, int C, int c_log, double inv_n, float eps, float decay, int training,
-                                float* moving, float* stats, float* out2, float* dbeta, int dbeta_add) {
-  // 8 channels x 32 slices per workgroup: a thread sums every 32nd partial row, the slices meet in LDS in a fixed order (one
-  // thread per channel walking all nb rows was 60 us of pure load latency per batch norm; 32 channels x 8 slices still 15 us --
-  // a 32-channel layer was ONE workgroup with 128 dependent loads per thread)
-  __shared__ double r1[32][8], r2[32][8];
+__global__ __launch_bounds__(1024) void bn_final_kernel(const float* ws, int nb, int C, int c_log, double inv_n, float eps, float decay, int training,
+                                                        float* moving, float* stats, float* out2, float* dbeta, int dbeta_add) {
+  // 8 channels x 128 slices per workgroup: a thread sums every 128th partial row (<= 8 loads), the slices meet in LDS in two fixed
+  // stages.  (One thread per channel walking all nb rows was 60 us of pure load latency per batch norm; 32 channels x 8 slices 15 us;
+  // 8 x 32 slices still 7.4 us of 32 dependent-latency loads -- 16 of these launches sit on the critical stream of a DeconvModel step.)
+  __shared__ double r1[BNF_SL][8], r2[BNF_SL][8];
   const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int b = sl; b < nb; b += 32) { s1 += (double)ws[((int64_t)b * C + c) * 2]; s2 += (double)ws[((int64_t)b * C + c) * 2 + 1]; }
+    for (int b = sl; b < nb; b += BNF_SL) { s1 += (double)ws[((int64_t)b * C + c) * 2]; s2 += (double)ws[((int64_t)b * C + c) * 2 + 1]; }
   r1[sl][cl] = s1; r2[sl][cl] = s2;
+  __syncthreads();
+  if (sl < 16) {                          // stage 1: slice groups of 8, in order
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { s1 += r1[sl * 8 + q][cl]; s2 += r2[sl * 8 + q][cl]; }
+  }
+  __syncthreads();
+  if (sl < 16) { r1[sl][cl] = s1; r2[sl][cl] = s2; }
   __syncthreads();
   if (sl != 0 || c >= C) return;
   s1 = 0.0; s2 = 0.0;
 #pragma unroll
-  for (int q = 0; q < 32; ++q) { s1 += r1[q][cl]; s2 += r2[q][cl]; }
+  for (int q = 0; q < 16; ++q) { s1 += r1[q][cl]; s2 += r2[q][cl]; }
   if (MODE == 0) {
     float mean, var;
     if (training) {
@@ -980,7 +989,7 @@ static int bn_fwd_launch(const seg_view* a, const seg_view* y, const float* beta
     else SEG_LAUNCH((bn_partial_kernel<bf16_t, 0>), dim3(nb), dim3(256), 0, st, *a, none, (const float*)nullptr, B, H, W, C, ws);
     if (int rc = seg_check_launch("bn_partial")) return rc;
   }
-  SEG_LAUNCH(bn_final_kernel<0>, dim3((C + 7) / 8), dim3(256), 0, st, (const float*)ws, training ? nb : 0, C, c_log, 1.0 / (double)npix, eps, decay,
+  SEG_LAUNCH(bn_final_kernel<0>, dim3((C + 7) / 8), dim3(8 * BNF_SL), 0, st, (const float*)ws, training ? nb : 0, C, c_log, 1.0 / (double)npix, eps, decay,
              training, moving, stats, (float*)nullptr, (float*)nullptr, 0);
   if (int rc = seg_check_launch("bn_final")) return rc;
   if (stats_only) return 0;
@@ -1007,7 +1016,7 @@ extern "C" int seg_bn_relu_bwd(const seg_view* a, const seg_view* dy, const seg_
   if (dtype == SEG_F32) SEG_LAUNCH((bn_partial_kernel<float, 1>), dim3(nb), dim3(256), 0, st, *a, *dy, stats, B, H, W, C, ws);
   else SEG_LAUNCH((bn_partial_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, st, *a, *dy, stats, B, H, W, C, ws);
   if (int rc = seg_check_launch("bn_partial_bwd")) return rc;
-  SEG_LAUNCH(bn_final_kernel<1>, dim3((C + 7) / 8), dim3(256), 0, st, (const float*)ws, nb, C, c_log, 1.0 / (double)npix, 0.f, 0.f, 1,
+  SEG_LAUNCH(bn_final_kernel<1>, dim3((C + 7) / 8), dim3(8 * BNF_SL), 0, st, (const float*)ws, nb, C, c_log, 1.0 / (double)npix, 0.f, 0.f, 1,
              (float*)nullptr, (float*)nullptr, means, dbeta, dbeta_add);
   if (int rc = seg_check_launch("bn_final_bwd")) return rc;
   const int g = grid_for(npix * (C / 8));
@@ -1031,7 +1040,7 @@ extern "C" int seg_bn_pool_relu_bwd(const seg_view* a, const seg_view* dpool, co
   if (dtype == SEG_F32) SEG_LAUNCH(bn_pool_partial_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, *a, *dpool, stats, k, B, Hp, Wp, C, ws);
   else SEG_LAUNCH(bn_pool_partial_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, *a, *dpool, stats, k, B, Hp, Wp, C, ws);
   if (int rc = seg_check_launch("bn_pool_partial_bwd")) return rc;
-  SEG_LAUNCH(bn_final_kernel<1>, dim3((C + 7) / 8), dim3(256), 0, st, (const float*)ws, nb, C, c_log, 1.0 / (double)npix, 0.f, 0.f, 1,
+  SEG_LAUNCH(bn_final_kernel<1>, dim3((C + 7) / 8), dim3(8 * BNF_SL), 0, st, (const float*)ws, nb, C, c_log, 1.0 / (double)npix, 0.f, 0.f, 1,
              (float*)nullptr, (float*)nullptr, means, dbeta, dbeta_add);
   if (int rc = seg_check_launch("bn_final_bwd")) return rc;
   const int g = grid_for((int64_t)B * ((H + k - 1) / k) * ((W + k - 1) / k) * (C / 8));
