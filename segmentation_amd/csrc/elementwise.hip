@@ -1136,7 +1136,8 @@ extern "C" int seg_softmax_xent_probs(const seg_view* logits, const uint8_t* lab
 static int head_xent_grid(int64_t B, int64_t H, int64_t W, int cpad) {
   // >= 4 pixels per lane group (a 68 x 68 map: 289 workgroups), at most 2048 workgroups (512 x 512: ~13 pixels each): the
   // per-workgroup partial row and the loss atomic stay cheap (16 k workgroups doubled the kernel time on the atomic alone)
-  const int64_t px_per_wg = 256 / (cpad / 8) * 4;
+  static const int per_group = getenv("SEG_HEAD_PX") ? atoi(getenv("SEG_HEAD_PX")) : 4;
+  const int64_t px_per_wg = 256 / (cpad / 8) * (per_group > 0 ? per_group : 4);
   return grid_for(B * H * W, (int)px_per_wg, 2048);
 }
 static int head_ncp(int n_classes) { return n_classes <= 4 ? 4 : n_classes <= 8 ? 8 : n_classes <= 16 ? 16 : 32; }
