@@ -55,7 +55,9 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--per-op', action='store_true', help='also print the per-op table to stderr')
     ap.add_argument('--streams', type=int, default=2, help='side streams for the filter gradients (0 = everything on one stream)')
-    ap.add_argument('--force-dist', action='store_true', help='diagnostic: take the data-parallel code path (RCCL group of size 1) on one GPU')
+    ap.add_argument('--force-dist', action='store_true', help='diagnostic: take the data-parallel code path (RCCL group of size 1) on one GPU; the one-rank '
+                    'collectives themselves are skipped, as in any world-1 run, unless --force-collectives')
+    ap.add_argument('--force-collectives', action='store_true', help='with --force-dist: issue the (identity) all-reduces of a one-rank group anyway (SEG_DP_FORCE=1)')
     ap.add_argument('--dp-cuts', default='auto', help="N>1: gradient-bucket boundaries (layer names, backward order); 'auto' times three bucket plans "
                     "(2, 4 and 6 buckets) on the actual node during warm-up and keeps the fastest; 'default' = the model's 4-bucket plan")
     ap.add_argument('--windows', type=int, default=5, help='timed windows of --steps steps each; the FIRST one is `value`, all of them are reported as config.ms_per_step_windows')
@@ -262,6 +264,8 @@ def main():
     backend = os.environ.get('SEG_BENCH_BACKEND', 'nccl')
     local = local % max(1, torch.cuda.device_count()) if backend != 'nccl' else local
     torch.cuda.set_device(local)
+    if args.force_collectives:
+        os.environ['SEG_DP_FORCE'] = '1'
     if world > 1 or args.force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29517')

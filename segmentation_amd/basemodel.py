@@ -392,11 +392,18 @@ class BaseModel(object):
 
             def on_marker(md, side_streams):
                 if md['marker'] == 'bucket':
+                    if self.pg.world == 1 and not self.pg.force_collectives:
+                        return                             # nothing to exchange: no events, no collective (dist.all_reduce_bucket)
                     # issued from the first side stream once it has also seen the other one (RCCL's stream waits for the stream that
                     # is current at the call): no stream of our own for the collectives
-                    st0 = side_streams[0] if side_streams else torch.cuda.current_stream(self.device)
+                    main = torch.cuda.current_stream(self.device)
+                    st0 = side_streams[0] if side_streams else main
                     for st in side_streams[1:]:
                         ev = torch.cuda.Event(); ev.record(st); st0.wait_event(ev)
+                    if md.get('main_event', True) and st0 is not main:
+                        # a gradient of this bucket was written on the main stream behind the last side fork
+                        # (engine.mark_bucket_main_writers): the issuing stream has to see it
+                        ev = torch.cuda.Event(); ev.record(main); st0.wait_event(ev)
                     with torch.cuda.stream(st0):
                         self.pg.all_reduce_bucket(self.store.g_full, md['lo'], md['hi'])
                     return
@@ -654,6 +661,8 @@ class BaseModel(object):
         self.net.adam(self.dp_step_plan, self.learning_rate, grad_scale=1.0 / self.pg.world)
         if self.adversary is not None:
             self.adversary.emit_update(self.dp_step_plan)
+        g0 = self.store.g_full.data_ptr()
+        self._dp_main_events = E.mark_bucket_main_writers(self.dp_step_plan, g0, g0 + self.store.g_full.numel() * 4)
 
     def set_weights(self, params):
         """Load {scope: {'weights','biases'}} in TF layouts (tests / interchange)."""

@@ -27,24 +27,49 @@ class DataParallel(object):
         import os
         self.algo = algo or os.environ.get('SEG_DP_ALGO', 'allreduce')
         self._dry = os.environ.get('SEG_DP_DRY', '0') == '1'
+        self.force_collectives = os.environ.get('SEG_DP_FORCE', '0') == '1'     # world 1: run the (identity) collectives anyway
+        self.rs_min = 4096                      # rs_ag: elements per rank below which a bucket goes through one all-reduce
+        self._has_rs = None
         if self.algo not in ('allreduce', 'rs_ag'):
             raise ValueError("SEG_DP_ALGO must be 'allreduce' or 'rs_ag'")
 
+    def _backend_has_reduce_scatter(self):
+        """RCCL (backend "nccl") has reduce_scatter_tensor / all_gather_into_tensor; gloo has neither reduce-scatter form.  There the
+        reduce-scatter is EMULATED -- an all-reduce of a copy of the bucket body, of which this rank keeps only its own slice, so
+        that the slice arithmetic, the all-gather into the in-place views and the tail all-reduce below are the code RCCL runs."""
+        if self._has_rs is None:
+            try:
+                self._has_rs = dist.get_backend(self.group) == 'nccl'
+            except Exception:                              # noqa
+                self._has_rs = False
+        return self._has_rs
+
     def all_reduce_bucket(self, flat, lo, hi):
-        if not self.enabled or hi <= lo:        # world 1 still runs the collective when a group exists (1-GPU RCCL path)
+        if not self.enabled or hi <= lo:
+            return
+        if self.world == 1 and not self.force_collectives:
+            # A one-rank "all-reduce" is the identity, but RCCL still launches its copy kernels for it: measured 2 % of the C2 step
+            # (profiles/r03_dp_overhead.txt), overhead an 8-rank run does not have in that form.  bench.py --force-dist keeps them
+            # as a diagnostic of the data-parallel step structure (force_collectives / SEG_DP_FORCE=1).
             return
         if self._dry:                           # (diagnostic: the step's own data-parallel overhead without RCCL's kernels)
             return
         n, w_ = hi - lo, self.world
-        if self.algo == 'rs_ag' and w_ > 1 and n >= 4096 * w_:
+        if self.algo == 'rs_ag' and w_ > 1 and n >= self.rs_min * w_:
             # equal slices (the tail that does not divide goes through a small all-reduce of its own)
             per = n // w_
             body = flat[lo:lo + per * w_]
             mine = body[self.rank * per:(self.rank + 1) * per]
-            w1 = dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            w1.wait()                          # (stream-level: orders the all-gather behind the reduce-scatter on RCCL's stream)
-            w = dist.all_gather_into_tensor(body, mine, group=self.group, async_op=True)
-            works = [w]
+            works = []
+            if self._backend_has_reduce_scatter():
+                # both collectives run in order on the process group's one RCCL stream: no host- or stream-level wait between them
+                # (a wait here would park the issuing side stream behind the reduce-scatter, ADVICE r03)
+                works.append(dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:
+                tmp = body.clone()
+                dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+                mine.copy_(tmp[self.rank * per:(self.rank + 1) * per])     # the other slices of `body` keep this rank's local sums
+            works.append(dist.all_gather_into_tensor(body, mine, group=self.group, async_op=True))
             if per * w_ < n:
                 works.append(dist.all_reduce(flat[lo + per * w_:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:

@@ -295,6 +295,49 @@ def _tail_layers(default=()):
     return set(x for x in v.split(',') if x and x != '-')
 
 
+def _touches(args, lo_ptr, hi_ptr):
+    """does any launch argument (a raw pointer, or a pointer field of a descriptor passed by reference) point into
+    [lo_ptr, hi_ptr)?"""
+    for a in args:
+        if isinstance(a, int):
+            if lo_ptr <= a < hi_ptr:
+                return True
+            continue
+        d = getattr(a, '_obj', None)
+        if d is None:
+            continue
+        for fld in ('dw', 'db', 'dst', 'dst1'):
+            v = getattr(d, fld, None)
+            v = getattr(v, 'ptr', v)                      # (a seg_view field: its base pointer)
+            if isinstance(v, int) and lo_ptr <= v < hi_ptr:
+                return True
+    return False
+
+
+def mark_bucket_main_writers(plan, lo_ptr, hi_ptr):
+    """Data-parallel plans: a bucket's all-reduce is issued from a side stream that has waited for the other side streams, never for
+    the main stream.  Gradients written ON the main stream (bias gradients of the transposed convolutions, filter gradients forced
+    onto stream 0, the loss word) are covered only if a side launch behind them forks from the main stream before the marker.
+    This walks the plan once and sets marker['main_event'] where that does not hold: Plan.run's caller then records an event on the
+    main stream for that bucket and the issuing stream waits for it (enforced, not assumed).  Conservative: any
+    main-stream launch with a pointer into the arena counts as a writer."""
+    uncovered = False
+    n = 0
+    for (name, fn, args), md in zip(plan.ops, plan.meta):
+        if fn is None:
+            if md.get('marker') == 'bucket':
+                md['main_event'] = uncovered
+                n += int(uncovered)
+                uncovered = False
+            continue
+        tag = md.get('side', 0)
+        if tag and tag != 'aux':
+            uncovered = False          # a filter-gradient stream forks from (or is already ordered behind) everything on main so far
+        elif not tag and _touches(args, lo_ptr, hi_ptr):
+            uncovered = True
+    return n
+
+
 class Plan(object):
     """Ordered list of C-ABI launches.  Every entry is (name, fn, args-without-stream)."""
 
@@ -844,11 +887,6 @@ class Net(object):
         plan.add('pool', self.lib.seg_maxpool2x2_fwd, C.byref(sv), C.byref(dv), None, self.B, Ho, Wo, src.Cp, self.dtype, kernel='maxpool_fwd_kernel')
 
     # ---------------- backward ----------------
-    def bias_grad(self, plan, layer, dz, H, W, dz_off=(0, 0)):
-        zv = dz.view(dz_off[0], dz_off[1])
-        plan.keep.append(zv)
-        self.bias_grad(plan, layer.name + '/db', zv, H, W, layer.cout, layer.b_off)
-
     def _wgrad_ws(self, w, plan, ksplit=0):
         """Asks the library for the K split / partial-slab workspace of this wgrad and allocates it."""
         ks, nbytes = C.c_int32(0), C.c_int64(0)

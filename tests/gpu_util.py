@@ -48,6 +48,18 @@ def tol(dtype, f32_tol=2e-5, bf16_tol=2e-2):
     return f32_tol if dtype == L.SEG_F32 else bf16_tol
 
 
+def tol_sum(dtype, f32_tol=2e-5):
+    """Bound for an f32 OUTPUT that is a sum of exact products of the operands given to the oracle (filter / bias gradients: bf16 x
+    bf16 products are exact in f32, so only the summation order differs from the float64 oracle): 1e-4 of the tensor maximum in
+    bf16 mode -- one dropped window pixel moves such a sum by 4e-3 and more."""
+    return f32_tol if dtype == L.SEG_F32 else 1e-4
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum()) / (np.sqrt((b ** 2).sum()) + 1e-30))
+
+
 def rel_err(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))

@@ -111,8 +111,8 @@ def test_conv_fwd_bwd(dtype, case):
     dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (k, k), padding, 1)
     dx_ref = ops.conv2d_dgrad(dzv, p['c']['weights'], (H, W), padding, 1)
     g = store.get_grads()['c']
-    assert U.rel_err(g['weights'], dw_ref) < U.tol(dtype, 2e-5, 1e-2), 'wgrad'
-    assert U.rel_err(g['biases'], db_ref) < U.tol(dtype, 2e-5, 1e-2), 'bias grad'
+    assert U.rel_err(g['weights'], dw_ref) < U.tol_sum(dtype), 'wgrad'
+    assert U.rel_err(g['biases'], db_ref) < U.tol_sum(dtype), 'bias grad'
     c0 = 0
     for i, c in enumerate(segs):
         want = dx_ref[..., c0:c0 + c]
@@ -268,13 +268,13 @@ def test_thin_tensors_through_the_mfma_kernels(dtype, nc, H, W, B, valu, monkeyp
     bp.run(U.stream()); U.sync()
     g = store.get_grads()
     dw_ref, db_ref = ops.conv2d_wgrad(a_got, dzv, (3, 3), 'SAME', 1)
-    assert U.rel_err(g['c']['weights'], dw_ref) < U.tol(dtype, 2e-5, 1e-2) and U.rel_err(g['c']['biases'], db_ref) < U.tol(dtype, 2e-5, 1e-2)
+    assert U.rel_err(g['c']['weights'], dw_ref) < U.tol_sum(dtype) and U.rel_err(g['c']['biases'], db_ref) < U.tol_sum(dtype)
     da_ref = ops.conv2d_dgrad(dzv, p['c']['weights'], (2 * H, 2 * W), 'SAME', 1) * (a_got > 0)
     assert U.rel_err(U.read_act(da), da_ref) < U.tol(dtype)
     assert bool((da.t[..., nc:].float() == 0).all().item())
     da_got = U.round_dtype(U.read_act(da), dtype)
     uw_ref, ub_ref = ops.conv2d_transpose_wgrad(xs, da_got, (2, 2), stride=2, padding='VALID')
-    assert U.rel_err(g['u']['weights'], uw_ref) < U.tol(dtype, 2e-5, 1e-2) and U.rel_err(g['u']['biases'], ub_ref) < U.tol(dtype, 2e-5, 1e-2)
+    assert U.rel_err(g['u']['weights'], uw_ref) < U.tol_sum(dtype) and U.rel_err(g['u']['biases'], ub_ref) < U.tol_sum(dtype)
     dx_ref = ops.conv2d_transpose_dgrad(da_got, p['u']['weights'], (H, W), stride=2, padding='VALID')
     assert U.rel_err(U.read_act(dx), dx_ref) < U.tol(dtype)
 
@@ -324,8 +324,8 @@ def test_wgrad_layouts(case):
     dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (k, k), padding, 1)
     g = store.get_grads()['c']
     assert np.isfinite(g['weights']).all() and np.isfinite(g['biases']).all()
-    assert U.rel_err(g['weights'], dw_ref) < 1e-2, 'wgrad ' + name
-    assert U.rel_err(g['biases'], db_ref) < 1e-2, 'bias grad ' + name
+    assert U.rel_err(g['weights'], dw_ref) < U.tol_sum(dtype), 'wgrad ' + name
+    assert U.rel_err(g['biases'], db_ref) < U.tol_sum(dtype), 'bias grad ' + name
     # same bits on a second run (fixed reduction order)
     g1 = store.g.clone(); store.g.fill_(0); bplan.run(U.stream()); U.sync()
     assert torch.equal(g1, store.g)
@@ -389,8 +389,8 @@ def test_wgrad_sweep(case):
     dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (k, k), padding, 1)
     g = store.get_grads()['c']
     assert np.isfinite(g['weights']).all() and np.isfinite(g['biases']).all(), name
-    assert U.rel_err(g['weights'], dw_ref) < 1e-2, 'wgrad ' + name
-    assert U.rel_err(g['biases'], db_ref) < 1e-2, 'bias grad ' + name
+    assert U.rel_err(g['weights'], dw_ref) < U.tol_sum(dtype), 'wgrad ' + name
+    assert U.rel_err(g['biases'], db_ref) < U.tol_sum(dtype), 'bias grad ' + name
     # same bits on a second run (fixed summation order), also from a poisoned workspace
     g1 = store.g.clone(); store.g.fill_(float('nan')); bplan.run(U.stream()); U.sync()
     assert torch.equal(g1, store.g), name
@@ -448,8 +448,8 @@ def test_upconv_fwd_bwd(dtype, case):
     dw_ref, db_ref = ops.conv2d_transpose_wgrad(xv, dzv, (2, 2), 2, 'VALID')
     dx_ref = ops.conv2d_transpose_dgrad(dzv, p['u']['weights'], (H, W), 2, 'VALID') * (xv > 0)
     g = store.get_grads()['u']
-    assert U.rel_err(g['weights'], dw_ref) < U.tol(dtype, 2e-5, 1e-2), 'up wgrad'
-    assert U.rel_err(g['biases'], db_ref) < U.tol(dtype, 2e-5, 1e-2), 'up bias grad'
+    assert U.rel_err(g['weights'], dw_ref) < U.tol_sum(dtype), 'up wgrad'
+    assert U.rel_err(g['biases'], db_ref) < U.tol_sum(dtype), 'up bias grad'
     assert U.rel_err(U.read_act(dx), dx_ref) < U.tol(dtype), 'up dgrad'
 
 
@@ -506,8 +506,8 @@ def test_wgrad_every_instance_on_a_long_tile_walk(dtype, kind, wcfg):
     g = store.get_grads()[key]
     name = bplan.kernel_name(0)
     assert np.isfinite(g['weights']).all() and np.isfinite(g['biases']).all(), name
-    assert U.rel_err(g['weights'], dw_ref) < U.tol(dtype, 5e-5, 1e-2), 'wgrad ' + name
-    assert U.rel_err(g['biases'], db_ref) < U.tol(dtype, 5e-5, 1e-2), 'bias grad ' + name
+    assert U.rel_err(g['weights'], dw_ref) < U.tol_sum(dtype, 5e-5), 'wgrad ' + name
+    assert U.rel_err(g['biases'], db_ref) < U.tol_sum(dtype, 5e-5), 'bias grad ' + name
 
 
 @pytest.mark.parametrize('relu', [True, False])
@@ -693,16 +693,17 @@ def test_conv_first(dtype, pad, cin, cout, H, impl, relu, monkeypatch):
         dz = net.act(Ho, Wo, cout); U.fill_act(dz, dzv)
         store.g.zero_()
         bp = E.Plan('b'); net.first_bwd(bp, layer, xt, H, W, dz); net.flush_reduce(bp); bp.run(U.stream()); U.sync()
-        dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (3, 3), layer.padding, 1)
+        # bf16 mode rounds the im2col'd input to bf16 (the MFMA operand type): the oracle gets the same rounded image, so the
+        # filter gradient is an f32 sum of exact products
+        dw_ref, db_ref = ops.conv2d_wgrad(U.round_dtype(x, dtype), dzv, (3, 3), layer.padding, 1)
         g = store.get_grads()['f']
-        # bf16 mode rounds the im2col'd input to bf16 (the MFMA operand type)
-        assert U.rel_err(g['weights'], dw_ref) < U.tol(dtype, 2e-5, 1e-2)
-        assert U.rel_err(g['biases'], db_ref) < U.tol(dtype, 2e-5, 1e-2)
+        assert U.rel_err(g['weights'], dw_ref) < U.tol_sum(dtype)
+        assert U.rel_err(g['biases'], db_ref) < U.tol_sum(dtype)
         assert [o[0] for o in bp.ops if o[1] is not None][0] == 'f/dw'          # no im2col launch: the rows are gathered while staging
         store.g.zero_()
         bl = E.Plan('bl'); net.first_bwd(bl, layer, xt, H, W, dz, ksplit=2); net.flush_reduce(bl); bl.run(U.stream()); U.sync()     # long tile walks
         gl = store.get_grads()['f']
-        assert U.rel_err(gl['weights'], dw_ref) < U.tol(dtype, 2e-5, 1e-2) and U.rel_err(gl['biases'], db_ref) < U.tol(dtype, 2e-5, 1e-2)
+        assert U.rel_err(gl['weights'], dw_ref) < U.tol_sum(dtype) and U.rel_err(gl['biases'], db_ref) < U.tol_sum(dtype)
         # the explicit form (im2col tensor + the same 1x1 walk): the same rounded operands, another summation order at most
         monkeypatch.setenv('SEG_FIRST_IM2COL', '1')
         store.g.zero_()
