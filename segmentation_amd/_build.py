@@ -31,11 +31,25 @@ def lint_ok():
 
 
 def build(force=False, verbose=True):
+    objdir = os.path.join(HERE, 'build')
     if not force and not _stale():
         if not lint_ok():
-            _lint_wgrad_registers()                    # (a library built before the lint existed, or a lost verdict file)
+            # a library built before the lint existed, or a lost verdict file (it is git-ignored): lint under the build lock (N
+            # data-parallel ranks come through here at once) and only WARN where the compiler is not available -- the library is
+            # the one that was shipped; tests/test_extras_gpu.py still insists on a clean verdict on the GPU box
+            import fcntl
+            os.makedirs(objdir, exist_ok=True)
+            with open(os.path.join(objdir, '.lock'), 'w') as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                try:
+                    if not lint_ok():
+                        try:
+                            _lint_wgrad_registers()
+                        except (OSError, subprocess.SubprocessError) as e:
+                            print('warning: register-budget lint skipped (%r)' % (e,), file=sys.stderr)
+                finally:
+                    fcntl.flock(lock, fcntl.LOCK_UN)
         return LIB
-    objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
     # one builder at a time (torch.distributed.run starts one process per GPU, all of which come through here): the others
     # wait for the lock and then find the library fresh
@@ -91,14 +105,15 @@ def _lint_wgrad_registers(limit=250):
     tests/test_extras_gpu.py asserts on the GPU box that the library it loaded was linted from these sources) and a violation
     fails the build.  (The bf16 3x3 filter gradients run in wgrad_sweep.hip, which has no such loads.)"""
     import json
-    sys.path.insert(0, os.path.join(HERE, '..', 'tools'))
-    import check_wgrad_regs as chk
+    from . import _wgrad_regs as chk
     inst = chk.instances(os.environ.get('SEG_EXTRA_FLAGS', '').split())
     bad = [i for i in inst if i['arch_vgprs'] >= limit or i['spills'] or i['scratch_bytes']]
     rec = {'sources': source_digest(), 'limit': limit, 'instances': len(inst), 'over_budget': bad,
            'max_arch_vgprs': max(i['arch_vgprs'] for i in inst) if inst else 0}
-    with open(LINT, 'w') as fh:
+    tmp = LINT + '.tmp.%d' % os.getpid()
+    with open(tmp, 'w') as fh:
         json.dump(rec, fh, indent=1)
+    os.replace(tmp, LINT)
     if bad or len(inst) < 30:
         raise RuntimeError('conv_wgrad.hip: %d of %d instances over the register budget (hand-waited asm loads become unsound): %s' % (len(bad), len(inst), bad))
 

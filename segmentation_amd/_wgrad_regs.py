@@ -8,14 +8,14 @@ AGPRs or in scratch, and a staging register parked before the wait captures a lo
 gradients with a deeper LDS look-ahead, a memory fault in an unused r01 layout).  The check: no scratch, no spills, and
 fewer than LIMIT architectural VGPRs in every instance.
 
-    python tools/check_wgrad_regs.py [--limit 250] [--list]      exit code 1 when an instance is over budget"""
+    python -m segmentation_amd._wgrad_regs [--limit 250] [--list]      exit code 1 when an instance is over budget"""
 import os
 import re
 import subprocess
 import sys
 import tempfile
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 
 
 def instances(extra=()):

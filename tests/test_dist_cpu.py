@@ -46,13 +46,15 @@ def _worker(rank, world, port, x, y, out):
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_matches_global_batch():
+@pytest.mark.parametrize('world,batch', [(2, 2), (8, 8)])
+def test_ranks_over_gloo_match_the_global_batch(world, batch):
+    """world 2, and config C4's shape of the exchange: 8 ranks x 1 image == the single-process step on the batch of 8"""
     rng = np.random.default_rng(5)
-    x = rng.uniform(0, 1, (2, 188, 188, 3)).astype(np.float32)
-    y = rng.integers(0, 2, (2, 188, 188, 1)).astype(np.uint8)
+    x = rng.uniform(0, 1, (batch, 188, 188, 3)).astype(np.float32)
+    y = rng.integers(0, 2, (batch, 188, 188, 1)).astype(np.uint8)
     port = _free_port()
     mgr = mp.Manager(); out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, x, y, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, x, y, out), nprocs=world, join=True)
     p = ounet.init_params(2, 2, seed=11)
     loss, g, _ = ounet.loss_and_grads(p, x, y)
     ref = _flat(g, list(reversed(ounet.CONV_ORDER)))

@@ -15,13 +15,15 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, x, y, out, backend='gloo', cuts=None):
+def _worker(rank, world, port, x, y, out, backend='gloo', cuts=None, use_graph=True, algo=None):
     import torch.distributed as dist
     from segmentation_amd.datasets import ArrayDataSet
     from segmentation_amd.dist import shard_batch
     from segmentation_amd.unet import UNetModel
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if algo:
+        os.environ['SEG_DP_ALGO'] = algo
     dev = rank if backend == 'nccl' else 0                       # RCCL needs one GPU per rank; gloo shares the single test GPU
     torch.cuda.set_device(dev)
     if backend == 'nccl':
@@ -31,8 +33,8 @@ def _worker(rank, world, port, x, y, out, backend='gloo', cuts=None):
     try:
         lo, hi = shard_batch(x.shape[1], world, rank)
         m = UNetModel(sess=None, dataset=ArrayDataSet(x[:, lo:hi], y[:, lo:hi]), n_classes=2, input_dims=188, learning_rate=1e-3,
-                      log_dir=None, save_dir=None, load_snapshot=False, dtype='f32', use_graph=True, dp_cuts=cuts)
-        assert m.pg.world == world and m.pg.enabled
+                      log_dir=None, save_dir=None, load_snapshot=False, dtype='f32', use_graph=use_graph, dp_cuts=cuts)
+        assert m.pg.world == world and m.pg.enabled and m.pg.algo == (algo or 'allreduce')
         if cuts:
             assert len(m.bwd_segments) == len(cuts.split(',')) + 1
         m.pg.broadcast_(m.store.p); m._repack()
@@ -53,12 +55,16 @@ def _worker(rank, world, port, x, y, out, backend='gloo', cuts=None):
 
 
 def _run_two_ranks(backend, cuts=None):
+    return _run_ranks(backend, cuts, 2)
+
+
+def _run_ranks(backend, cuts=None, world=2, use_graph=True, algo=None):
     import torch.multiprocessing as mp
     from segmentation_amd.datasets import ArrayDataSet
     from segmentation_amd.unet import UNetModel
     rng = np.random.default_rng(7)
-    x = rng.uniform(0, 1, (2, 2, 188, 188, 3)).astype(np.float32)
-    y = rng.integers(0, 2, (2, 2, 188, 188, 1)).astype(np.uint8)
+    x = rng.uniform(0, 1, (2, world, 188, 188, 3)).astype(np.float32)
+    y = rng.integers(0, 2, (2, world, 188, 188, 1)).astype(np.uint8)
     ref = UNetModel(sess=None, dataset=ArrayDataSet(x, y), n_classes=2, input_dims=188, learning_rate=1e-3, log_dir=None,
                     save_dir=None, load_snapshot=False, dtype='f32', use_graph=False)
     ref.train_step()
@@ -69,7 +75,7 @@ def _run_two_ranks(backend, cuts=None):
     torch.cuda.synchronize()
     pref = ref.store.p.cpu().numpy()
     mgr = mp.Manager(); out = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), x, y, out, backend, cuts), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), x, y, out, backend, cuts, use_graph, algo), nprocs=world, join=True)
     # same math up to summation order (mean over 2 images vs mean of two per-image means)
     for name, l in ref.store.layers.items():
         for lo, n in ((l.w_off, l.wsize), (l.b_off, l.cout)):
@@ -80,7 +86,7 @@ def _run_two_ranks(backend, cuts=None):
     d = np.abs(out['p'] - pref)
     assert np.median(d) < 1e-6 and (d > 1e-4).mean() < 1e-3 and d.max() < 3.5e-3
     rep = out['rep']
-    assert rep['world'] == 2 and len(rep['buckets_mb']) == len(rep['exposed_us']) and abs(sum(rep['buckets_mb']) - 31.04) < 0.05
+    assert rep['world'] == world and len(rep['buckets_mb']) == len(rep['exposed_us']) and abs(sum(rep['buckets_mb']) - 31.04) < 0.05
     return rep
 
 
@@ -93,6 +99,15 @@ def test_two_ranks_equal_single_process_global_batch():
 def test_two_ranks_six_bucket_plan():
     rep = _run_two_ranks('gloo', 'conv6_2,upconv1,conv5_2,conv5_1,conv3_1')
     assert len(rep['buckets_mb']) == 6 and max(rep['buckets_mb']) < 9.5
+
+
+def test_four_ranks_eager_rs_ag_equal_the_global_batch():
+    """Config C4's control flow as far as a one-GPU box allows it (at most 6 processes may use the card: this one + 4 ranks): four
+    ranks with ONE image each, the eager one-plan data-parallel step bench.py times (bucket markers, collectives issued from a side
+    stream), SEG_DP_ALGO=rs_ag (reduce-scatter emulated over gloo, tail all-reduce) == the single-process step on the batch of 4.
+    The 8-rank form of the same exchange runs on the CPU (tests/test_dist_cpu.py)."""
+    rep = _run_ranks('gloo', None, world=4, use_graph=False, algo='rs_ag')
+    assert len(rep['buckets_mb']) == 4
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one GPU per rank: runs only where >= 2 GPUs are visible')

@@ -244,7 +244,7 @@ def test_example_adversarial_script_runs(tmp_path):
 @pytest.mark.gpu
 def test_loaded_library_was_linted_for_the_wgrad_register_budget():
     """The register-staged filter-gradient kernels (f32, 1x1, 2x2/s2, first layer) wait by hand for asm loads: sound only while no
-    instance is over its register budget (tools/check_wgrad_regs.py).  _build runs that lint with the compiler that builds the
+    instance is over its register budget (segmentation_amd/_wgrad_regs.py).  _build runs that lint with the compiler that builds the
     library and leaves the verdict next to the .so; here, on the GPU box, the library that is actually loaded must carry a clean
     verdict for exactly the sources in the tree (the guard travels with the build)."""
     import json
@@ -297,3 +297,21 @@ def test_bench_two_ranks_rehearsal_over_gloo():
     ar = j['config']['allreduce']
     assert ar['world'] == 2 and len(ar['exposed_us']) == len(ar['buckets_mb']) and len(ar['bucket_plan_probe_ms']) == 3
     assert abs(sum(ar['buckets_mb']) - 31.04) < 0.01 and j['value'] > 0 and np.isfinite(j['config']['final_loss'])
+
+
+def test_bench_four_ranks_one_image_each_rehearsal_over_gloo():
+    """C4's launch shape at the rank count a one-GPU box admits (process guard: 6 on the card): `bench.py --gpus 4 --batch 1 --size 188`
+    over gloo with rs_ag -- one JSON line, global batch 4, dp4.  (8 ranks x 1 image == batch 8: tests/test_dist_cpu.py on the CPU.)"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SEG_BENCH_BACKEND='gloo', SEG_DP_ALGO='rs_ag', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('MASTER_PORT', None); env.pop('RANK', None); env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4', '--batch', '1', '--size', '188', '--steps', '3', '--warmup', '1',
+                        '--windows', '1', '--no-cpu-baseline', '--no-roofline', '--dp-cuts', 'default'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-500:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 4 and j['config']['global_batch'] == 4 and j['config']['parallelism'] == 'dp4' and j['scaling'] == 'weak'
+    assert j['config']['allreduce']['world'] == 4 and j['value'] > 0 and np.isfinite(j['config']['final_loss'])
