@@ -521,6 +521,37 @@ int seg_cast_pad(const float* x, int64_t npix, int32_t c, const seg_view* dst_de
 
 const char* seg_last_error(void);
 int seg_version(void);
+/* Name of the FIRST kernel the calling host thread has launched through this library since the previous call of this function (as
+ * spelled at its launch site, blanks dropped, e.g. "conv_first_win_kernel<1,true,true>"; "" when no launch site recorded one: the
+ * templated convolution / filter-gradient dispatchers are queried with seg_conv2d_kernel_name / seg_conv2d_wgrad_kernel_name).
+ * bench.py labels launches whose instance the C side picks (first layer, thresholds) with what actually ran. */
+const char* seg_last_kernel_name(void);
+
+/* ---- A whole launch plan from one host call (models/basemodel.py:480-489 train_step body; :527-531 infer) -----------------
+ * The host side compiles the launches of a train step / forward pass once into an array of seg_plan_op -- the entry point of each
+ * launch (seg_plan_fn_id), its arguments as seg_arg words WITHOUT the trailing stream, the index of the stream it goes to, and the
+ * cross-stream edges: EVENT forks (record on `stream`, `stream2` waits) and the signal forks of seg_conv_desc.signal (the
+ * convolution with signal_slot > 0 stores signal_base + slot to *signal_flag when it starts; a WAIT_VALUE op makes `stream` wait for
+ * that value with hipStreamWaitValue32) -- and replays it with ONE call per step instead of ~130 interpreter iterations and ctypes
+ * calls (0.64 ms of host time per 0.98 ms U-Net step in round 3).  Returns 0 or the first failing launch's code (*failed_op = its
+ * index).  seg_plan_op.event is owned by the library (zero-initialise; created on first use, one per fork op). */
+typedef union seg_arg { int64_t i; float f32; void* p; } seg_arg;
+#define SEG_OP_LAUNCH 0
+#define SEG_OP_EVENT_FORK 1
+#define SEG_OP_WAIT_VALUE 2
+typedef struct seg_plan_op {
+  int32_t kind;
+  int32_t fn;              /* SEG_OP_LAUNCH: seg_plan_fn_id() of the entry point */
+  int32_t stream, stream2; /* indices into the streams array */
+  int32_t nargs;           /* seg_arg words at args (checked against the entry point) */
+  int32_t signal_slot;     /* LAUNCH of seg_conv2d: > 0 = announce signal_base + slot (0: no signal); WAIT_VALUE: the slot waited for */
+  const seg_arg* args;
+  void* event;
+} seg_plan_op;
+int seg_plan_fn_id(const char* name);
+int seg_plan_run(seg_plan_op* ops, int32_t n, void* const* streams, int32_t n_streams, uint32_t* signal_flag, uint32_t signal_base,
+                 int32_t* failed_op);
+int seg_plan_destroy_events(seg_plan_op* ops, int32_t n);
 
 #ifdef __cplusplus
 }

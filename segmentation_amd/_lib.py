@@ -61,6 +61,17 @@ class PackEntry(C.Structure):
                 ('n_total', C.c_int32), ('n_elems', C.c_int64), ('blk_start', C.c_int64)]
 
 
+class SegArg(C.Union):
+    _fields_ = [('i', C.c_int64), ('f32', C.c_float), ('p', C.c_void_p)]
+
+
+class PlanOp(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('fn', C.c_int32), ('stream', C.c_int32), ('stream2', C.c_int32), ('nargs', C.c_int32),
+                ('signal_slot', C.c_int32), ('args', C.POINTER(SegArg)), ('event', C.c_void_p)]
+
+
+OP_LAUNCH, OP_EVENT_FORK, OP_WAIT_VALUE = 0, 1, 2
+
 i32, i64, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
 PV = C.POINTER(View)
 
@@ -160,6 +171,14 @@ def load():
     lib.seg_last_error.argtypes = []
     lib.seg_version.restype = C.c_int
     lib.seg_version.argtypes = []
+    lib.seg_last_kernel_name.restype = C.c_char_p
+    lib.seg_last_kernel_name.argtypes = []
+    lib.seg_plan_fn_id.restype = C.c_int
+    lib.seg_plan_fn_id.argtypes = [C.c_char_p]
+    lib.seg_plan_run.restype = C.c_int
+    lib.seg_plan_run.argtypes = [C.POINTER(PlanOp), C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]
+    lib.seg_plan_destroy_events.restype = C.c_int
+    lib.seg_plan_destroy_events.argtypes = [C.POINTER(PlanOp), C.c_int32]
     lib.seg_bn_ws_bytes.restype = C.c_int64
     lib.seg_bn_ws_bytes.argtypes = [C.c_int32]
     lib.seg_dconv_wgrad_ws_bytes.restype = C.c_int64

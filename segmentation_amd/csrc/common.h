@@ -14,9 +14,10 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define SEG_DEV __device__ __forceinline__
 // hipGetLastError() is sticky across unrelated runtime calls: clear it before every launch we check.
-#define SEG_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+#define SEG_LAUNCH(k, ...) do { (void)hipGetLastError(); seg_note_kernel(#k); hipLaunchKernelGGL(k, __VA_ARGS__); } while (0)
 
 void seg_set_error(const char* fmt, ...);
+void seg_note_kernel(const char* launch_site_spelling);     // -> seg_last_kernel_name() (thread-local)
 int seg_check_launch(const char* what);
 
 // ---------------------------------------------------------------------------------------------

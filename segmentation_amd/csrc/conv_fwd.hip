@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 int seg_conv_sweep(const seg_conv_desc& d, char* name_out, int name_cap, hipStream_t st, int* rc);   // conv_sweep.hip
+int seg_conv_ring(const seg_conv_desc& d, char* name_out, int name_cap, hipStream_t st, int* rc);    // conv_ring.hip
 
 namespace {
 
@@ -487,6 +488,10 @@ void conv_fwd_kernel(const ConvK P) {
 // ---------------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0, 0, 0, 0};
 
+// (Round 4 tried the fills as inline asm: with the builtin hipcc waits lgkmcnt(0) in front of every use of a ds_read result once an
+// LDS-DMA is pending -- 40 full waits and not one counted wait in this kernel's .s -- and the asm form restores lgkmcnt(1) / (2).  In
+// the C2 train step it measured 1.5 % SLOWER (0.981 against 0.967 ms, three interleaved rounds, profiles/r04_ab_glds_asm_256.txt):
+// the asm statements pin the fills in front of the MFMAs, where the builtin lets the scheduler spread them.)
 SEG_DEV void glds16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -868,7 +873,17 @@ extern "C" int seg_conv2d_splitk_plan(const seg_conv_desc* dp, int32_t* ksplit, 
 
 extern "C" int seg_conv2d(const seg_conv_desc* dp, void* stream) {
   if (!dp) { seg_set_error("conv: null descriptor"); return SEG_ERR_ARG; }
-  const seg_conv_desc& d = *dp;
+  seg_conv_desc d_local;
+  const seg_conv_desc* dq = dp;
+  const seg_conv_desc& d0 = *dp;
+  if (d0.cfg == 204 || d0.cfg == 208 || d0.cfg == 209) {
+    // a forced tile class of conv_ring.hip: where that kernel does not take the layer (32-channel blocks, f32, 1x1 ...) the
+    // automatic choice runs instead
+    int rc = SEG_OK;
+    char dry[4];                                     // (a name buffer makes the call a dry run)
+    if (seg_conv_ring(d0, dry, sizeof(dry), nullptr, &rc) == 0) { d_local = d0; d_local.cfg = 0; dq = &d_local; }
+  }
+  const seg_conv_desc& d = *dq;
   if (!d.src0.ptr || !d.dst.ptr || !d.w_packed) { seg_set_error("conv: null pointer"); return SEG_ERR_ARG; }
   if (d.src0.c <= 0 || d.src0.c % 32 || (d.src1.ptr && (d.src1.c <= 0 || d.src1.c % 32))) {
     seg_set_error("conv: source channels must be positive multiples of 32 (got %d,%d)", d.src0.c, d.src1.c); return SEG_ERR_ARG;
@@ -915,6 +930,7 @@ extern "C" int seg_conv2d(const seg_conv_desc* dp, void* stream) {
   {
     // bf16 3x3 / stride 1 without the fused pool: the wave-specialised kernel (conv_sweep.hip) unless a tile of this file is forced
     int rc = SEG_OK;
+    if (!g_plan_out && seg_conv_ring(d, g_name_out, g_name_cap, reinterpret_cast<hipStream_t>(stream), &rc)) return rc;
     if (!g_plan_out && seg_conv_sweep(d, g_name_out, g_name_cap, reinterpret_cast<hipStream_t>(stream), &rc)) return rc;
   }
   ConvK P;

@@ -19,6 +19,23 @@ int seg_check_launch(const char* what) {
   return SEG_OK;
 }
 extern "C" const char* seg_last_error(void) { return g_err; }
+
+// the kernel this host thread launched last, as spelled at the launch site (parentheses dropped); launch sites that go through a
+// function-pointer variable ("kern": the templated convolution / filter-gradient dispatchers) leave "" -- their instance is
+// reported by seg_conv2d_kernel_name / seg_conv2d_wgrad_kernel_name
+static thread_local char g_kname[160] = "", g_kname_out[160] = "";
+void seg_note_kernel(const char* s) {
+  if (g_kname[0]) return;                           // the FIRST kernel since the last query (a finishing pass does not rename the launch)
+  if (s[0] == 'k' && s[1] == 'e' && s[2] == 'r' && s[3] == 'n' && s[4] == 0) return;
+  int n = 0;
+  for (const char* p = s; *p && n < 159; ++p) if (*p != '(' && *p != ')' && *p != ' ') g_kname[n++] = *p;
+  g_kname[n] = 0;
+}
+extern "C" const char* seg_last_kernel_name(void) {
+  memcpy(g_kname_out, g_kname, sizeof(g_kname));
+  g_kname[0] = 0;
+  return g_kname_out;
+}
 extern "C" int seg_version(void) { return 100; }
 
 namespace {

@@ -136,24 +136,42 @@ class ParamStore(object):
         # one-read re-pack (seg_pack_weights_dual): the forward entries only, 32x32 tiles counted over them, each with the packed
         # offset of its dgrad copy (training stores; an inference store has no dgrad copies and uses the table-driven kernel)
         self.pack_dual = None
+        self._pack_entries = entries
+        self._pack_parts = {}
         if training and entries:
-            fwd, dg, tiles = [], [], 0
-            for i, e in enumerate(entries):
-                if e.mode not in (L.PACK_CONV_FWD, L.PACK_UP_FWD):
-                    continue
-                f = L.PackEntry.from_buffer_copy(e)
-                f.blk_start = tiles
-                tiles += e.n_elems // 1024
-                nxt = entries[i + 1] if i + 1 < len(entries) else None
-                dg.append(nxt.dst_off if nxt is not None and nxt.src_off == e.src_off and nxt.mode in (L.PACK_CONV_DGRAD, L.PACK_UP_DGRAD) else -1)
-                fwd.append(f)
-            self.pack_dual = (torch.frombuffer(bytearray(b''.join(bytes(f) for f in fwd)), dtype=torch.uint8).to(device),
-                              torch.tensor(dg, dtype=torch.int64, device=device), len(fwd), tiles)
+            self.pack_dual = self._dual_table(lambda src_off: True)
         if entries:
             raw = b''.join(bytes(e) for e in entries)
             self.pack_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         else:
             self.pack_table = None
+
+    def _dual_table(self, keep):
+        """seg_pack_weights_dual table over the forward entries whose arena offset passes `keep`: (entries, dgrad offsets, n, tiles)"""
+        entries = self._pack_entries
+        fwd, dg, tiles = [], [], 0
+        for i, e in enumerate(entries):
+            if e.mode not in (L.PACK_CONV_FWD, L.PACK_UP_FWD) or not keep(e.src_off):
+                continue
+            f = L.PackEntry.from_buffer_copy(e)
+            f.blk_start = tiles
+            tiles += e.n_elems // 1024
+            nxt = entries[i + 1] if i + 1 < len(entries) else None
+            dg.append(nxt.dst_off if nxt is not None and nxt.src_off == e.src_off and nxt.mode in (L.PACK_CONV_DGRAD, L.PACK_UP_DGRAD) else -1)
+            fwd.append(f)
+        if not fwd:
+            return None
+        return (torch.frombuffer(bytearray(b''.join(bytes(f) for f in fwd)), dtype=torch.uint8).to(self.device),
+                torch.tensor(dg, dtype=torch.int64, device=self.device), len(fwd), tiles)
+
+    def pack_part(self, names, complement=False):
+        """The re-pack table of a SUBSET of the layers (training stores): the models pack the few filters the first layers of the
+        forward pass need beside the first layer and the bulk afterwards (Net.pack(part=...))."""
+        key = (tuple(sorted(names)), complement)
+        if key not in self._pack_parts:
+            offs = set(self.layers[n].w_off for n in names)
+            self._pack_parts[key] = self._dual_table((lambda o: o not in offs) if complement else (lambda o: o in offs))
+        return self._pack_parts[key]
 
     # ---- host access (tests, snapshots, weight loading) ----
     def packed_ptr(self, off):
@@ -338,6 +356,97 @@ def mark_bucket_main_writers(plan, lo_ptr, hi_ptr):
     return n
 
 
+# SEG_PLAN_C=0: the per-launch Python walk of Plan.run (debugging; bitwise the same launches in the same order)
+_PLAN_C = os.environ.get('SEG_PLAN_C', '1') != '0'
+
+
+class CompiledPlan(object):
+    """A recorded multi-stream walk of a Plan as seg_plan_op records (include/seg_hip.h): replayed by ONE call of seg_plan_run.
+    Launch arguments are marshalled once into seg_arg arrays (Plan.rebind patches them in place); descriptors passed by reference
+    stay the plan's own ctypes objects, so a descriptor field changed on the Python side is seen by the next replay."""
+
+    def __init__(self, plan, rec, nslots, stream, main, side):
+        lib = L.load()
+        self.lib, self.plan, self.nslots = lib, plan, nslots
+        streams, sidx = [stream], {None: 0, id(main): 0}
+        for o_ in side:
+            if id(o_) not in sidx:
+                sidx[id(o_)] = len(streams)
+                streams.append(o_.cuda_stream)
+        self.streams = (C.c_void_p * len(streams))(*streams)
+        self.n = len(rec)
+        self.ops = (L.PlanOp * max(1, self.n))()
+        self.args_of = {}                          # plan op index -> its seg_arg array (Plan.rebind)
+        self.names = []
+        self._keep = []
+        self.main = main
+        for k, r in enumerate(rec):
+            op = self.ops[k]
+            if r[0] == 'L':
+                _, i_, name, fn, args, st, slot = r
+                at = L.SIGNATURES[fn.__name__][:-1]
+                if len(at) != len(args):
+                    raise L.SegError('%s/%s: %d arguments for %s' % (plan.name, name, len(args), fn.__name__))
+                arr = (L.SegArg * max(1, len(args)))()
+                for j, (t, a) in enumerate(zip(at, args)):
+                    self._marshal(arr[j], t, a)
+                fid = lib.seg_plan_fn_id(fn.__name__.encode())
+                if fid < 0:
+                    raise L.SegError('seg_plan_run has no entry point %s' % fn.__name__)
+                op.kind, op.fn, op.stream, op.stream2, op.nargs = L.OP_LAUNCH, fid, sidx[None if st is None else id(st)], 0, len(args)
+                op.signal_slot = slot or 0
+                op.args = arr
+                self.args_of[i_] = (arr, at)
+                self._keep.append(arr)
+                self.names.append(name)
+            elif r[0] == 'F':
+                op.kind, op.stream, op.stream2 = L.OP_EVENT_FORK, sidx[id(r[1])], sidx[id(r[2])]
+                self.names.append('fork')
+            else:
+                op.kind, op.stream, op.signal_slot = L.OP_WAIT_VALUE, sidx[id(r[1])], r[2]
+                self.names.append('wait')
+        self.failed = C.c_int32(-1)
+
+    @staticmethod
+    def _marshal(slot, t, a):
+        if t is C.c_float:
+            slot.f32 = float(a)
+        elif t in (C.c_int32, C.c_int64, C.c_uint64):
+            v = int(a)
+            slot.i = v - (1 << 64) if v >= (1 << 63) else v           # (uint64 values travel as their two's-complement bits)
+        else:                                          # a pointer: raw address, None, byref(ctypes object) or a ctypes array / pointer
+            if a is None:
+                slot.p = None
+            elif isinstance(a, int):
+                slot.p = a
+            else:
+                o_ = getattr(a, '_obj', None)
+                slot.p = C.addressof(o_) if o_ is not None else C.cast(a, C.c_void_p).value
+
+    def patch(self, i, j, value):
+        ent = self.args_of.get(i)
+        if ent is not None:
+            self._marshal(ent[0][j], ent[1][j], value)
+
+    def run(self):
+        sig = _signal_state(self.main) if self.nslots else None
+        base, flag = 0, None
+        if sig is not None:
+            base = sig['n']
+            sig['n'] += self.nslots
+            flag = sig['flag'].data_ptr()
+        rc = self.lib.seg_plan_run(self.ops, self.n, self.streams, len(self.streams), flag, base & 0x7fffffff, C.byref(self.failed))
+        if rc != 0:
+            k = self.failed.value
+            L.check(rc, '%s/%s' % (self.plan.name, self.names[k] if 0 <= k < len(self.names) else '?'))
+
+    def __del__(self):
+        try:
+            self.lib.seg_plan_destroy_events(self.ops, self.n)
+        except Exception:                              # noqa
+            pass
+
+
 class Plan(object):
     """Ordered list of C-ABI launches.  Every entry is (name, fn, args-without-stream)."""
 
@@ -382,17 +491,42 @@ class Plan(object):
                     torch.cuda.synchronize()
             return
         main = torch.cuda.current_stream()
-        fork = _fork
+        capturing = torch.cuda.is_current_stream_capturing()
+        if _PLAN_C and not capturing and join_into is None and on_marker is None:
+            # the whole walk below was recorded once (forks, signal forks, held launches and all) and is replayed by ONE call into
+            # the library (seg_plan_run): ~130 interpreter iterations + ctypes calls per train step become one
+            return self._run_compiled(stream, main, side, tuple(skip), flavor)
+        return self._walk(stream, main, side, skip, flavor, join_into, on_marker, None)
+
+    def _walk(self, stream, main, side, skip, flavor, join_into, on_marker, rec):
+        """The multi-stream walk of run().  rec is None: launches, forks and waits are issued; rec is a list: they are RECORDED as
+        ('L', op index, name, fn, args, stream or None, signal slot) / ('F', src stream, dst stream) / ('W', stream, slot) with
+        signal slots 1 .. K instead of absolute signal numbers (CompiledPlan adds a per-run base) and nothing touches the GPU."""
+        sp = C.c_void_p(stream)
+        recording = rec is not None
+        if recording:
+            def fork(a_, b_):
+                rec.append(('F', a_, b_))
+        else:
+            fork = _fork
         used = {}
         aux = side[-1]                   # dedicated stream for side='aux' ops (weight re-pack), joined by a 'join_aux' marker
         aux_used = False
         main_epoch, forked_at = 0, {}             # launches on the main stream so far; per side stream: the count at its last fork
-        capturing = torch.cuda.is_current_stream_capturing()
+        capturing = (not recording) and torch.cuda.is_current_stream_capturing()
         dirty = set()                             # side streams with launches the main stream has not waited for yet
         sig = _signal_state(main) if (_SIGNAL_ON and not capturing and not _SIGNALS.get('off')) else None
+        nslot = [0]                               # (recording) signal slots handed out so far
         sig_at = {}                               # op index of a main-stream convolution -> the number it has to announce
         held = {}                                 # side stream id -> (op index it waits for, [(name, fn, args)] to launch behind it)
         by_id = {id(o_): o_ for o_ in side}
+
+        def launch(i_, name_, fn_, args_, st_, slot_=None):
+            """st_: a side stream, or None for the main stream"""
+            if recording:
+                rec.append(('L', i_, name_, fn_, args_, st_, slot_))
+                return 0
+            return fn_(*args_, sp if st_ is None else C.c_void_p(st_.cuda_stream))
 
         def next_main_conv(i0):
             """the next op after i0 that will launch on the main stream, if it is a convolution (it can carry a signal)"""
@@ -457,13 +591,14 @@ class Plan(object):
                     join(aux)
                     aux_used = False
                 continue
+            rc = 0
             if tag == 'aux':
                 if capturing or forked_at.get(id(aux)) != main_epoch:
                     fork(main, aux)
                     forked_at[id(aux)] = main_epoch
                 aux_used = True
                 dirty.add(id(aux))
-                rc = fn(*args, C.c_void_p(aux.cuda_stream))
+                rc = launch(i, name, fn, args, aux)
             elif tag:
                 # side stream ids are assigned when the plan is built (Net._add_wgrad alternates 1, 2): a filter
                 # gradient and the reduction of its slabs are then in order on ONE stream
@@ -476,7 +611,7 @@ class Plan(object):
                 # Under stream capture every edge is kept: the captured graph's split into streams depends on them (1.38 against
                 # 1.25 ms without).
                 if id(st) in held:
-                    held[id(st)][1].append((name, fn, args))         # stays in order behind the held launches of its stream
+                    held[id(st)][1].append((i, name, fn, args))      # stays in order behind the held launches of its stream
                     continue
                 if capturing or forked_at.get(id(st)) != main_epoch:
                     j = next_main_conv(i) if sig is not None else None
@@ -485,37 +620,44 @@ class Plan(object):
                         # announces its start -- the waiter is always enqueued behind its signaller, whatever hardware queue
                         # the two streams share, so the wait cannot block the kernel it waits for
                         if j not in sig_at:
-                            sig['n'] += 1
-                            sig_at[j] = sig['n'] & 0x7fffffff
-                        held[id(st)] = (j, [(name, fn, args)])
+                            if recording:
+                                nslot[0] += 1
+                                sig_at[j] = nslot[0]
+                            else:
+                                sig['n'] += 1
+                                sig_at[j] = sig['n'] & 0x7fffffff
+                        held[id(st)] = (j, [(i, name, fn, args)])
                         forked_at[id(st)] = main_epoch
                         dirty.add(id(st))
                         continue
                     fork(main, st)
                     forked_at[id(st)] = main_epoch
                 dirty.add(id(st))
-                rc = fn(*args, C.c_void_p(st.cuda_stream))
+                rc = launch(i, name, fn, args, st)
             else:
                 main_epoch += 1
                 d_ = self.meta[i].get('desc')
                 v = None
                 if isinstance(d_, L.ConvDesc):           # (always rewritten: the descriptor is reused by every run of the plan)
                     v = sig_at.pop(i, None)
-                    d_.signal = sig['flag'].data_ptr() if v is not None else None
-                    d_.signal_value = v or 0
-                rc = fn(*args, sp)
+                    if not recording:
+                        d_.signal = sig['flag'].data_ptr() if v is not None else None
+                        d_.signal_value = v or 0
+                rc = launch(i, name, fn, args, None, v)
                 if v is not None and rc == 0:
                     for sid_, (j, lst) in list(held.items()):
                         if j != i:
                             continue
                         st_ = by_id[sid_]
-                        if sig['hip'].hipStreamWaitValue32(C.c_void_p(st_.cuda_stream), C.c_void_p(sig['flag'].data_ptr()), v, 0, 0xffffffff) != 0:   # 0 = >=
+                        if recording:
+                            rec.append(('W', st_, v))
+                        elif sig['hip'].hipStreamWaitValue32(C.c_void_p(st_.cuda_stream), C.c_void_p(sig['flag'].data_ptr()), v, 0, 0xffffffff) != 0:   # 0 = >=
                             # (a runtime without stream memory operations: an event recorded now orders the held launches just as
                             # well -- op i is already on the main stream -- and later forks of this process use events)
                             _SIGNALS['off'] = True
                             fork(main, st_)
-                        for nm_, f_, a_ in lst:
-                            r_ = f_(*a_, C.c_void_p(st_.cuda_stream))
+                        for i2_, nm_, f_, a_ in lst:
+                            r_ = launch(i2_, nm_, f_, a_, st_)
                             if r_ != 0:
                                 L.check(r_, '%s/%s' % (self.name, nm_))
                         del held[sid_]
@@ -534,9 +676,21 @@ class Plan(object):
             assert not held, 'a signal fork was still pending at the end of a segment'
             for st in used.values():
                 ev = torch.cuda.Event(); ev.record(st); join_into.wait_event(ev)
-            return
+            return nslot[0]
         for st in used.values():
             join(st)
+        return nslot[0]
+
+    def _run_compiled(self, stream, main, side, skip, flavor):
+        cache = self.__dict__.setdefault('_compiled', {})
+        sig_on = bool(_SIGNAL_ON and not _SIGNALS.get('off'))
+        key = (stream, main.device.index, tuple(o_.cuda_stream for o_ in side), skip, flavor, sig_on, len(self.ops))
+        cp = cache.get(key)
+        if cp is None:
+            rec = []
+            nslots = self._walk(stream, main, side, skip, flavor, None, None, rec)
+            cp = cache[key] = CompiledPlan(self, rec, nslots, stream, main, side)
+        cp.run()
 
     def rebind(self, mapping):
         """Replaces raw device pointers among the launch arguments ({old: new}; the network inputs when a device-resident
@@ -565,6 +719,8 @@ class Plan(object):
                 i, j = site
                 name, fn, args = self.ops[i]
                 self.ops[i] = (name, fn, args[:j] + (new,) + args[j + 1:])
+                for cp in self.__dict__.get('_compiled', {}).values():
+                    cp.patch(i, j, new)
                 n += 1
             sites[new] = where
         return n
@@ -574,6 +730,7 @@ class Plan(object):
 
     def extend(self, other):
         self.__dict__.pop('_ptr_sites', None)
+        self.__dict__.pop('_compiled', None)
         self.ops += other.ops; self.meta += other.meta; self.keep += other.keep; self.flops += other.flops
 
     def kernel_name(self, i):
@@ -596,6 +753,8 @@ class Plan(object):
         main = torch_mod.cuda.current_stream()
         E_ = lambda: torch_mod.cuda.Event(enable_timing=True)
         recs = []
+        lib_ = L.load()
+        launched = {}                              # op index -> the kernel its launch site named (seg_last_kernel_name)
         used, aux_used = {}, False
         aux = side[-1] if side else None
         for i, (name, fn, args) in enumerate(self.ops):
@@ -626,9 +785,11 @@ class Plan(object):
             d_ = self.meta[i].get('desc')
             if isinstance(d_, L.ConvDesc):
                 d_.signal = None                          # (forks are events here)
+            lib_.seg_last_kernel_name()                 # (clears: the next answer is the first kernel of THIS launch)
             rc = fn(*args, C.c_void_p(st.cuda_stream) if st is not main else sp)
             if rc != 0:
                 L.check(rc, '%s/%s' % (self.name, name))
+            launched[i] = lib_.seg_last_kernel_name().decode()
             e1.record(st)
             recs.append((i, e0, e1))
         if side and aux_used:
@@ -636,7 +797,10 @@ class Plan(object):
         for st in used.values():
             ev = torch_mod.cuda.Event(); ev.record(st); main.wait_event(ev)
         torch_mod.cuda.synchronize()
-        return [(self.ops[i][0], self.kernel_name(i), e0.elapsed_time(e1), self.meta[i].get('flops', 0), self.meta[i].get('bytes', 0)) for i, e0, e1 in recs]
+        # kernel names: what the launch itself reported (first layer, pools ...: the C side picks the instance), the descriptor query
+        # for the templated convolution / filter-gradient dispatchers (they launch through a function-pointer variable)
+        return [(self.ops[i][0], launched.get(i) or self.kernel_name(i), e0.elapsed_time(e1), self.meta[i].get('flops', 0), self.meta[i].get('bytes', 0))
+                for i, e0, e1 in recs]
 
 
 class Net(object):
@@ -1635,15 +1799,29 @@ class Net(object):
         plan.keep.append(lv)
         plan.add('sigmoid_argmax', self.lib.seg_sigmoid_argmax, C.byref(lv), self.B, H, W, n_classes, sig.data_ptr(), out.data_ptr(), kernel='sigmoid_argmax_kernel')
 
-    def pack(self, plan, aux=False):
+    def pack(self, plan, aux=False, part=None, side=None):
         """Re-packs the fp32 master weights into the MFMA operand layout.  aux=True: on the auxiliary stream (the
-        training forward starts with it, overlapped with the first layer, which reads the fp32 arena directly)."""
+        training forward starts with it, overlapped with the first layer, which reads the fp32 arena directly).
+        part = (layer names, complement): only those layers (or all the others) -- training stores; side: a filter-gradient stream
+        instead of the main / auxiliary one."""
         s = self.store
         if s.pack_table is None:
             return
         meta = {'kernel': 'pack_kernel'}
         if aux:
             meta['side'] = 'aux'
+        if side:
+            meta['side'] = side
+        if part is not None:
+            t = s.pack_part(part[0], part[1])
+            if t is None:
+                return
+            tab, dg, ne, tiles = t
+            plan.keep += [tab, dg]
+            meta['kernel'] = 'pack_dual_kernel'
+            plan.add('pack' + ('/rest' if part[1] else '/first'), self.lib.seg_pack_weights_dual, s.p.data_ptr(), s.packed.data_ptr(), tab.data_ptr(),
+                     dg.data_ptr(), ne, tiles, self.dtype, **meta)
+            return
         if getattr(s, 'pack_dual', None) is not None:
             # training stores: both packed copies of a tile from ONE read of the arena
             tab, dg, ne, tiles = s.pack_dual

@@ -124,7 +124,13 @@ class UNetModel(BaseModel):
         return self.fwd_plan
 
     # ---- forward graph (shared by training and inference builders) ----
-    def _emit_forward(self, net, plan, x_in, H, W, crop_aware, dropout=None, after_first=None, head=True):
+    # the layers whose packed filters the forward pass needs before conv4_1: re-packed beside conv1_1; everything else (96 % of the
+    # bytes) is re-packed on a filter-gradient stream (idle in the forward pass) AFTER conv1_1, beside conv2_1 .. conv3_2 -- the
+    # first layer is HBM-bound and ran at half its stand-alone rate while the whole re-pack shared the memory with it (49.9 us in
+    # the C2 step against 23)
+    PACK_FIRST = ('conv1_2', 'conv2_1', 'conv2_2', 'conv3_1', 'conv3_2')
+
+    def _emit_forward(self, net, plan, x_in, H, W, crop_aware, dropout=None, after_first=None, head=True, split_pack=False):
         nk, Ly = self.n_kernels, self.store.layers
         if H != W:
             # the reference crops every skip with a SQUARE target taken from the height (models/unet.py:139-140,146-147):
@@ -138,6 +144,8 @@ class UNetModel(BaseModel):
         if after_first is not None:
             after_first()
         net.join_aux(plan)                 # packed weights (re-packed on the aux stream in training) are needed from here on
+        if split_pack:
+            net.pack(plan, part=(self.PACK_FIRST, True), side=2)      # the bulk: starts when conv2_1 starts, joined in front of conv4_1
         # conv1_2: only its centre window survives the crop of the last skip
         t4h, t4w = sh['upconv4'], sw['upconv4']
         o4h, o4w = (sh['conv1_2'] - t4h) // 2, (sw['conv1_2'] - t4w) // 2
@@ -161,6 +169,8 @@ class UNetModel(BaseModel):
             if not pooled:
                 net.pool_fwd(plan, prev, P, P.H, P.W)
             c1, c2 = 'conv%d_1' % i, 'conv%d_2' % i
+            if split_pack and i == 4:
+                net.join_wgrad(plan)         # the rest of the packed filters
             A[c1] = net.act(sh[c1], sw[c1], Ly[c1].cout, name=c1)
             net.conv_fwd(plan, Ly[c1], [(P, 0, 0)], P.H, P.W, A[c1])
             A[c2] = net.act(sh[c2], sw[c2], Ly[c2].cout, name=c2)
@@ -219,13 +229,17 @@ class UNetModel(BaseModel):
         fwd = self.fwd_plan = E.Plan('fwd')
         self.loss_buf = self.store.loss_slot()          # (behind the gradient arena: reduced with the last bucket under data parallelism)
         net.step_begin(fwd, self.loss_buf)     # aux stream: global_step += 1, loss accumulator = 0
-        net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1_1
+        split_pack = self._side is not None and len(self._side) >= 2 and os.environ.get('SEG_SPLIT_PACK', '1') != '0'
+        if split_pack:
+            net.pack(fwd, aux=True, part=(self.PACK_FIRST, False))
+        else:
+            net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1_1
         cols = []       # im2col of the input for conv1_1's filter gradient: side stream, right after conv1_1 (both are
         #                 bandwidth-bound), overlapping the rest of the forward pass
         fuse_head = (E.rup(Ly['output'].cin) in (32, 64) and self.n_classes <= 32 and os.environ.get('SEG_FUSE_HEAD', '1') != '0' and
                      not self.adversarial_training)     # (the adversary adds its term to dlogits before the output layer's backward)
         A, sh, sw, skip_off, o4 = self._emit_forward(net, fwd, self.input_x, H, W, self.crop_aware, head=not fuse_head,
-                                                     after_first=lambda: cols.append(net.first_im2col(fwd, Ly['conv1_1'], self.input_x, H, W)))
+                                                     after_first=lambda: cols.append(net.first_im2col(fwd, Ly['conv1_1'], self.input_x, H, W)), split_pack=split_pack)
         col = cols[0]
         self.acts = A
         oh, ow = sh['output'], sw['output']

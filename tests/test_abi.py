@@ -26,25 +26,50 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 18
     for n in names:
         assert hasattr(lib, n), n
-    bound = set(_lib.SIGNATURES) | {'seg_last_error', 'seg_version', 'seg_bn_ws_bytes', 'seg_dconv_wgrad_ws_bytes', 'seg_bilinear_up_bwd_ws_bytes',
+    bound = set(_lib.SIGNATURES) | {'seg_last_error', 'seg_version', 'seg_last_kernel_name', 'seg_plan_fn_id', 'seg_plan_run', 'seg_plan_destroy_events', 'seg_bn_ws_bytes', 'seg_dconv_wgrad_ws_bytes', 'seg_bilinear_up_bwd_ws_bytes',
              'seg_head_xent_ws_bytes', 'seg_bias_grad_ws_bytes', 'seg_conv_first_gen_rows', 'seg_thin_up2x2_rows', 'seg_thin_wgrad3x3_ws_bytes', 'seg_conv_first_gen_wgrad_ws_bytes'}
     assert bound == set(names)
     assert _lib.load().seg_version() == 100
 
 
+def test_plan_thunks_are_up_to_date_and_cover_every_launcher():
+    """csrc/plan_thunks.inc is generated from _lib.SIGNATURES (segmentation_amd/_gen_thunks.py): the committed file must be what the
+    generator writes today, and seg_plan_fn_id must know every launching entry point."""
+    from segmentation_amd import _gen_thunks as G, _lib
+    assert open(G.OUT).read() == G.render(), 'run python -m segmentation_amd._gen_thunks'
+    lib = _lib.load()
+    names = [n for n, _ in G.launchers()]
+    assert len(names) >= 55 and 'seg_conv2d' in names and 'seg_adam' in names
+    ids = [lib.seg_plan_fn_id(n.encode()) for n in names]
+    assert sorted(ids) == list(range(len(names)))
+    assert lib.seg_plan_fn_id(b'seg_conv2d_kernel_name') == -1 and lib.seg_plan_fn_id(b'nope') == -1
+    # argument checks without a GPU: a launch op whose argument count does not match its entry point is refused
+    a = (_lib.SegArg * 2)()
+    op = (_lib.PlanOp * 1)()
+    op[0].kind = _lib.OP_LAUNCH; op[0].fn = lib.seg_plan_fn_id(b'seg_adam'); op[0].stream = 0; op[0].nargs = 2; op[0].args = a
+    st = (ctypes.c_void_p * 1)(None)
+    bad = ctypes.c_int32(-5)
+    assert lib.seg_plan_run(op, 1, st, 1, None, 0, ctypes.byref(bad)) == -1 and bad.value == 0
+    assert b'takes 11 arguments' in lib.seg_last_error()
+    assert lib.seg_plan_run(op, 0, st, 1, None, 0, ctypes.byref(bad)) == 0
+
+
 def test_ctypes_struct_layouts_match_c(tmp_path):
     from segmentation_amd import _lib
     src = tmp_path / 's.c'
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "seg_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "seg_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(seg_view),sizeof(seg_conv_desc),sizeof(seg_wgrad_desc),sizeof(seg_pack_entry),'
                    'offsetof(seg_conv_desc,dst),offsetof(seg_conv_desc,cfg),offsetof(seg_wgrad_desc,dw),'
-                   'sizeof(seg_dconv_desc),offsetof(seg_dconv_desc,w),offsetof(seg_dconv_desc,mask));return 0;}')
+                   'sizeof(seg_dconv_desc),offsetof(seg_dconv_desc,w),offsetof(seg_dconv_desc,mask),sizeof(seg_arg),sizeof(seg_plan_op),'
+                   'offsetof(seg_plan_op,args),offsetof(seg_plan_op,event),offsetof(seg_conv_desc,signal),offsetof(seg_conv_desc,signal_value));return 0;}')
     exe = tmp_path / 's'
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     got = list(map(int, subprocess.check_output([str(exe)]).split()))
     want = [ctypes.sizeof(_lib.View), ctypes.sizeof(_lib.ConvDesc), ctypes.sizeof(_lib.WgradDesc), ctypes.sizeof(_lib.PackEntry),
             _lib.ConvDesc.dst.offset, _lib.ConvDesc.cfg.offset, _lib.WgradDesc.dw.offset,
-            ctypes.sizeof(_lib.DconvDesc), _lib.DconvDesc.w.offset, _lib.DconvDesc.mask.offset]
+            ctypes.sizeof(_lib.DconvDesc), _lib.DconvDesc.w.offset, _lib.DconvDesc.mask.offset,
+            ctypes.sizeof(_lib.SegArg), ctypes.sizeof(_lib.PlanOp), _lib.PlanOp.args.offset, _lib.PlanOp.event.offset,
+            _lib.ConvDesc.signal.offset, _lib.ConvDesc.signal_value.offset]
     assert got == want
 
 

@@ -50,6 +50,22 @@ def _rand_params(layer, rng, dtype):
     (3, 'VALID', [32], 128, 26, 26, 2, True, 106),       # 24 x 24 output maps: 12 x 24 windows
     (3, 'VALID', [16], 24, 11, 11, 1, True, 102),        # unpadded channel counts
     (3, 'VALID', [256], 256, 12, 12, 3, True, 0),        # automatic tile class on a deep layer
+    # the round-4 kernel (csrc/conv_ring.hip; bf16, 64-channel blocks): cfg 208 = 512-pixel tiles, 204 = 256-pixel tiles; the
+    # data gradients of these cases run on it too where they have 64-channel blocks (two-destination form: [64, 64])
+    (3, 'VALID', [64, 64], 64, 35, 37, 2, True, 208),
+    (3, 'VALID', [64, 64], 64, 35, 37, 2, True, 204),
+    (3, 'SAME', [64], 128, 19, 33, 3, True, 208),        # zero padding on every side, ragged tiles
+    (3, 'SAME', [128], 64, 9, 11, 2, False, 204),
+    (3, 'VALID', [32], 128, 26, 26, 2, True, 208),
+    (3, 'VALID', [64], 64, 150, 131, 4, True, 204),      # more tiles than compute units: the persistent walk + tile tickets
+    (3, 'SAME', [32, 32], 64, 97, 140, 3, True, 208),
+    (3, 'VALID', [64], 128, 70, 200, 2, True, 208),      # wide maps: the 8 x 64 tile shape
+    (3, 'VALID', [192], 64, 10, 10, 5, True, 204),       # 8 x 8 maps: most of a tile is padding
+    (3, 'VALID', [64, 64], 64, 35, 37, 2, True, 209),    # 209 = 4 waves x 8 rows (512-pixel tiles, one wave per SIMD)
+    (3, 'SAME', [64], 128, 19, 33, 3, True, 209),
+    (3, 'VALID', [64], 64, 150, 131, 4, True, 209),
+    (3, 'SAME', [32, 32], 64, 97, 140, 3, True, 209),
+    (3, 'VALID', [64], 128, 70, 200, 2, True, 209),
     (3, 'VALID', [32], 64, 150, 131, 4, True, 102),      # more tiles than compute units: the persistent walk + tile tickets
     (3, 'SAME', [32, 32], 64, 97, 140, 3, True, 104),
     (3, 'VALID', [64], 128, 120, 123, 2, True, 106),
@@ -79,7 +95,9 @@ def test_conv_fwd_bwd(dtype, case):
     out = net.act(Ho, Wo, cout)
     plan = E.Plan('t')
     net.conv_fwd(plan, layer, srcs, H, W, out, cfg=cfg)
-    if cfg >= 100:
+    if cfg in (204, 208, 209):
+        assert plan.kernel_name(0).startswith('conv_ring_kernel<%s,' % {204: '8,4,2,2', 208: '8,4,1,4', 209: '4,8,1,4'}[cfg]), plan.kernel_name(0)
+    elif cfg >= 100:
         assert plan.kernel_name(0).startswith('conv_sweep_kernel<%d,' % (cfg - 100)), plan.kernel_name(0)
     plan.run(U.stream()); U.sync()
     ref = ops.conv2d(x, p['c']['weights'], p['c']['biases'], padding, 1, relu)
@@ -396,8 +414,10 @@ def test_wgrad_sweep(case):
     assert torch.equal(g1, store.g), name
 
 
-@pytest.mark.parametrize('cin,cout,H,W,padding', [(64, 64, 23, 37, 'VALID'), (32, 32, 34, 34, 'SAME'), (128, 96, 19, 50, 'VALID')])
-def test_conv_with_fused_maxpool(cin, cout, H, W, padding):
+@pytest.mark.parametrize('cin,cout,H,W,padding,cfg', [(64, 64, 23, 37, 'VALID', 0), (32, 32, 34, 34, 'SAME', 0), (128, 96, 19, 50, 'VALID', 0),
+                                                       (64, 64, 23, 37, 'VALID', 208), (128, 128, 34, 70, 'SAME', 204), (32, 64, 61, 59, 'VALID', 208),
+                                                       (64, 128, 45, 70, 'VALID', 209), (32, 64, 61, 59, 'SAME', 209)])
+def test_conv_with_fused_maxpool(cin, cout, H, W, padding, cfg):
     """seg_conv_desc.pool: same activation bits as the plain launch, pooled map == 2x2 max-pool of those bits."""
     dtype = L.SEG_BF16
     rng = np.random.default_rng(cin + H)
@@ -411,9 +431,11 @@ def test_conv_with_fused_maxpool(cin, cout, H, W, padding):
     Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
     y0 = net.act(Ho, Wo, cout); y1 = net.act(Ho, Wo, cout); pooled = net.act(Ho // 2, Wo // 2, cout)
     plan = E.Plan('t')
-    net.conv_fwd(plan, layer, [(x, 0, 0)], H, W, y0)
-    net.conv_fwd(plan, layer, [(x, 0, 0)], H, W, y1, pool=pooled)
+    net.conv_fwd(plan, layer, [(x, 0, 0)], H, W, y0, cfg=cfg)          # (the same kernel: another one sums the taps in another order)
+    net.conv_fwd(plan, layer, [(x, 0, 0)], H, W, y1, pool=pooled, cfg=cfg)
     assert net.pool_fused and plan.ops[-1][0] == 'c+pool'
+    if cfg:
+        assert plan.kernel_name(1).startswith('conv_ring_kernel<') and plan.kernel_name(1).endswith('true>'), plan.kernel_name(1)
     plan.run(U.stream()); U.sync()
     assert torch.equal(y0.t, y1.t)
     o = y0.t.to(torch.float32)[:, :Ho // 2 * 2, :Wo // 2 * 2]

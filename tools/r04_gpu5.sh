@@ -1,0 +1,9 @@
+cd $GRAFT_REPO_ROOT
+timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "conv_fwd_bwd or fused_maxpool" > gpurun_out/r04_tests2.log 2>&1; echo "tests rc $?" >> gpurun_out/r04_tests2.log
+tail -3 gpurun_out/r04_tests2.log
+grep -q "tests rc 0" gpurun_out/r04_tests2.log || exit 1
+timeout -k 10 300 python tools/conv_micro2.py --size 512 --cfgs 0,208,204,209 --layers conv2_1,conv2_2,conv3_1,conv3_2,conv4_1,conv4_2,conv5_2,conv6_1,conv7_1,conv8_1,conv8_2 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_ring_micro512.txt; cat gpurun_out/r04_ring_micro512.txt
+timeout -k 10 300 python tools/conv_micro2.py --size 256 --cfgs 0,208,204,209 --layers conv2_1,conv2_2,conv3_1,conv3_2,conv4_2 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_ring_micro256.txt; cat gpurun_out/r04_ring_micro256.txt
+( echo "=== full"; timeout -k 10 200 python tools/stamp_ring.py 58,256,256,16,208 58,256,256,16,204 58,256,256,16,209 123,128,128,16,209
+for f in "" "-DSEG_RING_NOREAD" "-DSEG_RING_NOMMA"; do echo "=== flags '$f' SEG_RING_ABL=3 (no fills)"; STAMP_FLAGS="$f" SEG_RING_ABL=3 timeout -k 10 200 python tools/stamp_ring.py 58,256,256,16,208 58,256,256,16,209; done ) 2>&1 | grep -v "amdgpu.ids\|wg 128\|wg 255\|warning\|note:\|asm volatile\|\^" > gpurun_out/r04_ring_ablate2.txt
+cut -c1-330 gpurun_out/r04_ring_ablate2.txt
