@@ -1046,14 +1046,26 @@ extern "C" int seg_conv2d_wgrad(const seg_wgrad_desc* dp, void* stream) {
       d.dz.oy + d.Ho > d.dz.H || d.dz.ox + d.Wo > d.dz.W || (!tz && d.dz.coff + d.dz.c > d.dz.cs)) {
     seg_set_error("wgrad: window exceeds its buffer"); return SEG_ERR_ARG;
   }
+  // 3x3 layers whose INPUT comes in 32-channel chunks (the U-Net's conv1_2, conv2_1, conv9_1 [32 | 32], conv9_2): the register-staged
+  // walk of this file with the 32 ci x 32 co layout -- 16 x 16 pixel tiles on big maps, 8 x 16 on small ones.  The wave-specialised
+  // walk owns 16 ci x 16 co per wave there and is bound by its loader waves (one window of x and dZ per 36 MFMAs): measured
+  // stand-alone at 512^2 (profiles/r04_wgrad32_micro.txt) conv9_1 205 -> 114 us, conv9_2 / conv1_2 101 -> 62, conv2_1 93 -> 80; at
+  // 256^2 with the in-step 64-workgroup target conv2_1 52 -> 38, conv9_1 28 -> 21, the 32 -> 32 layers level.
+  seg_wgrad_desc d32;
+  const seg_wgrad_desc* dq = dp;
+  if (d.dtype == SEG_BF16 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.cfg == 0 && !d.im2col_x && !d.pool_y.ptr && !d.thin &&
+      (d.src0.c % 64 != 0 || (d.src1.ptr && d.src1.c % 64 != 0))) {
+    d32 = d; d32.cfg = (int64_t)d.Ho * d.Wo >= 160 * 160 ? 9 : 3; dq = &d32;
+  }
+  const seg_wgrad_desc& de = *dq;
   {
     // bf16 3x3 / stride 1: the wave-specialised walk (wgrad_sweep.hip) unless the caller asks for a layout of this file (cfg 1..99)
     WgQuery q; q.name_out = g_wname_out; q.name_cap = g_wname_cap; q.plan_ks = g_plan_ks; q.plan_bytes = g_plan_bytes; q.job_out = g_job_out;
     int rc = SEG_OK;
-    if (seg_wgrad_sweep(d, q, reinterpret_cast<hipStream_t>(stream), &rc)) return rc;
+    if (seg_wgrad_sweep(de, q, reinterpret_cast<hipStream_t>(stream), &rc)) return rc;
   }
   WgK P;
-  P.d = d;
+  P.d = de;
   if (!d.src1.ptr) { P.d.src1 = d.src0; P.d.src1.c = 0; P.d.src1_clog = 0; }
   P.nchunks0 = P.nchunks = 0;                     // set by launch_cfg from its channel tile
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

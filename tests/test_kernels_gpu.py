@@ -364,12 +364,14 @@ def test_wgrad_layouts(case):
     ('VALID', [256], 256, 10, 10, 5, 291, 1),
     ('VALID', [128], 192, 12, 12, 3, 230, 1),           # whole 10 x 10 maps as windows (100 pixels -> 4 K steps)
     ('VALID', [128], 128, 16, 16, 2, 211, 1),           # 14 x 14 = 196 pixels: one window per image at 7 K steps
-    ('VALID', [32], 64, 37, 35, 3, 0, 0),               # 32 ci x 64 co
-    ('VALID', [96], 32, 19, 23, 2, 0, 0),               # 32-channel layouts on unpadded / ragged channel counts
-    ('SAME', [32, 32], 64, 33, 17, 2, 0, 3),
+    ('VALID', [32], 64, 37, 35, 3, 211, 0),             # 32 ci x 64 co (forced: by default inputs in 32-channel chunks run on the register-staged kernel, r04)
+    ('VALID', [96], 32, 19, 23, 2, 211, 0),             # 32-channel layouts on unpadded / ragged channel counts
+    ('SAME', [32, 32], 64, 33, 17, 2, 211, 3),
     ('VALID', [64], 32, 41, 23, 2, 0, 0),               # 64 ci x 32 co
-    ('VALID', [32], 32, 41, 23, 2, 0, 4),               # 32 x 32
-    ('VALID', [48, 16], 40, 21, 19, 2, 0, 0),           # unpadded channel counts
+    ('VALID', [32], 32, 41, 23, 2, 211, 4),             # 32 x 32
+    ('VALID', [48, 16], 40, 21, 19, 2, 211, 0),         # unpadded channel counts
+    ('VALID', [32], 64, 37, 35, 3, 0, 0),               # ... and the default route of such layers: conv_wgrad_kernel, 8 x 16 tiles
+    ('SAME', [32, 32], 32, 170, 165, 2, 0, 0),          # ... 16 x 16 tiles on big maps
     ('VALID', [64], 64, 37, 35, 3, 0, 0),               # automatic choice
     ('VALID', [512], 512, 10, 10, 4, 0, 0),             # automatic choice on a bottleneck layer
 ])
@@ -399,7 +401,10 @@ def test_wgrad_sweep(case):
     net.conv_bwd(bplan, layer, srcs, H, W, dz, [None] * len(segs), wcfg=wcfg, ksplit=ksplit)
     net.flush_reduce(bplan)
     name = bplan.kernel_name(0)
-    assert name.startswith('wgrad_sweep_kernel<'), name
+    if wcfg == 0 and any(E.rup(c) % 64 for c in segs):
+        assert name.startswith('conv_wgrad_kernel<bf16,%s,3,3,1,2,2,1,1,' % ('16,16' if Ho * Wo >= 160 * 160 else '8,16')), name
+    else:
+        assert name.startswith('wgrad_sweep_kernel<'), name
     if wcfg >= 200:
         nu_nv = {1: ',3,3,', 3: ',1,3,', 9: ',1,1,'}[(wcfg - 200) // 10]
         assert nu_nv in name and name.endswith(',4,192>' if wcfg % 10 == 0 else ',8,352>'), name

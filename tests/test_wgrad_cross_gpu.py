@@ -21,7 +21,7 @@ from test_configs_gpu import _data, _unet, _record
 
 pytestmark = pytest.mark.gpu
 
-# measured on MI355X (r04, gpurun_out/parity_measured.jsonl): worst rel-L2 over the layers 2.4e-7 (C2) / 4.6e-7 (C4 shard)
+# measured on MI355X (r04, profiles/r04_parity_measured.jsonl): worst rel-L2 over the layers 5.8e-7 (C2) / 1.1e-6 (C4 shard)
 REL_L2 = 1e-5
 REL_MAX = 1e-4
 
@@ -50,7 +50,7 @@ def _cross_check(m, tag):
             buf = C.create_string_buffer(200)
             L.check(lib.seg_conv2d_wgrad_kernel_name(C.byref(d), buf, 200), 'name')
             kname = buf.value.decode()
-            if kname.startswith('wgrad_sweep_kernel'):
+            if kname.startswith(('wgrad_sweep_kernel', 'conv_wgrad_kernel<bf16')):      # (r04: inputs in 32-channel chunks run on the register-staged kernel)
                 f = L.WgradDesc.from_buffer_copy(d)
                 for fld in ('src0', 'src1', 'dz'):
                     v = getattr(f, fld)
