@@ -526,6 +526,9 @@ int seg_version(void);
  * templated convolution / filter-gradient dispatchers are queried with seg_conv2d_kernel_name / seg_conv2d_wgrad_kernel_name).
  * bench.py labels launches whose instance the C side picks (first layer, thresholds) with what actually ran. */
 const char* seg_last_kernel_name(void);
+/* The library reads its environment switches (SEG_FIRST_IMPL, SEG_CONV_MODE, SEG_CONV_IMPL, SEG_WGRAD_WGS ...) once; this makes the
+ * next use re-read those that go through the cache (a test hook: the first-layer test flips SEG_FIRST_IMPL between launches). */
+void seg_dbg_reload_env(void);
 
 /* ---- A whole launch plan from one host call (models/basemodel.py:480-489 train_step body; :527-531 infer) -----------------
  * The host side compiles the launches of a train step / forward pass once into an array of seg_plan_op -- the entry point of each
@@ -551,6 +554,7 @@ typedef struct seg_plan_op {
 int seg_plan_fn_id(const char* name);
 int seg_plan_run(seg_plan_op* ops, int32_t n, void* const* streams, int32_t n_streams, uint32_t* signal_flag, uint32_t signal_base,
                  int32_t* failed_op);
+/* Hands the fork events of a plan that is going away back to the library's pool (no HIP call: safe from a finaliser at any time). */
 int seg_plan_destroy_events(seg_plan_op* ops, int32_t n);
 
 #ifdef __cplusplus

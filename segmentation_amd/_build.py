@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['conv_fwd.hip', 'conv_sweep.hip', 'conv_ring.hip', 'conv_wgrad.hip', 'wgrad_sweep.hip', 'conv_first.hip', 'elementwise.hip', 'deconv_ops.hip', 'adv_ops.hip', 'plan_run.hip']
+SOURCES = ['conv_fwd.hip', 'conv_ring.hip', 'conv_wgrad.hip', 'wgrad_sweep.hip', 'conv_first.hip', 'elementwise.hip', 'deconv_ops.hip', 'adv_ops.hip', 'plan_run.hip']
 LIB = os.path.join(HERE, 'libseg_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-result'] + os.environ.get('SEG_EXTRA_FLAGS', '').split()

@@ -171,6 +171,8 @@ def load():
     lib.seg_last_error.argtypes = []
     lib.seg_version.restype = C.c_int
     lib.seg_version.argtypes = []
+    lib.seg_dbg_reload_env.restype = None
+    lib.seg_dbg_reload_env.argtypes = []
     lib.seg_last_kernel_name.restype = C.c_char_p
     lib.seg_last_kernel_name.argtypes = []
     lib.seg_plan_fn_id.restype = C.c_int

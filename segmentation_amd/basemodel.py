@@ -21,6 +21,34 @@ from . import engine as E
 from . import dist as D
 
 
+_GRAPH_WARM = set()
+
+
+def _warm_graph_runtime(device):
+    """First hipGraph capture / instantiate / launch of the process on a QUIET runtime.  A model's own first capture can happen while
+    loader / prefetcher threads are issuing copies and event calls: on ROCm 7.2 the first graph launch of a process under such
+    traffic segfaulted inside hipGraphLaunch whenever no earlier graph had been launched (reproducible in the round-3 tree with
+    `pytest -k "dp or extras or unet"`, where test_device_prefetcher_feeds_identical_batches is the process's first capture; the
+    full suite captured earlier and passed).  Models are built before their datasets' threads start, so a trivial graph replayed here
+    does the runtime's lazy set-up single-threaded."""
+    key = device.index if device is not None and device.type == 'cuda' else None
+    if key in _GRAPH_WARM or not torch.cuda.is_available():
+        return
+    _GRAPH_WARM.add(key)
+    with torch.cuda.device(device):
+        t = torch.zeros(64, device=device)
+        st = torch.cuda.Stream(device)
+        st.wait_stream(torch.cuda.current_stream(device))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(st):
+            t.add_(1.0)                                # (eager once: allocator / kernel load)
+            with torch.cuda.graph(g, stream=st, capture_error_mode='thread_local'):
+                t.add_(1.0)
+        torch.cuda.current_stream(device).wait_stream(st)
+        g.replay()
+        torch.cuda.synchronize(device)
+
+
 class BaseModel(object):
     SHARE_AUX_STREAM = True      # single-GPU builds: the auxiliary launches share a filter-gradient stream (see __init__)
 
@@ -94,6 +122,8 @@ class BaseModel(object):
         self.dtype_name = dtype
         self.dtype = {'bf16': L.SEG_BF16, 'f32': L.SEG_F32, 'fp32': L.SEG_F32}[dtype]
         self.use_graph = use_graph
+        if use_graph:
+            _warm_graph_runtime(self.device)
         self.crop_aware = crop_aware
         self.seed = seed
         self.dp_cuts = dp_cuts                   # gradient-bucket boundaries (layer names, backward order); None = model default
@@ -104,9 +134,8 @@ class BaseModel(object):
         # side streams: wgrad_streams for the filter gradients + one auxiliary (weight re-pack)
         if wgrad_streams > 0 and os.environ.get('SEG_WGRAD_STREAMS'):
             wgrad_streams = max(1, int(os.environ['SEG_WGRAD_STREAMS']))
-        sp_ = int(os.environ.get('SEG_SIDE_PRIO', '0'))      # (experiment: stream priority of the side streams; 0 = normal)
-        self._side = [torch.cuda.Stream(self.device, priority=sp_) for _ in range(wgrad_streams + 1)] if wgrad_streams > 0 else None
-        share = os.environ.get('SEG_SHARE_AUX', '1' if (self.SHARE_AUX_STREAM and not self.pg.enabled) else '0') == '1'
+        self._side = [torch.cuda.Stream(self.device) for _ in range(wgrad_streams + 1)] if wgrad_streams > 0 else None
+        share = os.environ.get('SEG_SHARE_AUX', '1' if (self.SHARE_AUX_STREAM and not self.pg.tuned) else '0') == '1'
         if self._side is not None and share:
             # the auxiliary launches (step_begin, the weight re-pack beside the first layer) go onto a filter-gradient
             # stream, idle at that time: main + two side streams instead of four streams is 2.7 % faster at C2 (1.010 -> 0.983 ms
@@ -114,12 +143,8 @@ class BaseModel(object):
             # Data-parallel builds keep the stream of their own: sharing it beside RCCL's stream measured 1.32 against 1.07 ms; so
             # does the FCN (SHARE_AUX_STREAM = False: 0.824 against 0.817 ms at C3).
             self._side[-1] = self._side[0]
-        if self._side is not None and self.pg.enabled and os.environ.get('SEG_DP_SHARE_AUX', '0') == '1':
-            # (experiment, off: the auxiliary work on the first filter-gradient stream, one stream fewer beside RCCL's -- 1.32 ms
-            # against 1.07 with its own stream at world 1; what did matter was NOT creating a communication stream of our own: the
-            # collectives are issued from a side stream, and asking for more hardware queues, GPU_MAX_HW_QUEUES = 6 / 8, is far
-            # worse: 1.46 / 2.6 ms -- profiles/r03_dp_overhead.txt)
-            self._side[-1] = self._side[-2]          # (the last one: the first carries the FCN's input im2col at the start of forward)
+        # (data-parallel builds keep an auxiliary stream of their own beside RCCL's: sharing it measured 1.32 against 1.07 ms at world 1;
+        # asking for more hardware queues, GPU_MAX_HW_QUEUES = 6 / 8, is far worse: 1.46 / 2.6 ms -- profiles/r03_dp_overhead.txt)
         self._packed_dirty = False
         self._infer_cache = {}
         self.sess = sess
@@ -311,8 +336,7 @@ class BaseModel(object):
         """One optimisation step (intended body of models/basemodel.py:477-489)."""
         if self.mode == 'INFERENCE':
             raise Exception('train_step() with INFERENCE mode invalid')
-        if (not self.use_graph and self._side is not None and os.environ.get('SEG_HIPRIO', '1') != '0' and
-                (not self.pg.enabled or os.environ.get('SEG_DP_HIPRIO', '0') == '1')):
+        if not self.use_graph and self._side is not None and not self.pg.tuned:      # (beside RCCL's stream a high-priority stream measured 2.6x slower)
             # Eager launches: the critical path (forward, dgrads, pools, Adam) runs on a HIGH-priority HIP stream, the filter
             # gradients stay on normal-priority side streams and fill what it leaves (+2 % measured; a captured graph
             # ignores stream priorities).  The high-priority stream BECOMES the thread's current stream (ordered after
@@ -361,7 +385,7 @@ class BaseModel(object):
         own = (self.input_x.data_ptr(), self.input_y.data_ptr())
         if not hasattr(self, '_bound'):
             self._bound, self._slots = own, {}
-        if hasattr(dataset, 'get_device_batch') and os.environ.get('SEG_ZERO_COPY', '1') != '0':
+        if hasattr(dataset, 'get_device_batch'):
             x, y = dataset.get_device_batch()
             ok = (x.dtype == torch.float32 and y.dtype == torch.uint8 and x.is_contiguous() and y.is_contiguous() and
                   x.numel() == self.input_x.numel() and y.numel() == self.input_y.numel() and x.device == self.input_x.device)
@@ -382,7 +406,7 @@ class BaseModel(object):
         probe (a list): instrumented step -- an event after the last backward segment and one behind the wait for each
         bucket are appended, so that the EXPOSED part of every all-reduce can be read off (dp_exposure_report)."""
         nseg = len(self.bwd_segments)
-        eager = not self.use_graph and self._side is not None and os.environ.get('SEG_DP_JOIN', 'comm') == 'comm'
+        eager = not self.use_graph and self._side is not None
         if eager:
             # Eager: the SAME plan walk as the single-GPU step (signal forks and all); at a bucket marker the bucket's all-reduce is
             # issued from a COMMUNICATION stream that waits for the side streams -- RCCL's stream then waits for exactly the filter

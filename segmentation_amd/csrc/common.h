@@ -17,6 +17,7 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 #define SEG_LAUNCH(k, ...) do { (void)hipGetLastError(); seg_note_kernel(#k); hipLaunchKernelGGL(k, __VA_ARGS__); } while (0)
 
 void seg_set_error(const char* fmt, ...);
+const char* seg_env(const char* name);                      // getenv, read once per name (elementwise.hip)
 void seg_note_kernel(const char* launch_site_spelling);     // -> seg_last_kernel_name() (thread-local)
 int seg_check_launch(const char* what);
 

@@ -762,16 +762,17 @@ static int launch_first_mfma(const FirstK& P0, hipStream_t st) {
   const int64_t total = (int64_t)P.B * P.blocks_x * P.blocks_y;
   int grid = (int)total; if (grid > 256 * 6) grid = 256 * 6;      // persistent: 6 workgroups per CU
   const int ng = P.im2col ? 1 : cdiv(P.cout, 32);
-  const bool old_form = getenv("SEG_FIRST_IMPL") && !strcmp(getenv("SEG_FIRST_IMPL"), "old");      // (read per launch: tests flip it)
+  // SEG_FIRST_IMPL = old / win forces either form (read once; seg_dbg_reload_env() re-reads it: the tests flip it between launches)
+  const char* fi = seg_env("SEG_FIRST_IMPL");
+  const bool old_form = fi && !strcmp(fi, "old");
   // The bf16-staged window form (round 3) for outputs that the 256 MB Infinity Cache absorbs: 23.0 against 31.1 us at C2 (16 x
   // 254^2 x 32: 83 MB written, 4.1 TB/s).  Its full-resolution stores are 64-byte halves of a line per instruction (a lane's
   // pixels are two apart) and once the writes really reach HBM -- 512^2 x 16: 332 MB -- it is the slower one (126-134 against
   // 117 us), so the big maps and the im2col mode keep the kernel below (SEG_FIRST_IMPL=old / win forces either).
-  const bool win_form = getenv("SEG_FIRST_IMPL") && !strcmp(getenv("SEG_FIRST_IMPL"), "win");
+  const bool win_form = fi && !strcmp(fi, "win");
   const double out_mb = (double)P.B * P.Ho * P.Wo * (ng * 32) * 2 * (P.pool.ptr ? 1.25 : 1.0) / 1e6;
   if (!P.im2col && !old_form && P.cin <= 3 && ng <= 2 && (win_form || out_mb <= 192.0)) {
-    static const int per_cu_env = getenv("SEG_FIRST_WGS_PER_CU") ? atoi(getenv("SEG_FIRST_WGS_PER_CU")) : 0;
-    const int per_cu = per_cu_env > 0 ? per_cu_env : (ng == 1 ? 6 : 3);
+    const int per_cu = ng == 1 ? 6 : 3;
     int g2 = (int)total; if (g2 > 256 * per_cu) g2 = 256 * per_cu;      // persistent: what the register budget keeps resident
     const int key = (ng - 1) * 4 + (P.relu ? 2 : 0) + (P.pool.ptr ? 1 : 0);
     switch (key) {
@@ -906,8 +907,7 @@ extern "C" int seg_im2col(const float* x, int32_t B, int32_t H, int32_t W, int32
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   {
     const int64_t patch_floats = (int64_t)((IT_TY - 1) * stride + KH) * (((IT_TX - 1) * stride + KW) * cin);
-    static const bool old_form = getenv("SEG_IM2COL_IMPL") && !strcmp(getenv("SEG_IM2COL_IMPL"), "old");
-    if (!old_form && cin <= 4 && patch_floats * 4 <= 60 * 1024 && (dtype == SEG_F32 || dtype == SEG_BF16)) {
+    if (cin <= 4 && patch_floats * 4 <= 60 * 1024 && (dtype == SEG_F32 || dtype == SEG_BF16)) {
       const int tiles_x = cdiv(Wo, IT_TX), tiles_y = cdiv(Ho, IT_TY);
       const size_t lds = (size_t)patch_floats * 4;
       auto k32 = im2col_tile_kernel<float>; auto k16 = im2col_tile_kernel<bf16_t>;
@@ -954,8 +954,8 @@ extern "C" int seg_conv_first_fwd(const float* x, int32_t B, int32_t H, int32_t 
 /* Small filter of any size / stride on the raw image as ONE pass (bf16, cin <= 3, cout <= 64): the DeconvModel's conv1_0
  * (/root/reference/models/deconvolution.py:44-46).  Instantiated: 5x5/s2, 3x3/s2, 3x3/s1, 7x7/s2. */
 static int first_gen_grid(int64_t total, int ng, bool stats) {
-  static const int per_cu_env = getenv("SEG_FIRST_WGS_PER_CU") ? atoi(getenv("SEG_FIRST_WGS_PER_CU")) : 0;
-  const int per_cu = (per_cu_env > 0 && !stats) ? per_cu_env : (ng == 1 ? 4 : 2);      // (what the filter fragments in registers leave resident)
+  (void)stats;
+  const int per_cu = ng == 1 ? 4 : 2;      // (what the filter fragments in registers leave resident)
   int g = total > 256 * per_cu ? 256 * per_cu : (int)total;
   return g < 1 ? 1 : g;
 }

@@ -17,7 +17,6 @@
 #include "common.h"
 #include <stdlib.h>
 
-int seg_conv_sweep(const seg_conv_desc& d, char* name_out, int name_cap, hipStream_t st, int* rc);   // conv_sweep.hip
 int seg_conv_ring(const seg_conv_desc& d, char* name_out, int name_cap, hipStream_t st, int* rc);    // conv_ring.hip
 
 namespace {
@@ -836,7 +835,7 @@ extern "C" int seg_conv2d_kernel_name(const seg_conv_desc* dp, char* buf, int32_
 extern "C" int seg_conv2d_splitk_plan(const seg_conv_desc* dp, int32_t* ksplit, int64_t* ws_bytes, int32_t* tickets) {
   if (!dp || !ksplit || !ws_bytes || !tickets) { seg_set_error("splitk_plan: null argument"); return SEG_ERR_ARG; }
   *ksplit = 1; *ws_bytes = 0; *tickets = 0;
-  if (dp->cfg >= 100) return SEG_OK;                 // an instance of the persistent kernel is forced: it has no K split
+  if (dp->cfg >= 200) return SEG_OK;                 // an instance of the persistent kernel (conv_ring.hip) is forced: it has no K split
   TilePlan tp = {0, 0, 0};
   seg_conv_desc d = *dp;
   d.ksplit = 0;
@@ -850,18 +849,7 @@ extern "C" int seg_conv2d_splitk_plan(const seg_conv_desc* dp, int32_t* ksplit, 
   if (dp->ksplit > 0) {
     ks = dp->ksplit < nch ? dp->ksplit : nch;
   } else {
-    // SEG_CONV_SPLITK = n (>= 2) turns the automatic split on, capped at n parts: only where the grid leaves the chip short of
-    // workgroups AND the K loop is long enough to be worth sharing -- the deep, small-map layers (<= 640 workgroups, >= 8 chunks
-    // of 32 channels); each part keeps >= 4 chunks, about 1024 workgroups in all.  OFF by default: measured on the C2 layers
-    // (profiles/r03_split_k.txt) the exchange of the partials costs ~5 us per launch -- more than the shorter K walk saves on every
-    // layer but conv5_2 (15.4 -> 13.8 us) -- and the train step went from 0.963 to 1.067 ms with it.
-    static const int cap = getenv("SEG_CONV_SPLITK") ? atoi(getenv("SEG_CONV_SPLITK")) : 0;
-    if (cap > 1 && dp->dtype == SEG_BF16 && nch >= 8 && tp.wgs <= 640) {
-      ks = (int)(1024 / tp.wgs);
-      if (ks > nch / 4) ks = nch / 4;
-      if (ks > cap) ks = cap;
-      if (ks < 1) ks = 1;
-    }
+    // (no automatic split: measured slower on every C2 layer but one, header comment of seg_conv_desc.ksplit)
   }
   if (ks > 1) {
     *ksplit = ks;
@@ -876,7 +864,7 @@ extern "C" int seg_conv2d(const seg_conv_desc* dp, void* stream) {
   seg_conv_desc d_local;
   const seg_conv_desc* dq = dp;
   const seg_conv_desc& d0 = *dp;
-  if (d0.cfg == 204 || d0.cfg == 208 || d0.cfg == 209) {
+  if (d0.cfg == 204 || d0.cfg == 208) {
     // a forced tile class of conv_ring.hip: where that kernel does not take the layer (32-channel blocks, f32, 1x1 ...) the
     // automatic choice runs instead
     int rc = SEG_OK;
@@ -928,10 +916,9 @@ extern "C" int seg_conv2d(const seg_conv_desc* dp, void* stream) {
     }
   }
   {
-    // bf16 3x3 / stride 1 without the fused pool: the wave-specialised kernel (conv_sweep.hip) unless a tile of this file is forced
+    // bf16 3x3 / stride 1: the persistent 8-wave kernel (conv_ring.hip) where it is asked for (cfg 204 / 208, SEG_CONV_IMPL=ring)
     int rc = SEG_OK;
     if (!g_plan_out && seg_conv_ring(d, g_name_out, g_name_cap, reinterpret_cast<hipStream_t>(stream), &rc)) return rc;
-    if (!g_plan_out && seg_conv_sweep(d, g_name_out, g_name_cap, reinterpret_cast<hipStream_t>(stream), &rc)) return rc;
   }
   ConvK P;
   P.d = d;

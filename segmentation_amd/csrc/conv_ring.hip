@@ -1,5 +1,5 @@
 // conv_ring.hip -- 3x3 / stride-1 NHWC convolution (forward, and the data gradient as a correlation with the flipped packed filters)
-// on MFMA, bf16: the round-4 main loop.  Replaces conv_fwd_kernel / conv_sweep_kernel on the layers it accepts
+// on MFMA, bf16: the round-4 main loop.  An alternative to conv_fwd_kernel on the layers it accepts (it replaces round 3's conv_sweep_kernel, which it beats everywhere)
 // (slim.convolution2d sites of /root/reference/models/unet.py:111-166, models/fcn.py:110-128 and their Conv2DBackpropInput);
 // conv_fwd.hip keeps f32, 1x1, 2x2/s2 and the transposed-convolution scatter.
 //
@@ -439,7 +439,7 @@ extern "C" int seg_dbg_set_crstamps(void* p) {
 int seg_conv_ring(const seg_conv_desc& d, char* name_out, int name_cap, hipStream_t st, int* rc) {
   static const char* impl = getenv("SEG_CONV_IMPL");
   static const int impl_mode = impl ? (!strcmp(impl, "ring") ? 1 : (!strcmp(impl, "tiled") ? -1 : 0)) : 0;
-  const bool forced = d.cfg == 208 || d.cfg == 204 || d.cfg == 209;
+  const bool forced = d.cfg == 208 || d.cfg == 204;
   if (!forced && (d.cfg != 0 || impl_mode <= 0)) return 0;
   if (d.dtype != SEG_BF16 || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.up2 || d.n_store || d.thin_src || d.out_f32 || d.ksplit > 1) return 0;
   if (d.n_count % 64 || d.n_split % 64) return 0;             // 64-channel blocks (the 32-channel layers stay on the tiled kernel)
@@ -455,11 +455,9 @@ int seg_conv_ring(const seg_conv_desc& d, char* name_out, int name_cap, hipStrea
   static const double t_chunk[3] = {3.7, 2.2, 4.8};              // us per 32-channel chunk (r04 stamps)
   int best_cls = -1; CrShape best_s = {0, 0}; double best_cost = 1e30;
   const int nblk = d.n_count / 64;
-  for (int cls = 0; cls < 3; ++cls) {
+  for (int cls = 0; cls < 2; ++cls) {                           // (class 2 = 4 waves x 8 rows, one wave per SIMD, measured 4.8 us per chunk against 3.7: not built)
     if (d.cfg == 208 && cls != 0) continue;
     if (d.cfg == 204 && cls != 1) continue;
-    if (d.cfg == 209 && cls != 2) continue;
-    if (d.cfg == 0 && cls == 2) continue;                         // (one wave per SIMD: 4.8 us per chunk against 3.7 -- kept for the record, never chosen)
     const int pxw = PXWs[cls];
     for (int wr = 1; wr <= pxw; wr *= 2) {
       const int wc = pxw / wr;
@@ -481,11 +479,14 @@ int seg_conv_ring(const seg_conv_desc& d, char* name_out, int name_cap, hipStrea
   P.m_pw = (uint32_t)((((uint64_t)1) << 32) / (uint64_t)P.PW + 1);
   P.tiles_x = cdiv(d.Wo, P.TW); P.tiles_y = cdiv(d.Ho, P.TH); P.nblk = nblk; P.ntiles = d.B * P.tiles_y * P.tiles_x * nblk;
   P.nchunks0 = d.src0.c / 32; P.nchunks = nchunks;
-  static const int abl = getenv("SEG_RING_ABL") ? atoi(getenv("SEG_RING_ABL")) : 0;
+#ifdef SEG_STAMPS
+  static const int abl = getenv("SEG_RING_ABL") ? atoi(getenv("SEG_RING_ABL")) : 0;      // (debug builds: tools/stamp_ring.py)
   P.abl = abl;
+#else
+  P.abl = 0;
+#endif
   const bool pool = d.pool.ptr != nullptr;
   if (best_cls == 0) *rc = pool ? cr_launch<8, 4, 1, 4, 672, true>(P, name_out, name_cap, st) : cr_launch<8, 4, 1, 4, 672, false>(P, name_out, name_cap, st);
-  else if (best_cls == 1) *rc = pool ? cr_launch<8, 4, 2, 2, 400, true>(P, name_out, name_cap, st) : cr_launch<8, 4, 2, 2, 400, false>(P, name_out, name_cap, st);
-  else *rc = pool ? cr_launch<4, 8, 1, 4, 672, true>(P, name_out, name_cap, st) : cr_launch<4, 8, 1, 4, 672, false>(P, name_out, name_cap, st);
+  else *rc = pool ? cr_launch<8, 4, 2, 2, 400, true>(P, name_out, name_cap, st) : cr_launch<8, 4, 2, 2, 400, false>(P, name_out, name_cap, st);
   return 1;
 }

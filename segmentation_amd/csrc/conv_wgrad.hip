@@ -901,9 +901,9 @@ int launch_k(const WgK& P, hipStream_t st) {
     // bound, ~480; ~540 with 256-pixel tiles).  Bigger accumulators mean bigger partial-sum slabs per K split (A: 147 KB per
     // workgroup), so A wins on the big maps (512 x 512: 540-717 TF/s for kernel + reduction) and B / C on the small ones.
     //   cost [us] = 8 + rounds * ceil(tiles / ksplit) * t_tile + (ksplit > 1 ? 3 + ksplit * slab_bytes / 4.5 TB/s : 0)
-    static const int layout = getenv("SEG_WGRAD_LAYOUT") ? atoi(getenv("SEG_WGRAD_LAYOUT")) : 2;   // 0 = r01 choice (C only), 1 = B and C
+    const int layout = 2;          // every layout is a candidate (0 was the r01 choice, C only; 1 = B and C)
     // (the layout choice keeps the stand-alone calibration at 256 workgroups: choosing layouts for 128 was measured slower)
-    static const int cm_wgs = getenv("SEG_WGRAD_CM_WGS") ? atoi(getenv("SEG_WGRAD_CM_WGS")) : 256;
+    const int cm_wgs = 256;
     const bool ci64 = d.src0.c % 64 == 0 && (!d.src1.ptr || d.src1.c % 64 == 0), co64 = d.dz.c % 64 == 0;
     struct Cand { int cfg, th, tw, cit, bn, occ; double rate; };
     static const Cand cands[] = {{11, 8, 16, 64, 64, 1, 750.}, {14, 8, 8, 64, 64, 1, 750.}, {12, 8, 16, 32, 64, 2, 620.}, {15, 8, 8, 32, 64, 2, 620.},

@@ -23,10 +23,27 @@ extern "C" const char* seg_last_error(void) { return g_err; }
 // the kernel this host thread launched last, as spelled at the launch site (parentheses dropped); launch sites that go through a
 // function-pointer variable ("kern": the templated convolution / filter-gradient dispatchers) leave "" -- their instance is
 // reported by seg_conv2d_kernel_name / seg_conv2d_wgrad_kernel_name
+// Environment switches of the library are read ONCE (seg_env caches the pointer per name); seg_dbg_reload_env() drops the cache --
+// the tests flip SEG_FIRST_IMPL between launches of one process.
+static int g_env_epoch = 1;
+const char* seg_env(const char* name) {
+  struct Ent { const char* name; const char* val; int epoch; };
+  static Ent tab[16];
+  for (int i = 0; i < 16; ++i) {
+    if (tab[i].name && !strcmp(tab[i].name, name)) {
+      if (tab[i].epoch != g_env_epoch) { tab[i].val = getenv(name); tab[i].epoch = g_env_epoch; }
+      return tab[i].val;
+    }
+    if (!tab[i].name) { tab[i].name = name; tab[i].val = getenv(name); tab[i].epoch = g_env_epoch; return tab[i].val; }
+  }
+  return getenv(name);
+}
+extern "C" void seg_dbg_reload_env(void) { ++g_env_epoch; }
+
 static thread_local char g_kname[160] = "", g_kname_out[160] = "";
 void seg_note_kernel(const char* s) {
   if (g_kname[0]) return;                           // the FIRST kernel since the last query (a finishing pass does not rename the launch)
-  if (s[0] == 'k' && s[1] == 'e' && s[2] == 'r' && s[3] == 'n' && s[4] == 0) return;
+  if (!strstr(s, "_kernel")) return;                // (a launch through a function-pointer variable -- kern, k0, k32 ...: the dispatcher's own name query answers)
   int n = 0;
   for (const char* p = s; *p && n < 159; ++p) if (*p != '(' && *p != ')' && *p != ' ') g_kname[n++] = *p;
   g_kname[n] = 0;
@@ -1153,8 +1170,7 @@ extern "C" int seg_softmax_xent_probs(const seg_view* logits, const uint8_t* lab
 static int head_xent_grid(int64_t B, int64_t H, int64_t W, int cpad) {
   // >= 4 pixels per lane group (a 68 x 68 map: 289 workgroups), at most 2048 workgroups (512 x 512: ~13 pixels each): the
   // per-workgroup partial row and the loss atomic stay cheap (16 k workgroups doubled the kernel time on the atomic alone)
-  static const int per_group = getenv("SEG_HEAD_PX") ? atoi(getenv("SEG_HEAD_PX")) : 4;
-  const int64_t px_per_wg = 256 / (cpad / 8) * (per_group > 0 ? per_group : 4);
+  const int64_t px_per_wg = 256 / (cpad / 8) * 4;        // (2 / 1 pixels per lane group measured no better at C2: profiles/r03_step_structure_ab.txt)
   return grid_for(B * H * W, (int)px_per_wg, 2048);
 }
 static int head_ncp(int n_classes) { return n_classes <= 4 ? 4 : n_classes <= 8 ? 8 : n_classes <= 16 ? 16 : 32; }
@@ -1354,7 +1370,7 @@ static int thin_conv_launch(const seg_view* src, int32_t B, int32_t Hi, int32_t 
   const seg_view mk = (mask && mask->ptr) ? *mask : seg_view{nullptr, 0, 0, 0, 0, 0, 0, 0};
   const int m = cin > cout ? cin : cout;
   const int g = grid_for((int64_t)B * Ho * Wo, 256, 16384);
-  const int remap = getenv("SEG_XCD_REMAP") ? atoi(getenv("SEG_XCD_REMAP")) : 1;
+  const int remap = 1;                     // XCD-aware run order (r03: measured faster; the plain order is gone)
 #define TC_ARGS dim3(g), dim3(256), 0, ST(stream), *src, w_hwio, bias, cin, cout, pad, relu, dgrad, mk, *dst, B, Ho, Wo, Hi, Wi, remap, bn_stats, bn_beta, cin
 #define TC_NC(TT, F32) do { if (m <= 2) SEG_LAUNCH((thin_conv3x3_kernel<TT, 2, F32>), TC_ARGS); \
     else if (m <= 4) SEG_LAUNCH((thin_conv3x3_kernel<TT, 4, F32>), TC_ARGS); else SEG_LAUNCH((thin_conv3x3_kernel<TT, 8, F32>), TC_ARGS); } while (0)
@@ -1495,7 +1511,7 @@ static int thin_wgrad_launch(const seg_view* src, int32_t B, int32_t Hi, int32_t
   const int nc = thin_wgrad_nc(cin, cout);
   const int g = grid_for((int64_t)B * Ho * Wo, 256, TW_ROWS);
   float* wsf = reinterpret_cast<float*>(ws);
-  const int remap = getenv("SEG_XCD_REMAP") ? atoi(getenv("SEG_XCD_REMAP")) : 1;
+  const int remap = 1;
 #define TWG_ARGS(GY) dim3(g, GY), dim3(256), 0, ST(stream), *src, *dz, pad, B, Ho, Wo, Hi, Wi, wsf, remap, bn_stats, bn_beta, cin
 #define TWG_NC(TT) do { if (nc == 2) SEG_LAUNCH((thin_wgrad3x3_partial_kernel<TT, 2, 9>), TWG_ARGS(1)); \
     else if (nc == 4) SEG_LAUNCH((thin_wgrad3x3_partial_kernel<TT, 4, 3>), TWG_ARGS(3)); else SEG_LAUNCH((thin_wgrad3x3_partial_kernel<TT, 8, 1>), TWG_ARGS(9)); } while (0)

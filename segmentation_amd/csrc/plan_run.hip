@@ -7,7 +7,16 @@
 struct SegThunk { const char* name; int (*fn)(const seg_arg*, void*); int nargs; };
 #include "plan_thunks.inc"
 
+#include <mutex>
+#include <vector>
+
 static const int N_THUNKS = (int)(sizeof(g_thunks) / sizeof(g_thunks[0]));
+
+// Fork events are never destroyed: a plan that goes away hands them back to this pool (its owner may be garbage-collected at any
+// time -- e.g. while another thread captures a hipGraph, where hipEventDestroy is not a safe call) and later plans take them again.
+// Re-recording a pooled event cannot disturb a wait issued earlier: a wait refers to the record that preceded it.
+static std::mutex g_ev_mutex;
+static std::vector<hipEvent_t> g_ev_free;
 static int g_conv2d_id = -2;
 
 extern "C" int seg_plan_fn_id(const char* name) {
@@ -45,7 +54,11 @@ extern "C" int seg_plan_run(seg_plan_op* ops, int32_t n, void* const* streams, i
     } else if (op.kind == SEG_OP_EVENT_FORK) {
       hipEvent_t ev = reinterpret_cast<hipEvent_t>(op.event);
       if (!ev) {
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { if (failed_op) *failed_op = i; seg_set_error("plan_run: cannot create an event"); return SEG_ERR_LAUNCH; }
+        {
+          std::lock_guard<std::mutex> lk(g_ev_mutex);
+          if (!g_ev_free.empty()) { ev = g_ev_free.back(); g_ev_free.pop_back(); }
+        }
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { if (failed_op) *failed_op = i; seg_set_error("plan_run: cannot create an event"); return SEG_ERR_LAUNCH; }
         op.event = ev;
       }
       if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(reinterpret_cast<hipStream_t>(streams[op.stream2]), ev, 0) != hipSuccess) {
@@ -68,6 +81,7 @@ extern "C" int seg_plan_run(seg_plan_op* ops, int32_t n, void* const* streams, i
 
 extern "C" int seg_plan_destroy_events(seg_plan_op* ops, int32_t n) {
   if (!ops) return SEG_OK;
-  for (int i = 0; i < n; ++i) if (ops[i].kind == SEG_OP_EVENT_FORK && ops[i].event) { (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ops[i].event)); ops[i].event = nullptr; }
+  std::lock_guard<std::mutex> lk(g_ev_mutex);
+  for (int i = 0; i < n; ++i) if (ops[i].kind == SEG_OP_EVENT_FORK && ops[i].event) { g_ev_free.push_back(reinterpret_cast<hipEvent_t>(ops[i].event)); ops[i].event = nullptr; }
   return SEG_OK;
 }

@@ -462,7 +462,7 @@ bool choose(const seg_wgrad_desc& d, int layout, Choice* best) {
   if (d.ksplit > 0) f_ks = d.ksplit;
   bool found = false;
   best->cost = 1e30;
-  static const double reduce_us = getenv("SEG_SWEEP_REDUCE_US") ? atof(getenv("SEG_SWEEP_REDUCE_US")) : 5.5;
+  const double reduce_us = 5.5;
   static const int tg_opts[] = {1, 3, 9};
   for (int tgs : tg_opts) {
     if (f_tgs && tgs != f_tgs) continue;

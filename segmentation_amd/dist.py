@@ -28,6 +28,9 @@ class DataParallel(object):
         self.algo = algo or os.environ.get('SEG_DP_ALGO', 'allreduce')
         self._dry = os.environ.get('SEG_DP_DRY', '0') == '1'
         self.force_collectives = os.environ.get('SEG_DP_FORCE', '0') == '1'     # world 1: run the (identity) collectives anyway
+        # the step's stream set-up is TUNED for RCCL's company (own auxiliary stream, no high-priority stream, lone-launch filter-gradient
+        # targets) only where collectives are really issued: a world-1 run keeps the single-GPU set-up and pays for the bucket markers only
+        self.tuned = self.enabled and (self.world > 1 or self.force_collectives)
         self.rs_min = 4096                      # rs_ag: elements per rank below which a bucket goes through one all-reduce
         self._has_rs = None
         if self.algo not in ('allreduce', 'rs_ag'):

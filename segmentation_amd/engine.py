@@ -137,7 +137,6 @@ class ParamStore(object):
         # offset of its dgrad copy (training stores; an inference store has no dgrad copies and uses the table-driven kernel)
         self.pack_dual = None
         self._pack_entries = entries
-        self._pack_parts = {}
         if training and entries:
             self.pack_dual = self._dual_table(lambda src_off: True)
         if entries:
@@ -163,15 +162,6 @@ class ParamStore(object):
             return None
         return (torch.frombuffer(bytearray(b''.join(bytes(f) for f in fwd)), dtype=torch.uint8).to(self.device),
                 torch.tensor(dg, dtype=torch.int64, device=self.device), len(fwd), tiles)
-
-    def pack_part(self, names, complement=False):
-        """The re-pack table of a SUBSET of the layers (training stores): the models pack the few filters the first layers of the
-        forward pass need beside the first layer and the bulk afterwards (Net.pack(part=...))."""
-        key = (tuple(sorted(names)), complement)
-        if key not in self._pack_parts:
-            offs = set(self.layers[n].w_off for n in names)
-            self._pack_parts[key] = self._dual_table((lambda o: o not in offs) if complement else (lambda o: o in offs))
-        return self._pack_parts[key]
 
     # ---- host access (tests, snapshots, weight loading) ----
     def packed_ptr(self, off):
@@ -378,6 +368,7 @@ class CompiledPlan(object):
         self.ops = (L.PlanOp * max(1, self.n))()
         self.args_of = {}                          # plan op index -> its seg_arg array (Plan.rebind)
         self.names = []
+        self.markers = []                          # (position in ops, marker meta, side streams to hand to the callback)
         self._keep = []
         self.main = main
         for k, r in enumerate(rec):
@@ -402,6 +393,12 @@ class CompiledPlan(object):
             elif r[0] == 'F':
                 op.kind, op.stream, op.stream2 = L.OP_EVENT_FORK, sidx[id(r[1])], sidx[id(r[2])]
                 self.names.append('fork')
+            elif r[0] == 'M':
+                # a data-parallel marker: the replay stops in front of it, the caller's callback runs, the replay goes on (the op
+                # itself is a no-op wait on slot 0 of the main stream that is never executed: stretches exclude it)
+                op.kind, op.stream, op.signal_slot = L.OP_WAIT_VALUE, 0, 0
+                self.markers.append((k, r[1], r[2]))
+                self.names.append('marker')
             else:
                 op.kind, op.stream, op.signal_slot = L.OP_WAIT_VALUE, sidx[id(r[1])], r[2]
                 self.names.append('wait')
@@ -428,17 +425,24 @@ class CompiledPlan(object):
         if ent is not None:
             self._marshal(ent[0][j], ent[1][j], value)
 
-    def run(self):
+    def run(self, on_marker=None):
         sig = _signal_state(self.main) if self.nslots else None
         base, flag = 0, None
         if sig is not None:
             base = sig['n']
             sig['n'] += self.nslots
             flag = sig['flag'].data_ptr()
-        rc = self.lib.seg_plan_run(self.ops, self.n, self.streams, len(self.streams), flag, base & 0x7fffffff, C.byref(self.failed))
-        if rc != 0:
-            k = self.failed.value
-            L.check(rc, '%s/%s' % (self.plan.name, self.names[k] if 0 <= k < len(self.names) else '?'))
+        lo = 0
+        for pos, md, streams in self.markers + [(self.n, None, None)]:
+            if pos > lo:
+                rc = self.lib.seg_plan_run(C.cast(C.byref(self.ops, lo * C.sizeof(L.PlanOp)), C.POINTER(L.PlanOp)), pos - lo, self.streams, len(self.streams),
+                                           flag, base & 0x7fffffff, C.byref(self.failed))
+                if rc != 0:
+                    k = lo + self.failed.value
+                    L.check(rc, '%s/%s' % (self.plan.name, self.names[k] if 0 <= k < len(self.names) else '?'))
+            if md is not None:
+                on_marker(md, streams)
+            lo = pos + 1
 
     def __del__(self):
         try:
@@ -492,10 +496,11 @@ class Plan(object):
             return
         main = torch.cuda.current_stream()
         capturing = torch.cuda.is_current_stream_capturing()
-        if _PLAN_C and not capturing and join_into is None and on_marker is None:
+        if _PLAN_C and not capturing and join_into is None:
             # the whole walk below was recorded once (forks, signal forks, held launches and all) and is replayed by ONE call into
-            # the library (seg_plan_run): ~130 interpreter iterations + ctypes calls per train step become one
-            return self._run_compiled(stream, main, side, tuple(skip), flavor)
+            # the library (seg_plan_run): ~130 interpreter iterations + ctypes calls per train step become one -- one call per
+            # stretch between two data-parallel markers when there is a marker callback
+            return self._run_compiled(stream, main, side, tuple(skip), flavor, on_marker)
         return self._walk(stream, main, side, skip, flavor, join_into, on_marker, None)
 
     def _walk(self, stream, main, side, skip, flavor, join_into, on_marker, rec):
@@ -507,6 +512,9 @@ class Plan(object):
         if recording:
             def fork(a_, b_):
                 rec.append(('F', a_, b_))
+            if on_marker is not None:                  # (markers become entries of the recording: CompiledPlan.run calls back between two replays)
+                def on_marker(md_, streams_):          # noqa: F811
+                    rec.append(('M', md_, list(streams_)))
         else:
             fork = _fork
         used = {}
@@ -681,16 +689,16 @@ class Plan(object):
             join(st)
         return nslot[0]
 
-    def _run_compiled(self, stream, main, side, skip, flavor):
+    def _run_compiled(self, stream, main, side, skip, flavor, on_marker=None):
         cache = self.__dict__.setdefault('_compiled', {})
         sig_on = bool(_SIGNAL_ON and not _SIGNALS.get('off'))
-        key = (stream, main.device.index, tuple(o_.cuda_stream for o_ in side), skip, flavor, sig_on, len(self.ops))
+        key = (stream, main.device.index, tuple(o_.cuda_stream for o_ in side), skip, flavor, sig_on, len(self.ops), on_marker is not None)
         cp = cache.get(key)
         if cp is None:
             rec = []
-            nslots = self._walk(stream, main, side, skip, flavor, None, None, rec)
+            nslots = self._walk(stream, main, side, skip, flavor, None, on_marker, rec)
             cp = cache[key] = CompiledPlan(self, rec, nslots, stream, main, side)
-        cp.run()
+        cp.run(on_marker)
 
     def rebind(self, mapping):
         """Replaces raw device pointers among the launch arguments ({old: new}; the network inputs when a device-resident
@@ -836,10 +844,10 @@ class Net(object):
     def _splitk(self, d, plan, ksplit=None):
         """Asks the library whether this convolution launch should share its K loop among several workgroups per output tile
         (seg_conv2d_splitk_plan: the deep, small-map layers) and gives the descriptor the workspace and tickets it then needs.
-        ksplit: None = automatic, 1 = off, n = ask for n parts (tests)."""
+        ksplit: None / 1 = off (no automatic split: measured slower), n = ask for n parts (tests)."""
         d.ksplit = 0 if ksplit is None else ksplit
         d.splitk_ws = None; d.splitk_tickets = None
-        if ksplit == 1 or (ksplit is None and os.environ.get('SEG_CONV_SPLITK', '0') in ('', '0', '1')):
+        if ksplit is None or ksplit == 1:
             d.ksplit = 0                      # (off by default: measured slower, see seg_conv2d_splitk_plan)
             return
         ks, nbytes, nt = C.c_int32(0), C.c_int64(0), C.c_int32(0)
@@ -855,7 +863,7 @@ class Net(object):
 
     def sched_slot(self):
         """device address of a fresh pair of ticket words (None once the pool is used up: the kernel then splits statically)"""
-        if os.environ.get('SEG_CONV_SCHED', '1') == '0' or 2 * self._sched_n + 2 > self._sched.numel():
+        if 2 * self._sched_n + 2 > self._sched.numel():
             return None
         self._sched_n += 1
         return self._sched.data_ptr() + 8 * (self._sched_n - 1)
@@ -1068,10 +1076,10 @@ class Net(object):
         the models' measured in-step durations fit (15 us + FLOPs at 200 TFLOP/s + 10 us for a slab reduction); plain alternation
         gave the conv*_2 layers (cin = cout, the heavier of each pair) to one stream: 567 against 478 us at C2.  Only the big steps
         (> 2.5 M input pixels: the side streams are their tail) gain from it -- 512^2 4.04 against 4.07 ms; at C2, bound by the
-        critical stream, the balanced assignment measured 0.953 against 0.941 ms and the alternation stays (SEG_WGRAD_BALANCE=0/1)."""
+        critical stream, the balanced assignment measured 0.953 against 0.941 ms and the alternation stays."""
         n = self.n_wgrad_streams
         big = getattr(self, 'input_pixels', None) is not None and self.input_pixels > 2500000
-        if n < 2 or os.environ.get('SEG_WGRAD_BALANCE', '1' if big else '0') == '0':
+        if n < 2 or not big:
             k = self._wg_rr % n
             self._wg_rr += 1
             return 1 + k
@@ -1261,8 +1269,7 @@ class Net(object):
     def _conv_bwd_data(self, plan, layer, srcs, Hi, Wi, dz, dsrcs, dz_off, cfg, dgrad_ksplit, Ho, Wo):
         k, pad = layer.k, layer.pad
         n_off = 0
-        merged = (len(dsrcs) == 2 and dsrcs[0] is not None and dsrcs[1] is not None and not any(len(x) > 4 and x[4] for x in dsrcs)
-                  and os.environ.get('SEG_MERGE_DGRAD', '1') != '0')
+        merged = len(dsrcs) == 2 and dsrcs[0] is not None and dsrcs[1] is not None and not any(len(x) > 4 and x[4] for x in dsrcs)
         if merged:
             # both halves of a channel-concat input in ONE launch (seg_conv_desc.n_split): one kernel less per decoder level
             assert not dz.thin and not self._thin(dsrcs[0][0], dsrcs[1][0]), 'thin tensors have one source'
@@ -1799,29 +1806,15 @@ class Net(object):
         plan.keep.append(lv)
         plan.add('sigmoid_argmax', self.lib.seg_sigmoid_argmax, C.byref(lv), self.B, H, W, n_classes, sig.data_ptr(), out.data_ptr(), kernel='sigmoid_argmax_kernel')
 
-    def pack(self, plan, aux=False, part=None, side=None):
+    def pack(self, plan, aux=False):
         """Re-packs the fp32 master weights into the MFMA operand layout.  aux=True: on the auxiliary stream (the
-        training forward starts with it, overlapped with the first layer, which reads the fp32 arena directly).
-        part = (layer names, complement): only those layers (or all the others) -- training stores; side: a filter-gradient stream
-        instead of the main / auxiliary one."""
+        training forward starts with it, overlapped with the first layer, which reads the fp32 arena directly)."""
         s = self.store
         if s.pack_table is None:
             return
         meta = {'kernel': 'pack_kernel'}
         if aux:
             meta['side'] = 'aux'
-        if side:
-            meta['side'] = side
-        if part is not None:
-            t = s.pack_part(part[0], part[1])
-            if t is None:
-                return
-            tab, dg, ne, tiles = t
-            plan.keep += [tab, dg]
-            meta['kernel'] = 'pack_dual_kernel'
-            plan.add('pack' + ('/rest' if part[1] else '/first'), self.lib.seg_pack_weights_dual, s.p.data_ptr(), s.packed.data_ptr(), tab.data_ptr(),
-                     dg.data_ptr(), ne, tiles, self.dtype, **meta)
-            return
         if getattr(s, 'pack_dual', None) is not None:
             # training stores: both packed copies of a tile from ONE read of the arena
             tab, dg, ne, tiles = s.pack_dual

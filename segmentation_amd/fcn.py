@@ -168,7 +168,7 @@ class FCNModel(BaseModel):
         B, (H, W) = self.batch_size, self.input_dims
         net = self.net = E.Net(self.store, B, self.dtype, self.device)
         net.n_wgrad_streams = max(1, len(self._side) - 1) if self._side else 1
-        net.input_pixels = B * H * W if not self.pg.enabled else None      # (data parallel keeps the lone-launch filter-gradient target: 1.05 against 1.09 ms at world 1)
+        net.input_pixels = B * H * W if not self.pg.tuned else None      # (data parallel keeps the lone-launch filter-gradient target: 1.05 against 1.09 ms at world 1)
         net.tail_layers = ('conv2',)      # last tiled filter gradient of the backward pass: aims for the whole chip (see unet.py); +2 % at C3
         Ly, nc = self.store.layers, self.n_classes
         fwd = self.fwd_plan = E.Plan('fwd')
@@ -244,7 +244,7 @@ class FCNModel(BaseModel):
             a = A[name]
             if i == 1 and net.fuses_first_pool_bwd(col):
                 # pool1's backward happens inside the first layer's filter gradient (no launch, no dZ(conv1) tensor)
-                aux_tail = not self.pg.enabled and not self.adversarial_training and os.environ.get('SEG_ADAM_OVERLAP', '1') != '0'
+                aux_tail = not self.pg.enabled and not self.adversarial_training
                 if aux_tail:
                     self._aux_tail_layer = name
                 net.first_bwd(seg, Ly[name], self.input_x, H, W, None, same_stream=not self.pg.enabled, pool=(a, dP[i], None, (0, 0), (0, 0)),

@@ -124,13 +124,7 @@ class UNetModel(BaseModel):
         return self.fwd_plan
 
     # ---- forward graph (shared by training and inference builders) ----
-    # the layers whose packed filters the forward pass needs before conv4_1: re-packed beside conv1_1; everything else (96 % of the
-    # bytes) is re-packed on a filter-gradient stream (idle in the forward pass) AFTER conv1_1, beside conv2_1 .. conv3_2 -- the
-    # first layer is HBM-bound and ran at half its stand-alone rate while the whole re-pack shared the memory with it (49.9 us in
-    # the C2 step against 23)
-    PACK_FIRST = ('conv1_2', 'conv2_1', 'conv2_2', 'conv3_1', 'conv3_2')
-
-    def _emit_forward(self, net, plan, x_in, H, W, crop_aware, dropout=None, after_first=None, head=True, split_pack=False):
+    def _emit_forward(self, net, plan, x_in, H, W, crop_aware, dropout=None, after_first=None, head=True):
         nk, Ly = self.n_kernels, self.store.layers
         if H != W:
             # the reference crops every skip with a SQUARE target taken from the height (models/unet.py:139-140,146-147):
@@ -144,8 +138,6 @@ class UNetModel(BaseModel):
         if after_first is not None:
             after_first()
         net.join_aux(plan)                 # packed weights (re-packed on the aux stream in training) are needed from here on
-        if split_pack:
-            net.pack(plan, part=(self.PACK_FIRST, True), side=2)      # the bulk: starts when conv2_1 starts, joined in front of conv4_1
         # conv1_2: only its centre window survives the crop of the last skip
         t4h, t4w = sh['upconv4'], sw['upconv4']
         o4h, o4w = (sh['conv1_2'] - t4h) // 2, (sw['conv1_2'] - t4w) // 2
@@ -153,7 +145,7 @@ class UNetModel(BaseModel):
         # beside conv2_1 ..., joined in front of conv9_1 -- one launch less on the critical stream: C2 0.969 against 0.972 ms on
         # one box; at 512^2, where the launch is not what its 75 us are made of, 4.20 against 4.18, so it stays on the main stream)
         px = getattr(net, 'input_pixels', None)
-        off_side = 1 if (px is not None and px <= 2500000 and os.environ.get('SEG_CONV1_2_SIDE', '1') != '0') else 0
+        off_side = 1 if (px is not None and px <= 2500000) else 0
         if crop_aware:
             A['conv1_2'] = net.act(t4h, t4w, nk, name='conv1_2')
             net.conv_fwd(plan, Ly['conv1_2'], [(A['conv1_1'], o4h, o4w)], t4h + 2, t4w + 2, A['conv1_2'], side=off_side)
@@ -169,8 +161,6 @@ class UNetModel(BaseModel):
             if not pooled:
                 net.pool_fwd(plan, prev, P, P.H, P.W)
             c1, c2 = 'conv%d_1' % i, 'conv%d_2' % i
-            if split_pack and i == 4:
-                net.join_wgrad(plan)         # the rest of the packed filters
             A[c1] = net.act(sh[c1], sw[c1], Ly[c1].cout, name=c1)
             net.conv_fwd(plan, Ly[c1], [(P, 0, 0)], P.H, P.W, A[c1])
             A[c2] = net.act(sh[c2], sw[c2], Ly[c2].cout, name=c2)
@@ -222,24 +212,25 @@ class UNetModel(BaseModel):
         B, (H, W) = self.batch_size, self.input_dims
         net = self.net = E.Net(self.store, B, self.dtype, self.device)
         net.n_wgrad_streams = max(1, len(self._side) - 1) if self._side else 1
-        net.input_pixels = B * H * W if not self.pg.enabled else None      # (data parallel keeps the lone-launch filter-gradient target: 1.05 against 1.09 ms at world 1)
+        net.input_pixels = B * H * W if not self.pg.tuned else None      # (data parallel keeps the lone-launch filter-gradient target: 1.05 against 1.09 ms at world 1)
         # the last filter gradients of the backward pass outlive the critical stream: they aim for the whole chip (256 workgroups)
         net.tail_layers = ('conv1_2', 'conv2_1')
         Ly = self.store.layers
         fwd = self.fwd_plan = E.Plan('fwd')
         self.loss_buf = self.store.loss_slot()          # (behind the gradient arena: reduced with the last bucket under data parallelism)
         net.step_begin(fwd, self.loss_buf)     # aux stream: global_step += 1, loss accumulator = 0
-        split_pack = self._side is not None and len(self._side) >= 2 and os.environ.get('SEG_SPLIT_PACK', '1') != '0'
-        if split_pack:
-            net.pack(fwd, aux=True, part=(self.PACK_FIRST, False))
-        else:
-            net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1_1
+        # refresh the packed weights after the previous Adam step, beside conv1_1.  (Round 4 tried to keep the first layer -- HBM-bound,
+        # 49.9 us in the step against 23 alone -- out of the re-pack's shadow: the few filters conv1_2 .. conv3_2 need packed beside
+        # conv1_1, the bulk on a filter-gradient stream beside conv2_1 .. conv3_2.  The step got 0.7 % SLOWER at C2 and 1 % at 512^2
+        # (profiles/r04_ab_split_pack_*.txt): the 62 MB have to share the memory with something, and conv2_x are no less
+        # bandwidth-hungry than conv1_1.  Removed.)
+        net.pack(fwd, aux=True)
         cols = []       # im2col of the input for conv1_1's filter gradient: side stream, right after conv1_1 (both are
         #                 bandwidth-bound), overlapping the rest of the forward pass
         fuse_head = (E.rup(Ly['output'].cin) in (32, 64) and self.n_classes <= 32 and os.environ.get('SEG_FUSE_HEAD', '1') != '0' and
                      not self.adversarial_training)     # (the adversary adds its term to dlogits before the output layer's backward)
         A, sh, sw, skip_off, o4 = self._emit_forward(net, fwd, self.input_x, H, W, self.crop_aware, head=not fuse_head,
-                                                     after_first=lambda: cols.append(net.first_im2col(fwd, Ly['conv1_1'], self.input_x, H, W)), split_pack=split_pack)
+                                                     after_first=lambda: cols.append(net.first_im2col(fwd, Ly['conv1_1'], self.input_x, H, W)))
         col = cols[0]
         self.acts = A
         oh, ow = sh['output'], sw['output']
@@ -351,13 +342,10 @@ class UNetModel(BaseModel):
         close_segment('conv1_2')
         if net.fuses_first_pool_bwd(col):
             # pool1's backward happens inside the first layer's filter gradient (no launch, no dZ(conv1_1) tensor)
-            # (Adam beside the last filter gradient: +1 % for the FCN, -0.4 % here at 256^2, +-0 at 512^2 -- both kernels are bandwidth-bound;
-            # off by default for the U-Net)
-            aux_tail = not self.pg.enabled and not self.adversarial_training and os.environ.get('SEG_ADAM_OVERLAP', '0') == '1'
-            if aux_tail:
-                self._aux_tail_layer = 'conv1_1'
+            # (the FCN runs Adam beside its last filter gradient: +1 % there; here that measured -0.4 % at 256^2 and +-0 at 512^2 -- both
+            # kernels are bandwidth-bound -- so it is not done)
             net.first_bwd(seg, Ly['conv1_1'], self.input_x, H, W, None, same_stream=not self.pg.enabled,
-                          pool=(A['conv1_1'], dP[1], d11s, (t4h + 2, t4w + 2), o4), on_aux=aux_tail)
+                          pool=(A['conv1_1'], dP[1], d11s, (t4h + 2, t4w + 2), o4))
         else:
             net.pool_bwd(seg, A['conv1_1'], dP[1], d11s, (t4h + 2, t4w + 2), o4, gz('conv1_1'), A['conv1_1'].H, A['conv1_1'].W)
             net.first_bwd(seg, Ly['conv1_1'], self.input_x, H, W, G['conv1_1'], col=col, same_stream=not self.pg.enabled)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 18
     for n in names:
         assert hasattr(lib, n), n
-    bound = set(_lib.SIGNATURES) | {'seg_last_error', 'seg_version', 'seg_last_kernel_name', 'seg_plan_fn_id', 'seg_plan_run', 'seg_plan_destroy_events', 'seg_bn_ws_bytes', 'seg_dconv_wgrad_ws_bytes', 'seg_bilinear_up_bwd_ws_bytes',
+    bound = set(_lib.SIGNATURES) | {'seg_last_error', 'seg_version', 'seg_last_kernel_name', 'seg_dbg_reload_env', 'seg_plan_fn_id', 'seg_plan_run', 'seg_plan_destroy_events', 'seg_bn_ws_bytes', 'seg_dconv_wgrad_ws_bytes', 'seg_bilinear_up_bwd_ws_bytes',
              'seg_head_xent_ws_bytes', 'seg_bias_grad_ws_bytes', 'seg_conv_first_gen_rows', 'seg_thin_up2x2_rows', 'seg_thin_wgrad3x3_ws_bytes', 'seg_conv_first_gen_wgrad_ws_bytes'}
     assert bound == set(names)
     assert _lib.load().seg_version() == 100

@@ -112,7 +112,23 @@ def test_device_prefetcher_feeds_identical_batches():
         pf.stop()
 
 
-def test_zero_copy_device_batches_equal_copied_ones(monkeypatch):
+class _HostOnly(object):
+    """a device-resident dataset seen through the host interface only (get_batch -> numpy): the model copies every batch into its own
+    input buffers instead of reading the dataset's buffers in place"""
+
+    def __init__(self, ds):
+        self.ds = ds
+        self.batch_size, self.has_masks, self.use_feed = ds.batch_size, True, False
+
+    def set_tf_sess(self, sess):
+        pass
+
+    def get_batch(self):
+        x, y = self.ds.get_device_batch()
+        return x.cpu().numpy(), y.cpu().numpy()
+
+
+def test_zero_copy_device_batches_equal_copied_ones():
     """Device-resident batches consumed in place (launch arguments re-pointed, one graph per buffer) vs copied into the
     model's own input buffers: identical parameters after a few steps, in graph and in eager mode."""
     import numpy as np
@@ -121,8 +137,9 @@ def test_zero_copy_device_batches_equal_copied_ones(monkeypatch):
     out = {}
     for zc in ('1', '0'):
         for graph in (True, False):
-            monkeypatch.setenv('SEG_ZERO_COPY', zc)
             ds = SyntheticDataSet(2, 188, 3, seed=11, n_batches=3)
+            if zc == '0':
+                ds = _HostOnly(ds)
             m = UNetModel(sess=None, dataset=ds, n_classes=3, input_dims=188, learning_rate=1e-3, log_dir=None, save_dir=None,
                           load_snapshot=False, dtype='bf16', use_graph=graph, seed=3)
             for _ in range(7):
@@ -131,6 +148,8 @@ def test_zero_copy_device_batches_equal_copied_ones(monkeypatch):
             out[(zc, graph)] = (m.store.p.clone(), m.last_loss())
             if zc == '1':
                 assert len(m._slots) == 3          # three dataset buffers were bound in place
+            else:
+                assert not getattr(m, '_slots', None)
     ref = out[('0', False)]
     for k, v in out.items():
         assert torch.equal(v[0], ref[0]) and v[1] == ref[1], k
@@ -315,3 +334,60 @@ def test_bench_four_ranks_one_image_each_rehearsal_over_gloo():
     j = json.loads(lines[0])
     assert j['n_gpus'] == 4 and j['config']['global_batch'] == 4 and j['config']['parallelism'] == 'dp4' and j['scaling'] == 'weak'
     assert j['config']['allreduce']['world'] == 4 and j['value'] > 0 and np.isfinite(j['config']['final_loss'])
+
+
+@pytest.mark.gpu
+def test_compiled_plan_replay_equals_the_interpreter_walk(monkeypatch):
+    """seg_plan_run (one host call per train step: the recorded walk of Plan.run -- launches, event forks, signal forks, held side
+    launches) enqueues the same launches in the same order as the per-launch Python walk: three bf16 U-Net train steps end in
+    bitwise equal parameters and Adam moments, with and without the input re-pointing of a device-resident dataset."""
+    from segmentation_amd import engine as E
+    from segmentation_amd.datasets import ArrayDataSet
+    from segmentation_amd.unet import UNetModel
+    rng = np.random.default_rng(11)
+    x = rng.uniform(0, 1, (3, 2, 188, 188, 3)).astype(np.float32)
+    y = rng.integers(0, 2, (3, 2, 188, 188, 1)).astype(np.uint8)
+    outs = []
+    for compiled in (True, False):
+        monkeypatch.setattr(E, '_PLAN_C', compiled)
+        m = UNetModel(sess=None, dataset=ArrayDataSet(x, y), n_classes=2, input_dims=188, learning_rate=1e-3, log_dir=None, save_dir=None,
+                      load_snapshot=False, dtype='bf16', use_graph=False, seed=7)
+        for _ in range(3):
+            m.train_step()
+        torch.cuda.synchronize()
+        if compiled:
+            cps = m.step_plan.__dict__.get('_compiled', {})
+            assert len(cps) == 1, 'the eager step did not go through seg_plan_run'
+            cp = list(cps.values())[0]
+            kinds = [int(cp.ops[k].kind) for k in range(cp.n)]
+            assert kinds.count(0) >= 70 and (kinds.count(2) >= 10 or kinds.count(1) >= 10), kinds      # launches + signal (or event) forks
+        else:
+            assert not m.step_plan.__dict__.get('_compiled')
+        outs.append((m.store.p.clone(), m.store.m.clone(), m.store.v.clone(), m.last_loss()))
+    (p1, m1, v1, l1), (p0, m0, v0, l0) = outs
+    assert torch.equal(p1, p0) and torch.equal(m1, m0) and torch.equal(v1, v0) and abs(l1 - l0) < 1e-5       # (the reported loss is a float-atomic sum)
+
+
+@pytest.mark.gpu
+def test_last_kernel_name_reports_the_first_layer_instance(monkeypatch):
+    """seg_last_kernel_name(): the first kernel launched since the previous query, as spelled at its launch site -- bench.py labels the
+    first layer with the instance the C side picked (window form for small outputs, float-staged MFMA form otherwise / when forced)."""
+    from segmentation_amd import _lib as L, engine as E
+    import gpu_util as U
+    lib = L.load()
+    layer = E.Layer('f', 'first', 3, [3], 32, 'VALID', True)
+    rng = np.random.default_rng(3)
+    store = U.make_store([layer], L.SEG_BF16, {'f': {'weights': rng.standard_normal(layer.wshape).astype(np.float32), 'biases': np.zeros(32, np.float32)}})
+    net = E.Net(store, 2, L.SEG_BF16, U.dev())
+    xt = torch.rand(2, 40, 40, 3, device=U.dev())
+    out = net.act(38, 38, 32); pooled = net.act(19, 19, 32)
+    for impl, want in (('win', 'conv_first_win_kernel<1,true,true>'), ('old', 'conv_first_mfma_kernel<1>')):
+        monkeypatch.setenv('SEG_FIRST_IMPL', impl); lib.seg_dbg_reload_env()
+        pl = E.Plan('p'); assert net.first_fwd(pl, layer, xt, 40, 40, out, pool=pooled)
+        lib.seg_last_kernel_name()
+        pl.run(U.stream()); U.sync()
+        assert lib.seg_last_kernel_name().decode() == want
+        assert lib.seg_last_kernel_name().decode() == ''                   # (the query clears)
+        rows = pl.run_profiled(U.stream(), torch)
+        assert rows[0][1] == want, rows
+    monkeypatch.delenv('SEG_FIRST_IMPL'); lib.seg_dbg_reload_env()

@@ -41,14 +41,6 @@ def _rand_params(layer, rng, dtype):
     (3, 'VALID', [16], 24, 11, 11, 1, True, 0),          # unpadded channel counts (n_kernels=16 style)
     (1, 'SAME', [96], 4, 7, 9, 2, False, 0),
     (1, 'SAME', [64], 160, 16, 16, 1, True, 0),
-    # the wave-specialised kernel (csrc/conv_sweep.hip; bf16): cfg 100 + fragments per wave (2 / 4 / 6 = 128 / 256 / 384-pixel windows)
-    (3, 'VALID', [64, 32], 64, 35, 37, 2, True, 106),
-    (3, 'VALID', [64, 32], 64, 35, 37, 2, True, 104),
-    (3, 'VALID', [64, 32], 64, 35, 37, 2, True, 102),
-    (3, 'SAME', [64], 96, 19, 33, 3, True, 106),         # zero padding, 32-channel blocks (96 outputs)
-    (3, 'SAME', [128], 64, 9, 11, 2, False, 104),
-    (3, 'VALID', [32], 128, 26, 26, 2, True, 106),       # 24 x 24 output maps: 12 x 24 windows
-    (3, 'VALID', [16], 24, 11, 11, 1, True, 102),        # unpadded channel counts
     (3, 'VALID', [256], 256, 12, 12, 3, True, 0),        # automatic tile class on a deep layer
     # the round-4 kernel (csrc/conv_ring.hip; bf16, 64-channel blocks): cfg 208 = 512-pixel tiles, 204 = 256-pixel tiles; the
     # data gradients of these cases run on it too where they have 64-channel blocks (two-destination form: [64, 64])
@@ -61,19 +53,11 @@ def _rand_params(layer, rng, dtype):
     (3, 'SAME', [32, 32], 64, 97, 140, 3, True, 208),
     (3, 'VALID', [64], 128, 70, 200, 2, True, 208),      # wide maps: the 8 x 64 tile shape
     (3, 'VALID', [192], 64, 10, 10, 5, True, 204),       # 8 x 8 maps: most of a tile is padding
-    (3, 'VALID', [64, 64], 64, 35, 37, 2, True, 209),    # 209 = 4 waves x 8 rows (512-pixel tiles, one wave per SIMD)
-    (3, 'SAME', [64], 128, 19, 33, 3, True, 209),
-    (3, 'VALID', [64], 64, 150, 131, 4, True, 209),
-    (3, 'SAME', [32, 32], 64, 97, 140, 3, True, 209),
-    (3, 'VALID', [64], 128, 70, 200, 2, True, 209),
-    (3, 'VALID', [32], 64, 150, 131, 4, True, 102),      # more tiles than compute units: the persistent walk + tile tickets
-    (3, 'SAME', [32, 32], 64, 97, 140, 3, True, 104),
-    (3, 'VALID', [64], 128, 120, 123, 2, True, 106),
 ])
 def test_conv_fwd_bwd(dtype, case):
     k, padding, segs, cout, H, W, B, relu, cfg = case
     if cfg > 10 and dtype != L.SEG_BF16:
-        pytest.skip('direct-to-LDS / wave-specialised variants are bf16 only')
+        pytest.skip('direct-to-LDS / persistent variants are bf16 only')
     rng = np.random.default_rng(k * 7919 + sum(segs) * 31 + cout * 17 + H * 5 + W + cfg)
     layer = E.Layer('c', 'conv', k, segs, cout, padding, relu)
     p = {'c': _rand_params(layer, rng, dtype)}
@@ -95,10 +79,8 @@ def test_conv_fwd_bwd(dtype, case):
     out = net.act(Ho, Wo, cout)
     plan = E.Plan('t')
     net.conv_fwd(plan, layer, srcs, H, W, out, cfg=cfg)
-    if cfg in (204, 208, 209):
-        assert plan.kernel_name(0).startswith('conv_ring_kernel<%s,' % {204: '8,4,2,2', 208: '8,4,1,4', 209: '4,8,1,4'}[cfg]), plan.kernel_name(0)
-    elif cfg >= 100:
-        assert plan.kernel_name(0).startswith('conv_sweep_kernel<%d,' % (cfg - 100)), plan.kernel_name(0)
+    if cfg in (204, 208):
+        assert plan.kernel_name(0).startswith('conv_ring_kernel<%s,' % {204: '8,4,2,2', 208: '8,4,1,4'}[cfg]), plan.kernel_name(0)
     plan.run(U.stream()); U.sync()
     ref = ops.conv2d(x, p['c']['weights'], p['c']['biases'], padding, 1, relu)
     got = U.read_act(out)
@@ -420,8 +402,7 @@ def test_wgrad_sweep(case):
 
 
 @pytest.mark.parametrize('cin,cout,H,W,padding,cfg', [(64, 64, 23, 37, 'VALID', 0), (32, 32, 34, 34, 'SAME', 0), (128, 96, 19, 50, 'VALID', 0),
-                                                       (64, 64, 23, 37, 'VALID', 208), (128, 128, 34, 70, 'SAME', 204), (32, 64, 61, 59, 'VALID', 208),
-                                                       (64, 128, 45, 70, 'VALID', 209), (32, 64, 61, 59, 'SAME', 209)])
+                                                       (64, 64, 23, 37, 'VALID', 208), (128, 128, 34, 70, 'SAME', 204), (32, 64, 61, 59, 'VALID', 208)])
 def test_conv_with_fused_maxpool(cin, cout, H, W, padding, cfg):
     """seg_conv_desc.pool: same activation bits as the plain launch, pooled map == 2x2 max-pool of those bits."""
     dtype = L.SEG_BF16
@@ -692,7 +673,8 @@ def test_batch_norm_statistics_from_the_producing_launch(which, cout, H, B):
 def test_conv_first(dtype, pad, cin, cout, H, impl, relu, monkeypatch):
     if dtype != L.SEG_BF16 and (impl == 'old' or not relu):
         pytest.skip('the two MFMA forms of the first layer are bf16 kernels')
-    monkeypatch.setenv('SEG_FIRST_IMPL', impl)         # bf16: the bf16-staged window kernel / the float-staged one (read per launch)
+    monkeypatch.setenv('SEG_FIRST_IMPL', impl)         # bf16: the bf16-staged window kernel / the float-staged one
+    L.load().seg_dbg_reload_env()                      # (the library reads its switches once)
     B, W = 2, H + 3
     rng = np.random.default_rng(cout + H)
     layer = E.Layer('f', 'first', 3, [cin], cout, 'VALID' if pad == 0 else 'SAME', relu)
