@@ -441,6 +441,10 @@ class BaseModel(object):
                 else:
                     self.pg.wait_all()
 
+            # With real collectives the walk stays the per-launch Python one: replayed through seg_plan_run the host runs ~0.2 ms further
+            # ahead, and with RCCL's stream as the fifth on four hardware queues the deeper queues block each other -- 1.34 against
+            # 1.09 ms per C2 step with a one-rank group (profiles/r04_dp_overhead.txt).  Without collectives (world 1) the replay is used.
+            on_marker.compiled_ok = not self.pg.tuned
             self.dp_step_plan.run(self._stream(), self._side, flavor=self._flavor(), on_marker=on_marker)
             self._packed_dirty = True
             self._loss_is_sum = True
@@ -487,7 +491,7 @@ class BaseModel(object):
             for i in range(min(nb, len(evs) - 1)):
                 us[i] += evs[i].elapsed_time(evs[i + 1]) * 1e3 / len(probe)
         return {'buckets_mb': [round((hi - lo) * 4 / 1e6, 3) for _, (lo, hi) in self.bwd_segments],
-                'cuts': list(getattr(self, 'dp_cuts_used', [])), 'exposed_us': [round(u, 1) for u in us],
+                'cuts': list(getattr(self, 'dp_cuts_used', [])), 'main_stream_events': getattr(self, '_dp_main_events', None), 'exposed_us': [round(u, 1) for u in us],
                 'exposed_total_us': round(sum(us), 1), 'world': self.pg.world}
 
     def last_loss(self):

@@ -496,7 +496,7 @@ class Plan(object):
             return
         main = torch.cuda.current_stream()
         capturing = torch.cuda.is_current_stream_capturing()
-        if _PLAN_C and not capturing and join_into is None:
+        if _PLAN_C and not capturing and join_into is None and (on_marker is None or getattr(on_marker, 'compiled_ok', False)):
             # the whole walk below was recorded once (forks, signal forks, held launches and all) and is replayed by ONE call into
             # the library (seg_plan_run): ~130 interpreter iterations + ctypes calls per train step become one -- one call per
             # stretch between two data-parallel markers when there is a marker callback
