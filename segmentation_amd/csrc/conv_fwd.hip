@@ -25,6 +25,7 @@ struct ConvK {          // kernel-side copy of the descriptor (trivially copyabl
   seg_conv_desc d;
   int tiles_x, tiles_y; // spatial tiles per image
   int nchunks0, nchunks; // K chunks from src0 / total
+  int lin_tr, lin_tc;   // linearised tile (conv_fwd_kernel<..., LIN>): rows x columns of the window, lin_tr * lin_tc <= 128 pixel slots
 };
 
 // ---- epilogue: bias, ReLU, ReLU-grad mask, store 8 channels per lane ----
@@ -98,7 +99,7 @@ struct EpiPre {
 };
 
 template <typename T, int TH, int TW, int BN, int WM, int FM, int FN>
-SEG_DEV void epi_issue(const seg_conv_desc& d, const EpiCtx<FN / 2>& E, int b, int oy0, int ox0, int wm, int lr, EpiPre<T, FN / 2, FM>& R) {
+SEG_DEV void epi_issue(const seg_conv_desc& d, const EpiCtx<FN / 2>& E, int b, int oy0, int ox0, int wm, int lr, EpiPre<T, FN / 2, FM>& R, int lin_tc = 0, int lin_n = 0) {
   constexpr int BM = TH * TW, NJ = FN / 2;
   const int sc = d.up2 ? 2 : 1;
   const T* mbase = reinterpret_cast<const T*>(d.mask.ptr) + ((int64_t)(b * d.mask.H + d.mask.oy) * d.mask.W + d.mask.ox) * d.mask.cs + d.mask.coff;
@@ -107,8 +108,9 @@ SEG_DEV void epi_issue(const seg_conv_desc& d, const EpiCtx<FN / 2>& E, int b, i
 #pragma unroll
   for (int fm = 0; fm < FM; ++fm) {
     const int m = wm * (BM / WM) + fm * 16 + lr;
-    const int oy = oy0 + m / TW, ox = ox0 + m % TW;
-    const bool ok = oy < d.Ho && ox < d.Wo;
+    // (lin_tc > 0: the linearised tile -- slot m is pixel (m / lin_tc, m % lin_tc) of the window, slots >= lin_n are padding)
+    const int oy = oy0 + (lin_tc > 0 ? m / lin_tc : m / TW), ox = ox0 + (lin_tc > 0 ? m % lin_tc : m % TW);
+    const bool ok = oy < d.Ho && ox < d.Wo && (lin_tc == 0 || m < lin_n);
     R.poff_d[fm] = ok ? (sc * oy * d.dst.W + sc * ox) * d.dst.cs : -1;
     poff_m[fm] = (sc * oy * d.mask.W + sc * ox) * d.mask.cs;
   }
@@ -289,7 +291,12 @@ SEG_DEV bool splitk_combine(const seg_conv_desc& d, f32x4 (&acc2)[FN][FM], int t
 // 128-pixel bf16 tiles (3 workgroups of 48 KB with 64 output channels, 4 of 30 KB with 32); the f32 parity mode is left alone.
 constexpr int conv_min_waves(int dt, int bm, int bn) { return dt != 1 || bm != 128 ? 1 : (bn == 64 ? 3 : 4); }
 
-template <int DT, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, bool POOL = false>
+// LIN (3x3 / stride 1 only): the 128 pixel slots of the tile are the pixels of a lin_tr x lin_tc window in row-major order, the
+// window shape chosen per layer at launch (lin_pick) -- a 10 x 10 map is ONE tile (78 % useful slots) instead of two 8 x 16 tiles
+// (39 %), a 26 x 26 map 6 tiles of 9 x 13 instead of 8.  The patch area of LDS is sized for LIN_CAP pixels.
+constexpr int LIN_CAP = 224;
+
+template <int DT, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, bool POOL = false, bool LIN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_min_waves(DT, TH * TW, BN))))
 void conv_fwd_kernel(const ConvK P) {
 #ifdef SEG_ABLATE
@@ -299,11 +306,15 @@ void conv_fwd_kernel(const ConvK P) {
   using T = typename DtSel<DT>::type;
   using TT = Tr<T>;
   constexpr int BM = TH * TW;
-  constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW, NPIX = PH * PW;
+  static_assert(!LIN || (S == 1 && KH == 3 && KW == 3 && !POOL && TH * TW == 128), "linearised tiles: 3x3 / s1, 128 slots");
+  constexpr int PH = (TH - 1) * S + KH, PW_C = (TW - 1) * S + KW, NPIX = LIN ? LIN_CAP : PH * PW_C;
   constexpr int NT = KH * KW;
   constexpr int PIECES = TT::PIECES, EPP = TT::EPP, RSTR = TT::RSTR;
   constexpr int PATCH_BYTES = ((NPIX * RSTR + 15) / 16) * 16;
   constexpr int NPP = (NPIX * PIECES + 255) / 256;       // patch pieces per thread
+  const int PW = LIN ? P.lin_tc + 2 : PW_C;              // patch row length in pixels
+  const int npix = LIN ? (P.lin_tr + 2) * PW : NPIX;     // patch pixels in use
+  const int lin_tc = LIN ? P.lin_tc : 0, lin_n = LIN ? P.lin_tr * P.lin_tc : 0;
   constexpr int NWP = (NT * BN * PIECES + 255) / 256;    // weight pieces per thread
   constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
   static_assert(WM * WN == 4, "4 waves");
@@ -325,7 +336,7 @@ void conv_fwd_kernel(const ConvK P) {
   int t = blockIdx.x;
   const int tx = t % P.tiles_x; t /= P.tiles_x;
   const int ty = t % P.tiles_y; const int b = t / P.tiles_y;
-  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int oy0 = ty * (LIN ? P.lin_tr : TH), ox0 = tx * (LIN ? P.lin_tc : TW);
   const int n0 = blockIdx.y * BN;                 // within this launch's n range
   select_dst(d, n0);
   const float bias_r = bias_fetch<BN>(d, n0, tid);
@@ -339,7 +350,7 @@ void conv_fwd_kernel(const ConvK P) {
   for (int i = 0; i < NPP; ++i) {
     const int idx = tid + i * 256;
     p_lds[i] = -1; p_off0[i] = -1; p_off1[i] = -1;
-    if (idx < NPIX * PIECES) {
+    if (idx < npix * PIECES) {
       const int q = idx / PIECES, h = idx % PIECES;
       const int py = q / PW, px = q % PW;
       const int iy = oy0 * S - d.pad_t + py, ix = ox0 * S - d.pad_l + px;
@@ -404,7 +415,8 @@ void conv_fwd_kernel(const ConvK P) {
 #pragma unroll
   for (int fm = 0; fm < FM; ++fm) {
     const int m = wm * (BM / WM) + fm * 16 + lr;
-    const int py = (m / TW) * S, px = (m % TW) * S;
+    int py = (m / TW) * S, px = (m % TW) * S;
+    if constexpr (LIN) { const int mm = m < lin_n ? m : 0; py = mm / lin_tc; px = mm % lin_tc; }     // (padding slots read pixel 0: finite, never stored)
 #pragma unroll
     for (int u = 0; u < KH; ++u)
 #pragma unroll
@@ -468,7 +480,7 @@ void conv_fwd_kernel(const ConvK P) {
   EpiCtx<FN / 2> epi;
   epi_setup<BN, WN, FN / 2>(d, n0, wn, g, epi, sB);
   EpiPre<T, FN / 2, FM> pre;
-  epi_issue<T, TH, TW, BN, WM, FM, FN>(d, epi, b, oy0, ox0, wm, lr, pre);
+  epi_issue<T, TH, TW, BN, WM, FM, FN>(d, epi, b, oy0, ox0, wm, lr, pre, lin_tc, lin_n);
   if (!ABL(4)) compute();
   if (ksn > 1) {
     int* s_flag = reinterpret_cast<int*>(sP);       // (the patch is dead: every wave is behind its last LDS read after the barrier inside)
@@ -673,25 +685,51 @@ inline int splitk_grid(const ConvK& P, int* gz) {
   return SEG_OK;
 }
 
-template <typename T, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, bool POOL = false>
+// Window of a linearised tile for an Ho x Wo map: nx column strips of tc = ceil(Wo / nx) pixels, tr rows with tr * tc <= 128 slots
+// and (tr + 2) * (tc + 2) <= LIN_CAP patch pixels, rows balanced over the strips; fewest tiles wins, then the smaller halo.
+inline long lin_pick(int Ho, int Wo, int* tr_out, int* tc_out) {
+  long best = -1, best_halo = 0;
+  for (int nx = 1; nx <= 16; ++nx) {
+    const int tc = cdiv(Wo, nx);
+    if (tc > 128) continue;
+    int tr = 128 / tc; if (tr > Ho) tr = Ho;
+    while (tr >= 1 && (tr + 2) * (tc + 2) > LIN_CAP) --tr;
+    if (tr < 1) continue;
+    const int ny = cdiv(Ho, tr);
+    tr = cdiv(Ho, ny);
+    const long tiles = (long)ny * nx, halo = tiles * (tr + 2) * (tc + 2);
+    if (best < 0 || tiles < best || (tiles == best && halo < best_halo)) { best = tiles; best_halo = halo; *tr_out = tr; *tc_out = tc; }
+    if (tc <= 8) break;
+  }
+  return best < 0 ? -1 : best * 128;
+}
+
+template <typename T, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, bool POOL = false, bool LIN = false>
 int launch_cfg(const ConvK& P0, hipStream_t st) {
   using TT = Tr<T>;
   if (g_name_out) {
     // (the fused-pool instance reports under the same name: same tile, same main loop, one more store per window)
-    snprintf(g_name_out, g_name_cap, "conv_fwd_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, WM, WN, KH, KW, S);
+    if (LIN) snprintf(g_name_out, g_name_cap, "conv_fwd_kernel<%s,lin128,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BN, WM, WN, KH, KW, S);
+    else snprintf(g_name_out, g_name_cap, "conv_fwd_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, WM, WN, KH, KW, S);
     return SEG_OK;
   }
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + KW;
-  constexpr int PATCH_BYTES = ((PH * PW * TT::RSTR + 15) / 16) * 16;
+  constexpr int PATCH_BYTES = (((LIN ? LIN_CAP : PH * PW) * TT::RSTR + 15) / 16) * 16;
   constexpr int LDS = PATCH_BYTES + KH * KW * BN * TT::RSTR + BN * 4;   // patch, filter rows, bias
   ConvK P = P0;
   P.tiles_x = cdiv(P.d.Wo, TW);
   P.tiles_y = cdiv(P.d.Ho, TH);
+  P.lin_tr = P.lin_tc = 0;
+  if (LIN) {
+    if (lin_pick(P.d.Ho, P.d.Wo, &P.lin_tr, &P.lin_tc) < 0) { seg_set_error("conv: no linearised tile for a %d x %d map", P.d.Ho, P.d.Wo); return SEG_ERR_ARG; }
+    P.tiles_x = cdiv(P.d.Wo, P.lin_tc);
+    P.tiles_y = cdiv(P.d.Ho, P.lin_tr);
+  }
   if (P.d.n_count % BN != 0 || P.d.n_split % BN != 0) { seg_set_error("conv: n_count %d / n_split %d not a multiple of BN %d", P.d.n_count, P.d.n_split, BN); return SEG_ERR_ARG; }
   if (g_plan_out) { g_plan_out->bm = TH * TW; g_plan_out->bn = BN; g_plan_out->wgs = (long)P.d.B * P.tiles_y * P.tiles_x * (P.d.n_count / BN); return SEG_OK; }
   int gz;
   if (int rc = splitk_grid(P, &gz)) return rc;
-  auto kern = conv_fwd_kernel<Tr<T>::DT, TH, TW, BN, WM, WN, KH, KW, S, POOL>;
+  auto kern = conv_fwd_kernel<Tr<T>::DT, TH, TW, BN, WM, WN, KH, KW, S, POOL, LIN>;
   static bool attr_done = false;
   if (!attr_done && LDS > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -770,7 +808,15 @@ int launch_k(const ConvK& P, hipStream_t st) {
       if (best < 0 || cost < best) { best = cost; bi = c; }
     }
     cfg = bi + 1;
-    if (sizeof(T) == 2) {
+    bool lin = false;
+    if constexpr (KH == 3 && KW == 3 && S == 1) {
+      // linearised tiles where the map pads badly into every fixed tile (round 4): at least SEG_CONV_LIN_PCT % (default 13) fewer slots
+      static const int lin_pct = seg_env("SEG_CONV_LIN_PCT") ? atoi(seg_env("SEG_CONV_LIN_PCT")) : 13;
+      int tr, tc;
+      const long sl = lin_pct > 0 ? lin_pick(d.Ho, d.Wo, &tr, &tc) : -1;
+      if (sl > 0 && sl * 100 <= waste(d.Ho, d.Wo, TH_[bi], TW_[bi]) * (100 - lin_pct)) { cfg = BN_[bi] == 64 ? 7 : 8; lin = true; }
+    }
+    if (sizeof(T) == 2 && !lin) {
       // bf16: direct-to-LDS double-buffered variants.  SEG_CONV_MODE: 0 = never, 1 = always, 2 = always + 256-pixel
       // tile on maps >= 32 wide, 3 (default) = only for the 64-pixel tiles, 4 = single-buffered direct-to-LDS everywhere (fastest stand-alone:
       // the host asks for it on the forward pass; in backward the dgrads share the chip with the filter gradients and 3 wins)
@@ -790,6 +836,10 @@ int launch_k(const ConvK& P, hipStream_t st) {
     case 5: return launch_cfg<T, 16, 16, 64, 4, 1, KH, KW, S>(P, st);  // 256 px x 64 ch
     case 6: return launch_cfg<T, 16, 16, 32, 4, 1, KH, KW, S>(P, st);  // 256 px x 32 ch
     default: break;
+  }
+  if constexpr (KH == 3 && KW == 3 && S == 1) {
+    if (cfg == 7) return launch_cfg<T, 8, 16, 64, 4, 1, KH, KW, S, false, true>(P, st);   // 128 linearised slots x 64 ch
+    if (cfg == 8) return launch_cfg<T, 8, 16, 32, 4, 1, KH, KW, S, false, true>(P, st);   // 128 linearised slots x 32 ch
   }
   if (sizeof(T) == 2) {
     switch (cfg) {      // bf16 direct-to-LDS double-buffered variants

@@ -53,6 +53,14 @@ def _rand_params(layer, rng, dtype):
     (3, 'SAME', [32, 32], 64, 97, 140, 3, True, 208),
     (3, 'VALID', [64], 128, 70, 200, 2, True, 208),      # wide maps: the 8 x 64 tile shape
     (3, 'VALID', [192], 64, 10, 10, 5, True, 204),       # 8 x 8 maps: most of a tile is padding
+    # linearised tiles (conv_fwd_kernel<.., LIN>: cfg 7 = 128 slots x 64 channels, 8 = x 32); the data gradients run on cfg 8
+    (3, 'VALID', [64], 64, 12, 12, 3, True, 7),          # 10 x 10 map: one tile, 28 padding slots
+    (3, 'VALID', [64, 32], 64, 28, 28, 2, True, 7),      # 26 x 26: 2 x 3 windows of 9 x 13; two-destination data gradient
+    (3, 'SAME', [32], 96, 38, 38, 2, True, 8),
+    (3, 'VALID', [64], 64, 59, 61, 2, False, 7),         # column strips
+    (3, 'SAME', [64], 32, 5, 131, 1, True, 8),           # one-row windows
+    (3, 'VALID', [32], 64, 3, 3, 2, True, 8),            # a single output pixel
+    (3, 'VALID', [64], 64, 150, 9, 1, True, 7),          # tall and narrow: 18-row windows
 ])
 def test_conv_fwd_bwd(dtype, case):
     k, padding, segs, cout, H, W, B, relu, cfg = case
@@ -81,6 +89,8 @@ def test_conv_fwd_bwd(dtype, case):
     net.conv_fwd(plan, layer, srcs, H, W, out, cfg=cfg)
     if cfg in (204, 208):
         assert plan.kernel_name(0).startswith('conv_ring_kernel<%s,' % {204: '8,4,2,2', 208: '8,4,1,4'}[cfg]), plan.kernel_name(0)
+    if cfg in (7, 8):
+        assert ',lin128,%d,' % {7: 64, 8: 32}[cfg] in plan.kernel_name(0), plan.kernel_name(0)
     plan.run(U.stream()); U.sync()
     ref = ops.conv2d(x, p['c']['weights'], p['c']['biases'], padding, 1, relu)
     got = U.read_act(out)
@@ -105,7 +115,7 @@ def test_conv_fwd_bwd(dtype, case):
         dsrc_acts.append(da)
     store.g.zero_()
     bplan = E.Plan('b')
-    net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs, cfg=cfg if cfg >= 100 else 0)
+    net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs, cfg=cfg if cfg >= 100 else (8 if cfg in (7, 8) else 0))
     net.flush_reduce(bplan)
     bplan.run(U.stream()); U.sync()
     dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (k, k), padding, 1)
@@ -121,6 +131,18 @@ def test_conv_fwd_bwd(dtype, case):
         assert U.rel_err(U.read_act(dsrc_acts[i]), want) < U.tol(dtype), 'dgrad seg %d' % i
         assert U.pad_channels_zero(dsrc_acts[i])
         c0 += c
+
+
+@pytest.mark.parametrize('H,W,lin', [(12, 12, True), (28, 28, True), (18, 18, False), (26, 26, False), (61, 61, False)])
+def test_conv_tile_choice_takes_linearised_tiles_where_fixed_ones_pad_badly(H, W, lin):
+    """automatic tile choice (cfg 0): a 10 x 10 / 26 x 26 output runs on the linearised tile, maps that fill the 8 x 8 / 8 x 16 tiles do not"""
+    layer = E.Layer('c', 'conv', 3, [64], 64, 'VALID', True)
+    store = U.make_store([layer], L.SEG_BF16, {'c': _rand_params(layer, np.random.default_rng(0), L.SEG_BF16)})
+    net = E.Net(store, 4, L.SEG_BF16, U.dev())
+    a = net.act(H, W, 64); out = net.act(H - 2, W - 2, 64)
+    plan = E.Plan('t')
+    net.conv_fwd(plan, layer, [(a, 0, 0)], H, W, out)
+    assert ('lin128' in plan.kernel_name(0)) == lin, plan.kernel_name(0)
 
 
 @pytest.mark.parametrize('dtype', DT)
