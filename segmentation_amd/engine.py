@@ -585,10 +585,15 @@ class Plan(object):
                         fire_markers()
                 continue
             if fn is None and name == 'join_all':      # marker: the main stream waits for every side stream used so far
+                probe = getattr(self, 'probe', None) if not recording else None      # (tools/tail_probe.py: how long does the main stream idle here?)
+                if probe is not None:
+                    e_ = torch.cuda.Event(enable_timing=True); e_.record(main); probe.append(e_)
                 for o_ in used.values():
                     join(o_)
                 if aux_used:
                     join(aux)
+                if probe is not None:
+                    e_ = torch.cuda.Event(enable_timing=True); e_.record(main); probe.append(e_)
                 continue
             if fn is None and name == 'join_wgrad':    # marker: ... for the filter-gradient streams only (the aux stream keeps running)
                 for o_ in used.values():
@@ -1195,6 +1200,10 @@ class Net(object):
         w.n_log = layer.cout
         w.dw = self.store.g_ptr(layer.w_off); w.dtype = self.dtype; w.cfg = 0
         w.bias_mode = 1; w.db = self.store.g_ptr(layer.b_off); w.bias_n = layer.cout
+        if self.side_enabled:
+            # the last filter gradient of the backward pass and bandwidth-bound: nothing is left on the critical stream to share the chip
+            # with (256^2 x 32 images alone: 109 -> 68 us against the 64-workgroup target of the other layers)
+            w.target_wgs = 256
         self._wgrad_ws(w, plan, ksplit)
         fl = 2 * self.B * Ho * Wo * 9 * layer.cin * layer.cout
         self._wg_bytes = self.B * (H * W * layer.cin * 4 + Ho * Wo * layer.cout * self.es) + 9 * layer.cin * layer.cout * 4
