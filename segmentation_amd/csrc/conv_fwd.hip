@@ -473,14 +473,17 @@ void conv_fwd_kernel(const ConvK P) {
     prefetch(c + 1);
     if (!ABL(4)) compute();
   }
-  // last chunk: nothing left to prefetch, so the epilogue's mask / accumulate loads fly during its MFMAs instead
-  __syncthreads();
-  if (!ABL(16)) commit();
-  __syncthreads();
+  // last chunk: nothing left to prefetch, so the epilogue's mask / accumulate loads fly during its commit and its MFMAs instead.
+  // (Issued BEFORE the commit waits for the chunk's data: a layer with a single K chunk -- the 32-channel data gradients of the
+  // full-resolution maps, bandwidth-bound -- then has its mask round trip in flight together with the patch, not behind it.)
   EpiCtx<FN / 2> epi;
   epi_setup<BN, WN, FN / 2>(d, n0, wn, g, epi, sB);
   EpiPre<T, FN / 2, FM> pre;
-  epi_issue<T, TH, TW, BN, WM, FM, FN>(d, epi, b, oy0, ox0, wm, lr, pre, lin_tc, lin_n);
+  if constexpr (!LIN) epi_issue<T, TH, TW, BN, WM, FM, FN>(d, epi, b, oy0, ox0, wm, lr, pre, lin_tc, lin_n);
+  __syncthreads();
+  if (!ABL(16)) commit();
+  __syncthreads();
+  if constexpr (LIN) epi_issue<T, TH, TW, BN, WM, FM, FN>(d, epi, b, oy0, ox0, wm, lr, pre, lin_tc, lin_n);   // (the linearised instances have no registers to spare across the commit)
   if (!ABL(4)) compute();
   if (ksn > 1) {
     int* s_flag = reinterpret_cast<int*>(sP);       // (the patch is dead: every wave is behind its last LDS read after the barrier inside)

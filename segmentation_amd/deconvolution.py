@@ -87,6 +87,9 @@ def deconv_sizes(H):
     return s
 
 
+_AUX_PACK = os.environ.get('SEG_PACK_ON_AUX', '0') == '1'
+
+
 class DeconvModel(BaseModel):
     def __init__(self,
                  sess=None,
@@ -298,8 +301,8 @@ class DeconvModel(BaseModel):
         Ly, nc = self.store.layers, self.n_classes
         fwd = self.fwd_plan = E.Plan('fwd')
         self.loss_buf = self.store.loss_slot()          # (behind the gradient arena: reduced with the last bucket under data parallelism)
-        net.step_begin(fwd, self.loss_buf)
-        net.pack(fwd, aux=True)
+        net.step_begin(fwd, self.loss_buf, aux=_AUX_PACK or self.pg.tuned)
+        net.pack(fwd, aux=_AUX_PACK or self.pg.tuned)
         A, Y, P, sz = self._emit_forward(net, fwd, self.input_x, H, W, bn_training=True, update_moving=True, dropout_step=True)
         self.acts, self.bn_out = A, Y
         self.out_hw, self.label_off = (H, W), (0, 0)

@@ -220,6 +220,9 @@ def _step_wgrad_wgs(input_pixels):
     return 64 if input_pixels is not None and input_pixels <= 2500000 else 0
 
 
+_DEBUG_SKIP = tuple(x for x in os.environ.get('SEG_DEBUG_SKIP', '').split(',') if x)
+
+
 def _fork(src, dst):
     """cross-stream dependency: `dst waits for what src holds now` (under stream capture this becomes a graph edge)"""
     ev = torch.cuda.Event(); ev.record(src); dst.wait_event(ev)
@@ -474,6 +477,8 @@ class Plan(object):
         main stream at its program position (so everything launched before it is its dependency) and the side
         streams are joined back into the main stream at the end -- under hipGraph capture this becomes a fork/join."""
         sp = C.c_void_p(stream)
+        if _DEBUG_SKIP:
+            skip = tuple(skip) + _DEBUG_SKIP       # (timing experiments: what would the step cost without these launches?  results are garbage)
         if not side:
             dbg = os.environ.get('SEG_DEBUG_SYNC')        # name every launch on stderr and synchronise after it (fault hunting)
             for i_, (name, fn, args) in enumerate(self.ops):

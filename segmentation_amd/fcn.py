@@ -43,6 +43,9 @@ def fcn_layers(n_classes, n_kernels, input_channel, fcn_type):
     return [ls[n] for n in order]
 
 
+_AUX_PACK = os.environ.get('SEG_PACK_ON_AUX', '0') == '1'
+
+
 class FCNModel(BaseModel):
     SHARE_AUX_STREAM = False     # (its forward starts with the input im2col on a side stream: a fourth stream measured 1-2 % faster)
 
@@ -173,8 +176,8 @@ class FCNModel(BaseModel):
         Ly, nc = self.store.layers, self.n_classes
         fwd = self.fwd_plan = E.Plan('fwd')
         self.loss_buf = self.store.loss_slot()          # (behind the gradient arena: reduced with the last bucket under data parallelism)
-        net.step_begin(fwd, self.loss_buf)     # aux stream: global_step += 1, loss accumulator = 0
-        net.pack(fwd, aux=True)            # refresh the packed weights after the previous Adam step, beside conv1
+        net.step_begin(fwd, self.loss_buf, aux=_AUX_PACK or self.pg.tuned)     # aux stream: global_step += 1, loss accumulator = 0
+        net.pack(fwd, aux=_AUX_PACK or self.pg.tuned)            # refresh the packed weights after the previous Adam step, beside conv1
         col = net.first_im2col(fwd, Ly['conv1'], self.input_x, H, W)         # side stream, overlaps the forward pass
         # The last up-sampling, the loss and dlogits are ONE launch (no 268 MB float logits tensor at 512^2 x 21 classes); the
         # adversary needs the logits as a tensor and keeps the separate launches; keep_logits=True also stores them (y_hat, tests).

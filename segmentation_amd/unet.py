@@ -74,6 +74,9 @@ def unet_sizes(n):
     return s
 
 
+_AUX_PACK = os.environ.get('SEG_PACK_ON_AUX', '0') == '1'
+
+
 class UNetModel(BaseModel):
     def __init__(self,
                  sess=None,
@@ -218,13 +221,13 @@ class UNetModel(BaseModel):
         Ly = self.store.layers
         fwd = self.fwd_plan = E.Plan('fwd')
         self.loss_buf = self.store.loss_slot()          # (behind the gradient arena: reduced with the last bucket under data parallelism)
-        net.step_begin(fwd, self.loss_buf)     # aux stream: global_step += 1, loss accumulator = 0
+        net.step_begin(fwd, self.loss_buf, aux=_AUX_PACK or self.pg.tuned)     # aux stream: global_step += 1, loss accumulator = 0
         # refresh the packed weights after the previous Adam step, beside conv1_1.  (Round 4 tried to keep the first layer -- HBM-bound,
         # 49.9 us in the step against 23 alone -- out of the re-pack's shadow: the few filters conv1_2 .. conv3_2 need packed beside
         # conv1_1, the bulk on a filter-gradient stream beside conv2_1 .. conv3_2.  The step got 0.7 % SLOWER at C2 and 1 % at 512^2
         # (profiles/r04_ab_split_pack_*.txt): the 62 MB have to share the memory with something, and conv2_x are no less
         # bandwidth-hungry than conv1_1.  Removed.)
-        net.pack(fwd, aux=True)
+        net.pack(fwd, aux=_AUX_PACK or self.pg.tuned)
         cols = []       # im2col of the input for conv1_1's filter gradient: side stream, right after conv1_1 (both are
         #                 bandwidth-bound), overlapping the rest of the forward pass
         fuse_head = (E.rup(Ly['output'].cin) in (32, 64) and self.n_classes <= 32 and os.environ.get('SEG_FUSE_HEAD', '1') != '0' and
