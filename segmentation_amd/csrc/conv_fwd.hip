@@ -98,7 +98,8 @@ struct EpiPre {
   Vec8<T> mk[NJ][FM], old[NJ][FM];
 };
 
-template <typename T, int TH, int TW, int BN, int WM, int FM, int FN>
+// JSEL >= 0: only channel-fragment pair JSEL is handled (the other one goes to another destination: conv_fwd_kernel<.., SPLIT>)
+template <typename T, int TH, int TW, int BN, int WM, int FM, int FN, int JSEL = -1>
 SEG_DEV void epi_issue(const seg_conv_desc& d, const EpiCtx<FN / 2>& E, int b, int oy0, int ox0, int wm, int lr, EpiPre<T, FN / 2, FM>& R, int lin_tc = 0, int lin_n = 0) {
   constexpr int BM = TH * TW, NJ = FN / 2;
   const int sc = d.up2 ? 2 : 1;
@@ -119,19 +120,19 @@ SEG_DEV void epi_issue(const seg_conv_desc& d, const EpiCtx<FN / 2>& E, int b, i
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int fm = 0; fm < FM; ++fm)
-        if (E.on[j] && R.poff_d[fm] >= 0) R.mk[j][fm].load(mbase + poff_m[fm] + (E.ua[j] * d.mask.W + E.uc[j]) * d.mask.cs + E.co[j]);
+        if ((JSEL < 0 || j == JSEL) && E.on[j] && R.poff_d[fm] >= 0) R.mk[j][fm].load(mbase + poff_m[fm] + (E.ua[j] * d.mask.W + E.uc[j]) * d.mask.cs + E.co[j]);
   }
   if (d.accum != 0) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int fm = 0; fm < FM; ++fm)
-        if (E.on[j] && R.poff_d[fm] >= 0)
+        if ((JSEL < 0 || j == JSEL) && E.on[j] && R.poff_d[fm] >= 0)
           R.old[j][fm].load(reinterpret_cast<const T*>(d.dst.ptr) + R.dbase + R.poff_d[fm] + (E.ua[j] * d.dst.W + E.uc[j]) * d.dst.cs + E.co[j]);
   }
 }
 
-template <typename T, int TH, int TW, int BN, int WM, int WN, int FM, int FN, bool POOL = false>
+template <typename T, int TH, int TW, int BN, int WM, int WN, int FM, int FN, bool POOL = false, int JSEL = -1>
 SEG_DEV void conv_epilogue(const seg_conv_desc& d, f32x4 (&acc)[FN][FM], const EpiCtx<FN / 2>& E, const EpiPre<T, FN / 2, FM>& R, int b, int oy0, int ox0, int wm, int lr) {
   constexpr int NJ = FN / 2;
   const int64_t dbase = R.dbase;
@@ -174,7 +175,7 @@ SEG_DEV void conv_epilogue(const seg_conv_desc& d, f32x4 (&acc)[FN][FM], const E
   }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    if (!E.on[j]) continue;
+    if ((JSEL >= 0 && j != JSEL) || !E.on[j]) continue;
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
       if (poff_d[fm] < 0) continue;
@@ -296,7 +297,10 @@ constexpr int conv_min_waves(int dt, int bm, int bn) { return dt != 1 || bm != 1
 // (39 %), a 26 x 26 map 6 tiles of 9 x 13 instead of 8.  The patch area of LDS is sized for LIN_CAP pixels.
 constexpr int LIN_CAP = 224;
 
-template <int DT, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, bool POOL = false, bool LIN = false>
+// SPLIT (two-destination data gradient of a [32 | 32]-channel concat, n_split = 32 = BN / 2): ONE 64-channel block computes both
+// halves from one patch -- channel-fragment pair 0 goes to dst / mask, pair 1 to dst1 / mask1 -- instead of two 32-channel blocks
+// that each stage the same patch (conv9_1's data gradient: one K chunk, bandwidth-bound).
+template <int DT, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, bool POOL = false, bool LIN = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_min_waves(DT, TH * TW, BN))))
 void conv_fwd_kernel(const ConvK P) {
 #ifdef SEG_ABLATE
@@ -338,7 +342,8 @@ void conv_fwd_kernel(const ConvK P) {
   const int ty = t % P.tiles_y; const int b = t / P.tiles_y;
   const int oy0 = ty * (LIN ? P.lin_tr : TH), ox0 = tx * (LIN ? P.lin_tc : TW);
   const int n0 = blockIdx.y * BN;                 // within this launch's n range
-  select_dst(d, n0);
+  static_assert(!SPLIT || (BN == 64 && WN == 1 && !POOL && !LIN), "split destinations: the 64-channel block with both fragment pairs in every wave");
+  if constexpr (!SPLIT) select_dst(d, n0);
   const float bias_r = bias_fetch<BN>(d, n0, tid);
 
   // ---- per-thread staging descriptors (constant over the K loop) ----
@@ -479,11 +484,32 @@ void conv_fwd_kernel(const ConvK P) {
   EpiCtx<FN / 2> epi;
   epi_setup<BN, WN, FN / 2>(d, n0, wn, g, epi, sB);
   EpiPre<T, FN / 2, FM> pre;
-  if constexpr (!LIN) epi_issue<T, TH, TW, BN, WM, FM, FN>(d, epi, b, oy0, ox0, wm, lr, pre, lin_tc, lin_n);
+  if constexpr (SPLIT) {
+    seg_conv_desc d1 = d;                            // the second destination, addressed like select_dst does for whole blocks
+    d1.dst = d.dst1; d1.dst.coff -= d.n_split;
+    d1.mask = d.mask1; d1.mask.coff -= d.n_split;
+    EpiPre<T, FN / 2, FM> pre1;
+    epi_issue<T, TH, TW, BN, WM, FM, FN, 0>(d, epi, b, oy0, ox0, wm, lr, pre);
+    epi_issue<T, TH, TW, BN, WM, FM, FN, 1>(d1, epi, b, oy0, ox0, wm, lr, pre1);
+    __syncthreads();
+    commit();
+    __syncthreads();
+    compute();
+    if (ksn > 1) {
+      int* s_flag = reinterpret_cast<int*>(sP);
+      if (!splitk_combine<FN, FM>(d, acc, (int)(blockIdx.x + gridDim.x * blockIdx.y), kz, tid, 256, s_flag)) return;
+    }
+    epi_bias<BN, WN, FN / 2>(sB, wn, g, epi);
+    conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN, false, 0>(d, acc, epi, pre, b, oy0, ox0, wm, lr);
+    conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN, false, 1>(d1, acc, epi, pre1, b, oy0, ox0, wm, lr);
+    return;
+  }
+  constexpr bool EARLY = !LIN && sizeof(T) == 2;    // (the linearised and the f32 instances have no registers to spare across the commit: 264 VGPRs)
+  if constexpr (EARLY) epi_issue<T, TH, TW, BN, WM, FM, FN>(d, epi, b, oy0, ox0, wm, lr, pre, lin_tc, lin_n);
   __syncthreads();
   if (!ABL(16)) commit();
   __syncthreads();
-  if constexpr (LIN) epi_issue<T, TH, TW, BN, WM, FM, FN>(d, epi, b, oy0, ox0, wm, lr, pre, lin_tc, lin_n);   // (the linearised instances have no registers to spare across the commit)
+  if constexpr (!EARLY) epi_issue<T, TH, TW, BN, WM, FM, FN>(d, epi, b, oy0, ox0, wm, lr, pre, lin_tc, lin_n);
   if (!ABL(4)) compute();
   if (ksn > 1) {
     int* s_flag = reinterpret_cast<int*>(sP);       // (the patch is dead: every wave is behind its last LDS read after the barrier inside)
@@ -707,12 +733,13 @@ inline long lin_pick(int Ho, int Wo, int* tr_out, int* tc_out) {
   return best < 0 ? -1 : best * 128;
 }
 
-template <typename T, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, bool POOL = false, bool LIN = false>
+template <typename T, int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, bool POOL = false, bool LIN = false, bool SPLIT = false>
 int launch_cfg(const ConvK& P0, hipStream_t st) {
   using TT = Tr<T>;
   if (g_name_out) {
     // (the fused-pool instance reports under the same name: same tile, same main loop, one more store per window)
-    if (LIN) snprintf(g_name_out, g_name_cap, "conv_fwd_kernel<%s,lin128,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BN, WM, WN, KH, KW, S);
+    if (SPLIT) snprintf(g_name_out, g_name_cap, "conv_fwd_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,split>", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, WM, WN, KH, KW, S);
+    else if (LIN) snprintf(g_name_out, g_name_cap, "conv_fwd_kernel<%s,lin128,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BN, WM, WN, KH, KW, S);
     else snprintf(g_name_out, g_name_cap, "conv_fwd_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, WM, WN, KH, KW, S);
     return SEG_OK;
   }
@@ -728,11 +755,11 @@ int launch_cfg(const ConvK& P0, hipStream_t st) {
     P.tiles_x = cdiv(P.d.Wo, P.lin_tc);
     P.tiles_y = cdiv(P.d.Ho, P.lin_tr);
   }
-  if (P.d.n_count % BN != 0 || P.d.n_split % BN != 0) { seg_set_error("conv: n_count %d / n_split %d not a multiple of BN %d", P.d.n_count, P.d.n_split, BN); return SEG_ERR_ARG; }
+  if (SPLIT ? (P.d.n_count != BN || P.d.n_split * 2 != BN) : (P.d.n_count % BN != 0 || P.d.n_split % BN != 0)) { seg_set_error("conv: n_count %d / n_split %d not a multiple of BN %d", P.d.n_count, P.d.n_split, BN); return SEG_ERR_ARG; }
   if (g_plan_out) { g_plan_out->bm = TH * TW; g_plan_out->bn = BN; g_plan_out->wgs = (long)P.d.B * P.tiles_y * P.tiles_x * (P.d.n_count / BN); return SEG_OK; }
   int gz;
   if (int rc = splitk_grid(P, &gz)) return rc;
-  auto kern = conv_fwd_kernel<Tr<T>::DT, TH, TW, BN, WM, WN, KH, KW, S, POOL, LIN>;
+  auto kern = conv_fwd_kernel<Tr<T>::DT, TH, TW, BN, WM, WN, KH, KW, S, POOL, LIN, SPLIT>;
   static bool attr_done = false;
   if (!attr_done && LDS > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -797,6 +824,13 @@ int launch_k(const ConvK& P, hipStream_t st) {
     }
     seg_set_error("conv: fused max-pool is not available for this layer / tile"); return SEG_ERR_UNSUPPORTED;
   }
+  if constexpr (KH == 3 && KW == 3 && S == 1) {
+    // two destinations of 32 channels each: one 64-channel block per tile (cfg 9; SEG_CONV_SPLIT2=0: two 32-channel blocks)
+    static const bool split2 = !(seg_env("SEG_CONV_SPLIT2") && atoi(seg_env("SEG_CONV_SPLIT2")) == 0);
+    // (automatic for bf16 on big maps: 512^2 step 4.068 -> 4.033 ms, C2 -- 83 k pixels -- unchanged; the f32 instance needs 272 VGPRs)
+    if ((cfg == 9 || (cfg <= 0 && split2 && sizeof(T) == 2 && (long)d.B * d.Ho * d.Wo >= 400000)) && d.n_split == 32 && d.n_count == 64) return launch_cfg<T, 8, 16, 64, 4, 1, KH, KW, S, false, false, true>(P, st);
+    if (cfg == 9) { seg_set_error("conv: cfg 9 is the [32 | 32]-channel two-destination block"); return SEG_ERR_ARG; }
+  }
   if (cfg <= 0) {
     // Tile choice by a two-term cost model calibrated on MI355X micro-benchmarks: a workgroup costs its MACs per
     // K step (BM*BN) plus a fixed part (prologue, first-load latency, epilogue ~ 5000 MAC-equivalents), and the
@@ -816,7 +850,7 @@ int launch_k(const ConvK& P, hipStream_t st) {
       // linearised tiles where the map pads badly into every fixed tile (round 4): at least SEG_CONV_LIN_PCT % (default 13) fewer slots
       static const int lin_pct = seg_env("SEG_CONV_LIN_PCT") ? atoi(seg_env("SEG_CONV_LIN_PCT")) : 13;
       int tr, tc;
-      const long sl = lin_pct > 0 ? lin_pick(d.Ho, d.Wo, &tr, &tc) : -1;
+      const long sl = lin_pct > 0 && sizeof(T) == 2 ? lin_pick(d.Ho, d.Wo, &tr, &tc) : -1;      // (bf16: the f32 64-channel instance needs 264 VGPRs)
       if (sl > 0 && sl * 100 <= waste(d.Ho, d.Wo, TH_[bi], TW_[bi]) * (100 - lin_pct)) { cfg = BN_[bi] == 64 ? 7 : 8; lin = true; }
     }
     if (sizeof(T) == 2 && !lin) {

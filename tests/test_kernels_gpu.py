@@ -61,6 +61,9 @@ def _rand_params(layer, rng, dtype):
     (3, 'SAME', [64], 32, 5, 131, 1, True, 8),           # one-row windows
     (3, 'VALID', [32], 64, 3, 3, 2, True, 8),            # a single output pixel
     (3, 'VALID', [64], 64, 150, 9, 1, True, 7),          # tall and narrow: 18-row windows
+    # [32 | 32]-channel concat input: its two-destination data gradient is ONE 64-channel block per tile (conv_fwd_kernel<.., SPLIT>)
+    (3, 'VALID', [32, 32], 32, 37, 41, 2, True, 9),
+    (3, 'SAME', [32, 32], 64, 18, 23, 3, False, 9),
 ])
 def test_conv_fwd_bwd(dtype, case):
     k, padding, segs, cout, H, W, B, relu, cfg = case
@@ -86,7 +89,7 @@ def test_conv_fwd_bwd(dtype, case):
     Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
     out = net.act(Ho, Wo, cout)
     plan = E.Plan('t')
-    net.conv_fwd(plan, layer, srcs, H, W, out, cfg=cfg)
+    net.conv_fwd(plan, layer, srcs, H, W, out, cfg=0 if cfg == 9 else cfg)
     if cfg in (204, 208):
         assert plan.kernel_name(0).startswith('conv_ring_kernel<%s,' % {204: '8,4,2,2', 208: '8,4,1,4'}[cfg]), plan.kernel_name(0)
     if cfg in (7, 8):
@@ -115,8 +118,11 @@ def test_conv_fwd_bwd(dtype, case):
         dsrc_acts.append(da)
     store.g.zero_()
     bplan = E.Plan('b')
-    net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs, cfg=cfg if cfg >= 100 else (8 if cfg in (7, 8) else 0))
+    net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs, cfg=cfg if cfg >= 100 or cfg == 9 else (8 if cfg in (7, 8) else 0))
     net.flush_reduce(bplan)
+    if cfg == 9:
+        names = [bplan.kernel_name(i) for i, (n, _, _) in enumerate(bplan.ops) if n.endswith('/dx01')]
+        assert len(names) == 1 and names[0].endswith(',split>'), names
     bplan.run(U.stream()); U.sync()
     dw_ref, db_ref = ops.conv2d_wgrad(x, dzv, (k, k), padding, 1)
     dx_ref = ops.conv2d_dgrad(dzv, p['c']['weights'], (H, W), padding, 1)
