@@ -60,7 +60,8 @@ typedef struct seg_conv_desc {
   int32_t relu;            /* fused ReLU                                     */
   int32_t out_f32;         /* store float even when dtype==SEG_BF16 (logits)  */
   int32_t dtype;
-  int32_t cfg;             /* 0 = auto tile choice; else forced config id (tuning/tests) */
+  int32_t cfg;             /* 0 = auto tile choice; else forced config id (tuning/tests): 1-6 fixed tiles, 7 / 8 linearised 128-slot tile x 64 / 32
+                            * channels (3x3/s1), 9 the [32 | 32] two-destination block, 11-24 direct-to-LDS forms, 204 / 208 conv_ring; < 0: auto with staging mode |cfg| */
   int32_t accum;           /* 1: add to what dst already holds (second consumer of a tensor in backward) */
   int32_t n_split;         /* > 0: two destinations in one launch (dgrad of a channel-concat input): out channels
                             * [0, n_split) -> dst / mask, channels [n_split, n_count) -> dst1 / mask1 (as j - n_split).
@@ -465,7 +466,10 @@ int seg_bn_fwd_rows(const seg_view* a, const seg_view* y, const float* beta, flo
 /* slim.batch_norm + the k x k / stride-k slim.max_pool2d behind it (models/deconvolution.py:50-75: bn1 -> pool 2x2, bn2 / bn3 -> pool
  * 3x3) in one pass over `a`: pooled [H/k, W/k] is bit for bit what seg_bn_fwd + seg_maxpool_k_fwd write (normalisation and rounding
  * are increasing maps, so they commute with the maximum) and the normalised full-resolution tensor does not exist;
- * seg_maxpool_k_bwd then takes `a` as its source (the same first maximum).  rows: 0, or the statistics rows already in ws. */
+ * seg_maxpool_k_bwd then takes `a` as its source: it routes to the first STRICT maximum of the raw activation, which is a maximum of
+ * the normalised tensor too -- but where rounding to bf16 collapses distinct values of `a` into a tie, the unfused pair routes to the
+ * first of the tied pixels and this one to the largest `a` among them (same forward bits, a different -- equally valid -- subgradient;
+ * float32 has no such ties in practice).  rows: 0, or the statistics rows already in ws. */
 int seg_bn_pool_fwd(const seg_view* a, const seg_view* pooled, const float* beta, float* moving, float* stats, int32_t training,
                     float decay, float eps, int32_t B, int32_t H, int32_t W, int32_t C, int32_t c_log, float* ws, int32_t rows,
                     int32_t k, int32_t dtype, void* stream);

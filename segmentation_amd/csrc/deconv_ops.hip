@@ -490,7 +490,9 @@ SEG_DEV void lerp_coord(int o, float scale, int n_in, int& i0, int& i1, float& l
 // Batch norm + the k x k / stride-k max-pool behind it in one pass (DeconvModel bn1 -> pool 2x2, bn2 / bn3 -> pool 3x3,
 // models/deconvolution.py:50-75): the normalisation is an increasing map per channel (rstd > 0) and so is the rounding to T, hence
 // max over the window of round(bn(a)) == round(bn(max a)) bit for bit -- the normalised full-resolution tensor is never written or
-// read (it had no other reader: the pool's backward finds the same first maximum in `a`).
+// read (it had no other reader: the pool's backward routes to the first strict maximum of `a`, a maximum of the normalised tensor as
+// well; where bf16 rounding makes a tie of distinct `a` values the unfused pair would pick the first tied pixel instead -- see the
+// header).
 template <typename T>
 __global__ void bn_pool_apply_kernel(seg_view a, seg_view out, const float* stats_g, const float* beta_g, int k, int B, int Ho, int Wo, int C8, int C, int c_log) {
   extern __shared__ float sst[];
