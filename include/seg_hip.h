@@ -61,7 +61,7 @@ typedef struct seg_conv_desc {
   int32_t out_f32;         /* store float even when dtype==SEG_BF16 (logits)  */
   int32_t dtype;
   int32_t cfg;             /* 0 = auto tile choice; else forced config id (tuning/tests): 1-6 fixed tiles, 7 / 8 linearised 128-slot tile x 64 / 32
-                            * channels (3x3/s1), 9 the [32 | 32] two-destination block, 11-24 direct-to-LDS forms, 204 / 208 conv_ring; < 0: auto with staging mode |cfg| */
+                            * channels (3x3/s1), 9 the [32 | 32] two-destination block, 32 / 34 / 38 and 62 / 64 / 68 the multi-tile walk (2 / 4 / 8 tiles x 32 / 64 channels, one K chunk), 11-24 direct-to-LDS forms, 204 / 208 conv_ring; < 0: auto with staging mode |cfg| */
   int32_t accum;           /* 1: add to what dst already holds (second consumer of a tensor in backward) */
   int32_t n_split;         /* > 0: two destinations in one launch (dgrad of a channel-concat input): out channels
                             * [0, n_split) -> dst / mask, channels [n_split, n_count) -> dst1 / mask1 (as j - n_split).

@@ -26,6 +26,7 @@ struct ConvK {          // kernel-side copy of the descriptor (trivially copyabl
   int tiles_x, tiles_y; // spatial tiles per image
   int nchunks0, nchunks; // K chunks from src0 / total
   int lin_tr, lin_tc;   // linearised tile (conv_fwd_kernel<..., LIN>): rows x columns of the window, lin_tr * lin_tc <= 128 pixel slots
+  int ntw;              // conv_fwd_mt_kernel: consecutive tiles per workgroup
 };
 
 // ---- epilogue: bias, ReLU, ReLU-grad mask, store 8 channels per lane ----
@@ -521,6 +522,151 @@ void conv_fwd_kernel(const ConvK P) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Multi-tile form of the 8 x 16 tiled kernel for layers with ONE K chunk (32 input channels: the full-resolution maps, 3x3 / stride 1):
+// a workgroup walks P.ntw consecutive tiles; the filter rows are staged once, and the NEXT tile's patch is requested before the MFMAs
+// of the current tile, so that it is in flight during this tile's MFMAs and epilogue (mask loads, stores).  These layers are bound by
+// how many bytes a CU keeps in flight (four workgroups x one patch each), not by the MFMAs.  No split K, no fused pool.
+// ---------------------------------------------------------------------------------------------------------
+template <int DT, int BN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_min_waves(DT, 128, BN))))
+void conv_fwd_mt_kernel(const ConvK P) {
+  using T = typename DtSel<DT>::type;
+  using TT = Tr<T>;
+  constexpr int TH = 8, TW = 16, WM = 4, WN = 1, KH = 3, KW = 3, BM = TH * TW;
+  constexpr int PH = TH + 2, PW = TW + 2, NPIX = PH * PW, NT = 9;
+  constexpr int PIECES = TT::PIECES, EPP = TT::EPP, RSTR = TT::RSTR;
+  constexpr int PATCH_BYTES = ((NPIX * RSTR + 15) / 16) * 16;
+  constexpr int NPP = (NPIX * PIECES + 255) / 256;
+  constexpr int NWP = (NT * BN * PIECES + 255) / 256;
+  constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sP = smem;
+  char* sW = smem + PATCH_BYTES;
+  float* sB = reinterpret_cast<float*>(smem + PATCH_BYTES + NT * BN * RSTR);
+
+  seg_conv_desc d = P.d;
+  conv_signal(d);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave, wn = 0;
+  const int lr = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.y * BN;
+  select_dst(d, n0);
+  const float bias_r = bias_fetch<BN>(d, n0, tid);
+  const int ntiles = d.B * P.tiles_y * P.tiles_x;
+  const int t_first = blockIdx.x * P.ntw;
+  const int t_last = t_first + P.ntw < ntiles ? t_first + P.ntw : ntiles;
+
+  int p_lds[NPP], p_off[NPP];                     // staging descriptors of the tile being REQUESTED (p_off: -1 = zero fill)
+  const T* src = nullptr;
+  auto tile_coords = [&](int t, int& b, int& oy0, int& ox0) {
+    const int tx = t % P.tiles_x; t /= P.tiles_x;
+    const int ty = t % P.tiles_y; b = t / P.tiles_y;
+    oy0 = ty * TH; ox0 = tx * TW;
+  };
+  u32x4 rp[NPP];
+  auto request = [&](int t) {                      // descriptors + loads of tile t's patch
+    int b, oy0, ox0;
+    tile_coords(t, b, oy0, ox0);
+    src = reinterpret_cast<const T*>(d.src0.ptr) + (int64_t)b * d.src0.H * d.src0.W * d.src0.cs;
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+      const int idx = tid + i * 256;
+      p_off[i] = -1;
+      rp[i] = u32x4{0, 0, 0, 0};
+      if (idx < NPIX * PIECES) {
+        const int q = idx / PIECES, h = idx % PIECES;
+        const int py = q / PW, px = q % PW;
+        const int iy = oy0 - d.pad_t + py, ix = ox0 - d.pad_l + px;
+        if (iy >= 0 && iy < d.Hi && ix >= 0 && ix < d.Wi) {
+          p_off[i] = ((iy + d.src0.oy) * d.src0.W + ix + d.src0.ox) * d.src0.cs + d.src0.coff + h * EPP;
+          rp[i] = *reinterpret_cast<const u32x4*>(src + p_off[i]);
+        }
+      }
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < NPP; ++i) { const int idx = tid + i * 256; p_lds[i] = idx < NPIX * PIECES ? TT::lds_off(idx / PIECES, idx % PIECES) : -1; }
+  request(t_first);
+  {
+    // the filter rows of the single chunk: staged once
+    const T* wp = reinterpret_cast<const T*>(d.w_packed);
+    u32x4 rw[NWP];
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+      const int idx = tid + i * 256;
+      if (NT * BN * PIECES % 256 == 0 || idx < NT * BN * PIECES) {
+        const int tap = idx / (BN * PIECES), row = (idx / PIECES) % BN, h = idx % PIECES;
+        rw[i] = *reinterpret_cast<const u32x4*>(wp + ((int64_t)tap * d.n_total + d.n_off + n0 + row) * 32 + h * EPP);
+      }
+    }
+    bias_to_lds<BN>(bias_r, tid, sB);
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+      const int idx = tid + i * 256;
+      if (NT * BN * PIECES % 256 == 0 || idx < NT * BN * PIECES) {
+        const int tap = idx / (BN * PIECES), row = (idx / PIECES) % BN, h = idx % PIECES;
+        *reinterpret_cast<u32x4*>(sW + TT::lds_off(tap * BN + row, h)) = rw[i];
+      }
+    }
+  }
+  int a_addr[FN];
+#pragma unroll
+  for (int fn = 0; fn < FN; ++fn) a_addr[fn] = frag_addr<T>(wn * (BN / WN) + fn * 16 + lr, g);
+  int b_addr[NT][FM];
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm) {
+    const int m = wm * (BM / WM) + fm * 16 + lr;
+    const int py = m / TW, px = m % TW;
+#pragma unroll
+    for (int u = 0; u < KH; ++u)
+#pragma unroll
+      for (int v = 0; v < KW; ++v) b_addr[u * KW + v][fm] = frag_addr<T>((py + u) * PW + px + v, g);
+  }
+  for (int t = t_first; t < t_last; ++t) {
+    int b, oy0, ox0;
+    tile_coords(t, b, oy0, ox0);
+    __syncthreads();                               // every wave is behind its LDS reads of the previous tile
+#pragma unroll
+    for (int i = 0; i < NPP; ++i)
+      if (p_lds[i] >= 0) *reinterpret_cast<u32x4*>(sP + p_lds[i]) = rp[i];
+    __syncthreads();
+    EpiCtx<FN / 2> epi;
+    epi_setup<BN, WN, FN / 2>(d, n0, wn, g, epi, sB);
+    EpiPre<T, FN / 2, FM> pre;
+    epi_issue<T, TH, TW, BN, WM, FM, FN>(d, epi, b, oy0, ox0, wm, lr, pre);
+    if (t + 1 < t_last) request(t + 1);            // in flight during this tile's MFMAs and stores
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = f32x4{0, 0, 0, 0};
+    {
+      Frag<T> fa[2][FN], fb[2][FM];
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) fa[0][fn] = lds_read_frag_at<T>(sW + a_addr[fn]);
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) fb[0][fm] = lds_read_frag_at<T>(sP + b_addr[0][fm]);
+#pragma unroll
+      for (int tap = 0; tap < NT; ++tap) {
+        if (tap + 1 < NT) {
+#pragma unroll
+          for (int fn = 0; fn < FN; ++fn) fa[(tap + 1) & 1][fn] = lds_read_frag_at<T>(sW + a_addr[fn] + (tap + 1) * BN * RSTR);
+#pragma unroll
+          for (int fm = 0; fm < FM; ++fm) fb[(tap + 1) & 1][fm] = lds_read_frag_at<T>(sP + b_addr[tap + 1 < NT ? tap + 1 : 0][fm]);
+        }
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+          for (int fm = 0; fm < FM; ++fm) mma32(acc[fn][fm], fa[tap & 1][fn], fb[tap & 1][fm]);
+      }
+    }
+    epi_bias<BN, WN, FN / 2>(sB, wn, g, epi);
+    conv_epilogue<T, TH, TW, BN, WM, WN, FM, FN>(d, acc, epi, pre, b, oy0, ox0, wm, lr);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // bf16 fast path: same tiling, but the patch and filter rows go global -> LDS directly (global_load_lds_dwordx4,
 // no staging VGPRs, no ds_write), into TWO LDS buffers: chunk c+1 is in flight while chunk c feeds the MFMAs, one
 // barrier per chunk.  The LDS image of a load is lane-linear (wave base + lane*16), so the bank swizzle of
@@ -772,6 +918,33 @@ int launch_cfg(const ConvK& P0, hipStream_t st) {
   return seg_check_launch("conv_fwd");
 }
 
+template <typename T, int BN>
+int launch_mt(const ConvK& P0, int ntw, hipStream_t st) {
+  using TT = Tr<T>;
+  if (g_name_out) { snprintf(g_name_out, g_name_cap, "conv_fwd_mt_kernel<%s,%d>", sizeof(T) == 2 ? "bf16" : "f32", BN); return SEG_OK; }
+  constexpr int PATCH_BYTES = ((10 * 18 * TT::RSTR + 15) / 16) * 16;
+  constexpr int LDS = PATCH_BYTES + 9 * BN * TT::RSTR + BN * 4;
+  ConvK P = P0;
+  P.tiles_x = cdiv(P.d.Wo, 16);
+  P.tiles_y = cdiv(P.d.Ho, 8);
+  P.lin_tr = P.lin_tc = 0;
+  P.ntw = ntw;
+  if (P.d.n_count % BN != 0 || P.d.n_split % BN != 0 || P.d.ksplit > 1 || ntw < 1 || P.nchunks != 1) { seg_set_error("conv (multi-tile): n_count %d / n_split %d / ksplit %d / %d K chunks", P.d.n_count, P.d.n_split, P.d.ksplit, P.nchunks); return SEG_ERR_ARG; }
+  const long ntiles = (long)P.d.B * P.tiles_y * P.tiles_x;
+  if (g_plan_out) { g_plan_out->bm = 128; g_plan_out->bn = BN; g_plan_out->wgs = ntiles * (P.d.n_count / BN); return SEG_OK; }
+  auto kern = conv_fwd_mt_kernel<Tr<T>::DT, BN>;
+  static bool attr_done = false;
+  if (!attr_done && LDS > 48 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      seg_set_error("conv: cannot raise dynamic LDS to %d", LDS); return SEG_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  dim3 grid((unsigned)cdiv(ntiles, ntw), P.d.n_count / BN, 1);
+  SEG_LAUNCH(kern, grid, dim3(256), LDS, st, P);
+  return seg_check_launch("conv_fwd_mt");
+}
+
 template <int TH, int TW, int BN, int WM, int WN, int KH, int KW, int S, int NBUF = 2>
 int launch_glds(const ConvK& P0, hipStream_t st) {
   if (g_name_out) {
@@ -853,6 +1026,16 @@ int launch_k(const ConvK& P, hipStream_t st) {
       const long sl = lin_pct > 0 && sizeof(T) == 2 ? lin_pick(d.Ho, d.Wo, &tr, &tc) : -1;      // (bf16: the f32 64-channel instance needs 264 VGPRs)
       if (sl > 0 && sl * 100 <= waste(d.Ho, d.Wo, TH_[bi], TW_[bi]) * (100 - lin_pct)) { cfg = BN_[bi] == 64 ? 7 : 8; lin = true; }
     }
+    if constexpr (KH == 3 && KW == 3 && S == 1 && sizeof(T) == 2) {
+      // multi-tile walk (conv_fwd_mt_kernel) for the maps with one K chunk and at least SEG_CONV_NTW_MIN workgroups: SEG_CONV_NTW tiles
+      // per workgroup (0 / 1 = off).  512^2 step 3.993 -> 3.948 ms with 2 (4: 3.946), C2 0.9695 -> 0.9667, inference 256^2 x 32 +0.8 %,
+      // FCN-8s / DeconvModel unchanged (profiles/r04_ab_mt_*.txt)
+      static const int ntw_env = seg_env("SEG_CONV_NTW") ? atoi(seg_env("SEG_CONV_NTW")) : 2;
+      static const int ntw_min = seg_env("SEG_CONV_NTW_MIN") ? atoi(seg_env("SEG_CONV_NTW_MIN")) : 512;
+      const long nwg = (long)d.B * cdiv(d.Ho, 8) * cdiv(d.Wo, 16) * (d.n_count / BN_[bi]);
+      if (ntw_env > 1 && !lin && (cfg == 1 || cfg == 2) && !d.up2 && d.ksplit <= 1 && P.nchunks == 1 && nwg >= ntw_min && !g_plan_out)
+        return cfg == 1 ? launch_mt<T, 64>(P, ntw_env, st) : launch_mt<T, 32>(P, ntw_env, st);
+    }
     if (sizeof(T) == 2 && !lin) {
       // bf16: direct-to-LDS double-buffered variants.  SEG_CONV_MODE: 0 = never, 1 = always, 2 = always + 256-pixel
       // tile on maps >= 32 wide, 3 (default) = only for the 64-pixel tiles, 4 = single-buffered direct-to-LDS everywhere (fastest stand-alone:
@@ -875,6 +1058,9 @@ int launch_k(const ConvK& P, hipStream_t st) {
     default: break;
   }
   if constexpr (KH == 3 && KW == 3 && S == 1) {
+    // 32 / 34 / 38: the multi-tile walk for one-chunk layers, 32-channel blocks, 2 / 4 / 8 tiles per workgroup; 62 / 64 / 68: 64-channel blocks
+    if (cfg == 32 || cfg == 34 || cfg == 38) return launch_mt<T, 32>(P, cfg - 30, st);
+    if (cfg == 62 || cfg == 64 || cfg == 68) return launch_mt<T, 64>(P, cfg - 60, st);
     if (cfg == 7) return launch_cfg<T, 8, 16, 64, 4, 1, KH, KW, S, false, true>(P, st);   // 128 linearised slots x 64 ch
     if (cfg == 8) return launch_cfg<T, 8, 16, 32, 4, 1, KH, KW, S, false, true>(P, st);   // 128 linearised slots x 32 ch
   }

@@ -61,13 +61,19 @@ def _rand_params(layer, rng, dtype):
     (3, 'SAME', [64], 32, 5, 131, 1, True, 8),           # one-row windows
     (3, 'VALID', [32], 64, 3, 3, 2, True, 8),            # a single output pixel
     (3, 'VALID', [64], 64, 150, 9, 1, True, 7),          # tall and narrow: 18-row windows
+    # multi-tile walk of the one-chunk layers (conv_fwd_mt_kernel: cfg 32 / 34 / 38 = 2 / 4 / 8 tiles per workgroup x 32 channels, 62 / 64 = x 64)
+    (3, 'VALID', [32], 32, 37, 41, 2, True, 32),
+    (3, 'SAME', [32], 32, 40, 75, 3, True, 34),          # 5 x 5 tiles per image: workgroups span images, the last one is short
+    (3, 'VALID', [32], 64, 21, 150, 1, False, 62),
+    (3, 'SAME', [17], 64, 9, 11, 2, True, 64),           # fewer tiles than a workgroup walks
+    (3, 'VALID', [32], 32, 70, 70, 2, True, 38),
     # [32 | 32]-channel concat input: its two-destination data gradient is ONE 64-channel block per tile (conv_fwd_kernel<.., SPLIT>)
     (3, 'VALID', [32, 32], 32, 37, 41, 2, True, 9),
     (3, 'SAME', [32, 32], 64, 18, 23, 3, False, 9),
 ])
 def test_conv_fwd_bwd(dtype, case):
     k, padding, segs, cout, H, W, B, relu, cfg = case
-    if cfg > 10 and dtype != L.SEG_BF16:
+    if cfg > 10 and dtype != L.SEG_BF16 and cfg not in (32, 34, 38, 62, 64, 68):
         pytest.skip('direct-to-LDS / persistent variants are bf16 only')
     rng = np.random.default_rng(k * 7919 + sum(segs) * 31 + cout * 17 + H * 5 + W + cfg)
     layer = E.Layer('c', 'conv', k, segs, cout, padding, relu)
@@ -94,6 +100,8 @@ def test_conv_fwd_bwd(dtype, case):
         assert plan.kernel_name(0).startswith('conv_ring_kernel<%s,' % {204: '8,4,2,2', 208: '8,4,1,4'}[cfg]), plan.kernel_name(0)
     if cfg in (7, 8):
         assert ',lin128,%d,' % {7: 64, 8: 32}[cfg] in plan.kernel_name(0), plan.kernel_name(0)
+    if cfg in (32, 34, 38, 62, 64):
+        assert plan.kernel_name(0).startswith('conv_fwd_mt_kernel<'), plan.kernel_name(0)
     plan.run(U.stream()); U.sync()
     ref = ops.conv2d(x, p['c']['weights'], p['c']['biases'], padding, 1, relu)
     got = U.read_act(out)
@@ -118,7 +126,7 @@ def test_conv_fwd_bwd(dtype, case):
         dsrc_acts.append(da)
     store.g.zero_()
     bplan = E.Plan('b')
-    net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs, cfg=cfg if cfg >= 100 or cfg == 9 else (8 if cfg in (7, 8) else 0))
+    net.conv_bwd(bplan, layer, srcs, H, W, dz, dspecs, cfg=cfg if cfg >= 100 or cfg == 9 else (8 if cfg in (7, 8) else (cfg if cfg in (32, 34, 38) and cout == 32 else 0)))
     net.flush_reduce(bplan)
     if cfg == 9:
         names = [bplan.kernel_name(i) for i, (n, _, _) in enumerate(bplan.ops) if n.endswith('/dx01')]
